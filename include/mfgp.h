@@ -1,0 +1,132 @@
+/*
+ * mfgp.h -- C-ABI of libmfgp_hip.so: the MI355X (gfx950) exact-GP engine that sits where the
+ * reference delegates to GPy.
+ *
+ * The reference has no FFI of its own: its "engine boundary" is the slice of the GPy object API
+ * that src/abstractMFGP.py and src/MFDataFusion.py touch.  Every entry point below names the
+ * reference call site (file:line under /root/reference) whose work it replaces.  The Python shim
+ * (multifidelity_datafusion_gps_amd/engine.py) binds these with ctypes.CDLL; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = OK; >0 = LAPACK-style info (1-based index of the first
+ *     non-positive pivot met by the Cholesky); <0 = argument / HIP error (text via mfgp_last_error).
+ *   - all matrices are row-major (C order) fp64, caller-owned HOST buffers unless a name says "dev";
+ *     the library copies what it needs and owns every device allocation behind the opaque handle.
+ *   - hyper-parameters cross the boundary in natural units (variance, lengthscale, noise variance);
+ *     the positivity transforms stay in Python (reference: paramz Logexp, [GPy-recall]).
+ *   - a handle is bound to one device and one HIP stream and is not thread-safe; distinct handles may
+ *     be driven from distinct threads / processes (one process per GPU is the multi-GPU model).
+ */
+#ifndef MFGP_H
+#define MFGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mfgp_handle mfgp_handle;
+
+/* kernel-part types: GPy.kern.RBF / Matern32 / Matern52 (src/abstractMFGP.py:60, :62 kern_class1..3) */
+enum { MFGP_KERN_RBF = 0, MFGP_KERN_MATERN32 = 1, MFGP_KERN_MATERN52 = 2 };
+
+/*
+ * One stationary factor k_f(x,x') = variance_f * shape_f(|x[c0:c1]-x'[c0:c1]| / lengthscale_f).
+ * The covariance is   K = sum over distinct `term` ids of ( product of the factors with that id ),
+ * which covers GPy.kern.RBF(D) (one factor, one term; src/abstractMFGP.py:59-60) and the NARGP
+ * composite kern1*kern2 + kern3 with active_dims column slices (src/abstractMFGP.py:73-80).
+ * Parameter vector layout used by every call: theta[2*f] = variance_f, theta[2*f+1] = lengthscale_f.
+ */
+typedef struct mfgp_kern_part {
+    int32_t type;      /* MFGP_KERN_* */
+    int32_t col_begin; /* active_dims = [col_begin, col_end) */
+    int32_t col_end;
+    int32_t term;      /* factors sharing a term id are multiplied; terms are summed; ids ascending */
+} mfgp_kern_part;
+
+#define MFGP_MAX_PARTS 6
+
+/* hipEvent stage timers of the most recent mfgp_eval / mfgp_predict (milliseconds) and the
+ * algorithmic work of the two single-launch kernels the bench reports rooflines for. */
+typedef struct mfgp_timings {
+    double kbuild_ms;    /* K(X,X)+noise lower-triangle build: ONE launch of mfgp_kbuild_tri_f64      */
+    double cholinv_ms;   /* recursive Cholesky + triangular inverse (leaf kernels + MFMA tile GEMMs)  */
+    double solve_ms;     /* z = L^-1 y, alpha = L^-T z, log-det, quadratic form                        */
+    double kinv_ms;      /* K^-1 = L^-T L^-1 lower triangle: ONE launch of the MFMA tile-GEMM kernel   */
+    double grad_ms;      /* fused dNLML/dtheta reduction over the lower triangle                       */
+    double predict_panel_ms; /* K(X*,X) panel + mean GEMV                                              */
+    double predict_var_ms;   /* V = K(X*,X) L^-T (MFMA) + row sum of squares                           */
+    double total_ms;     /* first event -> last event of the call                                       */
+    double kbuild_bytes; /* algorithmic bytes of the K-build launch (4*Np*(Np+128) B)      */
+    double kinv_flops;   /* algorithmic flops of the K^-1 launch (Np^3/3)                               */
+    double cholinv_flops;/* 2*Np^3/3                                                                    */
+    int64_t n_launches;  /* kernel launches issued by the call                                          */
+} mfgp_timings;
+
+/* ---- lifecycle --------------------------------------------------------------------------------- */
+
+/* create an engine on HIP device `device_id` (one stream). Fails loudly (<0) when no HIP device. */
+int32_t mfgp_create(int32_t device_id, mfgp_handle** out);
+int32_t mfgp_destroy(mfgp_handle* h);
+/* text of the last error on this handle (or a global one when h == NULL); owned by the library */
+const char* mfgp_last_error(mfgp_handle* h);
+/* library / device identification string ("mfgp_hip gfx950 <device name> CUs=..") */
+const char* mfgp_device_info(mfgp_handle* h);
+
+/* replaces GPy.models.GPRegression(X=, Y=, kernel=) data capture
+ * (src/MFDataFusion.py:93-98, src/abstractMFGP.py:100-102): one upload per fit.
+ * X is (N, D) row-major, Y is (N,) [the reference's (N,1) column]. */
+int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, const double* Y);
+
+/* replaces the kernel objects built at src/abstractMFGP.py:51-80 (RBF / Prod / Add with active_dims) */
+int32_t mfgp_set_kernel(mfgp_handle* h, const mfgp_kern_part* parts, int32_t n_parts);
+
+/* ---- hot calls --------------------------------------------------------------------------------- */
+
+/* One objective(+gradient) evaluation = what every paramz/GPy parameter change triggers
+ * (ExactGaussianInference.inference behind src/abstractMFGP.py:103,132-137; src/MFDataFusion.py:93-100):
+ *   Ky = K(theta) + (noise + jitter) I ; L = chol(Ky) ; alpha = Ky^-1 y ; logdet ;
+ *   nlml = 0.5*(N log 2pi + logdet + y^T alpha) ;
+ *   want_grad: grad[2f], grad[2f+1] = dNLML/d variance_f, d lengthscale_f ; grad[2*n_parts] = dNLML/d noise.
+ * theta has 2*n_parts entries.  GPy adds 1e-8 to the diagonal itself; pass it (plus any jitchol
+ * retry jitter) as `jitter`.  Returns >0 (pivot index) when Ky is not positive definite. */
+int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitter,
+                  int32_t want_grad, double* nlml, double* grad);
+
+/* the pieces of mfgp_eval, for callers that want them separately (same state machine) */
+int32_t mfgp_factorize(mfgp_handle* h, const double* theta, double noise, double jitter);
+int32_t mfgp_nlml(mfgp_handle* h, double* value);
+int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad);
+
+/* replaces hf_model.predict(X*) / lf_model.predict(t) (src/MFDataFusion.py:156, src/abstractMFGP.py:104,114):
+ * mean = K(X*,X) alpha ; var = kdiag(X*) - rowsum((K(X*,X) L^-T)^2), floored at 1e-15,
+ * + noise when include_noise (GPy's predict() default).  Needs a successful mfgp_factorize/mfgp_eval.
+ * var may be NULL when want_var == 0. */
+int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double* mean, double* var,
+                     int32_t want_var, int32_t include_noise);
+
+/* ---- parity / debug read-back (host buffers sized N*N, N) ---------------------------------------- */
+int32_t mfgp_get_K(mfgp_handle* h, double* out);      /* K(X,X) WITHOUT noise, full symmetric (rebuilt)  */
+int32_t mfgp_get_L(mfgp_handle* h, double* out);      /* lower Cholesky factor of Ky, zeros above diag   */
+int32_t mfgp_get_Linv(mfgp_handle* h, double* out);   /* L^-1 lower                                       */
+int32_t mfgp_get_Kinv(mfgp_handle* h, double* out);   /* Ky^-1 full symmetric (valid after a gradient)    */
+int32_t mfgp_get_alpha(mfgp_handle* h, double* out);  /* alpha (N)                                        */
+int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out);
+
+/* ---- kernel-level test hooks (tests/ only) -------------------------------------------------------- */
+/* C = alpha * A B^T + beta * C on Mp x Np x Kp host matrices (multiples of 128) through the MFMA
+ * tile-GEMM kernel; tile = 128 or 64. */
+int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, double* C, int32_t M,
+                         int32_t N, int32_t K, double alpha, double beta, int32_t tile);
+/* Cholesky + inverse of one SPD 128x128 block through the leaf kernel: Lout, Xout are 128x128. */
+int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xout, double* logdet_half);
+/* peak probes: returns achieved TFLOP/s of a bare v_mfma_f64_16x16x4_f64 loop and GB/s of a
+ * 1 GiB device copy (used by bench.py to sanity-check the roofline denominators). */
+int32_t mfgp_dbg_probe(mfgp_handle* h, double* mfma_f64_tflops, double* copy_gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFGP_H */

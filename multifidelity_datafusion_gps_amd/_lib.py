@@ -1,0 +1,257 @@
+"""ctypes binding of libmfgp_hip.so (the C-ABI declared in include/mfgp.h).
+
+This is the whole Python<->HIP boundary: plain pointers and sizes, no torch types.  The library is
+the product -- there is no CPU fallback: if it is missing or no HIP device is present, loading /
+`Engine()` raises `EngineUnavailable` loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfgp_hip.so")
+
+KERN_RBF, KERN_MATERN32, KERN_MATERN52 = 0, 1, 2
+MAX_PARTS = 6
+
+# every symbol include/mfgp.h declares (tests check the .so exports each of them)
+EXPORTED_SYMBOLS = [
+    "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
+    "mfgp_set_kernel", "mfgp_eval", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_predict",
+    "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
+    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_probe",
+]
+
+
+class EngineUnavailable(RuntimeError):
+    """libmfgp_hip.so is missing / not loadable, or there is no HIP device."""
+
+
+class NotPositiveDefinite(np.linalg.LinAlgError):
+    """The Cholesky met a non-positive pivot (status > 0 = 1-based pivot index)."""
+
+    def __init__(self, info, msg=""):
+        super().__init__(msg or "not positive definite (pivot %d)" % info)
+        self.info = info
+
+
+class KernPart(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int32), ("col_begin", ctypes.c_int32), ("col_end", ctypes.c_int32),
+                ("term", ctypes.c_int32)]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in (
+        "kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms", "grad_ms", "predict_panel_ms", "predict_var_ms",
+        "total_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops")] + [("n_launches", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the engine (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise EngineUnavailable(
+            "%s not found: build it with `python -m multifidelity_datafusion_gps_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise EngineUnavailable("cannot load %s: %s" % (p, e)) from e
+    H = ctypes.c_void_p
+    dp = ctypes.POINTER(ctypes.c_double)
+    i32, i64, f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    protos = {
+        "mfgp_create": (i32, [i32, ctypes.POINTER(H)]),
+        "mfgp_destroy": (i32, [H]),
+        "mfgp_last_error": (ctypes.c_char_p, [H]),
+        "mfgp_device_info": (ctypes.c_char_p, [H]),
+        "mfgp_set_data": (i32, [H, dp, i64, i32, dp]),
+        "mfgp_set_kernel": (i32, [H, ctypes.POINTER(KernPart), i32]),
+        "mfgp_eval": (i32, [H, dp, f64, f64, i32, dp, dp]),
+        "mfgp_factorize": (i32, [H, dp, f64, f64]),
+        "mfgp_nlml": (i32, [H, dp]),
+        "mfgp_nlml_grad": (i32, [H, dp]),
+        "mfgp_predict": (i32, [H, dp, i64, dp, dp, i32, i32]),
+        "mfgp_get_K": (i32, [H, dp]),
+        "mfgp_get_L": (i32, [H, dp]),
+        "mfgp_get_Linv": (i32, [H, dp]),
+        "mfgp_get_Kinv": (i32, [H, dp]),
+        "mfgp_get_alpha": (i32, [H, dp]),
+        "mfgp_get_timings": (i32, [H, ctypes.POINTER(Timings)]),
+        "mfgp_dbg_gemm_nt": (i32, [H, dp, dp, dp, i32, i32, i32, f64, f64, i32]),
+        "mfgp_dbg_leaf": (i32, [H, dp, dp, dp, dp]),
+        "mfgp_dbg_probe": (i32, [H, dp, dp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Engine:
+    """One engine handle = one HIP device + stream + the device-resident state of one GP level."""
+
+    def __init__(self, device=None):
+        self._lib = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self._h = ctypes.c_void_p()
+        rc = self._lib.mfgp_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.mfgp_last_error(None).decode()
+            self._h = None
+            raise EngineUnavailable("mfgp_create(device=%d) failed (%d): %s" % (device, rc, msg))
+        self.device = device
+        self.n = 0
+        self.n_parts = 0
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mfgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, who):
+        if rc == 0:
+            return
+        msg = self._lib.mfgp_last_error(self._h).decode()
+        if rc > 0:
+            raise NotPositiveDefinite(rc, "%s: %s" % (who, msg))
+        raise RuntimeError("%s failed (%d): %s" % (who, rc, msg))
+
+    @property
+    def device_info(self):
+        return self._lib.mfgp_device_info(self._h).decode()
+
+    # -- state ----------------------------------------------------------------------------------
+    def set_data(self, X, Y):
+        X = _c64(X)
+        Y = _c64(Y).reshape(-1)
+        if X.ndim != 2 or Y.shape[0] != X.shape[0]:
+            raise ValueError("X must be (N, D) and Y (N,) / (N, 1)")
+        self._check(self._lib.mfgp_set_data(self._h, _dptr(X), X.shape[0], X.shape[1], _dptr(Y)), "mfgp_set_data")
+        self.n, self.d = X.shape
+
+    def set_kernel(self, parts):
+        """parts: iterable of (type, col_begin, col_end, term)."""
+        parts = list(parts)
+        arr = (KernPart * len(parts))(*[KernPart(*map(int, p)) for p in parts])
+        self._check(self._lib.mfgp_set_kernel(self._h, arr, len(parts)), "mfgp_set_kernel")
+        self.n_parts = len(parts)
+
+    # -- hot calls ------------------------------------------------------------------------------
+    def eval(self, theta, noise, jitter=1e-8, want_grad=True):
+        theta = _c64(theta).reshape(-1)
+        if theta.shape[0] != 2 * self.n_parts:
+            raise ValueError("theta must have 2*n_parts entries")
+        nlml = ctypes.c_double()
+        grad = np.zeros(2 * self.n_parts + 1)
+        rc = self._lib.mfgp_eval(self._h, _dptr(theta), float(noise), float(jitter), int(bool(want_grad)),
+                                 ctypes.byref(nlml), _dptr(grad))
+        self._check(rc, "mfgp_eval")
+        return (nlml.value, grad) if want_grad else nlml.value
+
+    def factorize(self, theta, noise, jitter=1e-8):
+        theta = _c64(theta).reshape(-1)
+        self._check(self._lib.mfgp_factorize(self._h, _dptr(theta), float(noise), float(jitter)), "mfgp_factorize")
+
+    def nlml(self):
+        v = ctypes.c_double()
+        self._check(self._lib.mfgp_nlml(self._h, ctypes.byref(v)), "mfgp_nlml")
+        return v.value
+
+    def nlml_grad(self):
+        g = np.zeros(2 * self.n_parts + 1)
+        self._check(self._lib.mfgp_nlml_grad(self._h, _dptr(g)), "mfgp_nlml_grad")
+        return g
+
+    def predict(self, Xstar, want_var=True, include_noise=True):
+        Xs = _c64(Xstar)
+        if Xs.ndim != 2 or Xs.shape[1] != self.d:
+            raise ValueError("Xstar must be (N*, %d)" % self.d)
+        mean = np.empty(Xs.shape[0])
+        var = np.empty(Xs.shape[0]) if want_var else None
+        rc = self._lib.mfgp_predict(self._h, _dptr(Xs), Xs.shape[0], _dptr(mean),
+                                    _dptr(var) if want_var else None, int(bool(want_var)), int(bool(include_noise)))
+        self._check(rc, "mfgp_predict")
+        return mean, var
+
+    # -- read-back ------------------------------------------------------------------------------
+    def _get_mat(self, fn, who):
+        out = np.empty((self.n, self.n))
+        self._check(fn(self._h, _dptr(out)), who)
+        return out
+
+    def get_K(self):
+        return self._get_mat(self._lib.mfgp_get_K, "mfgp_get_K")
+
+    def get_L(self):
+        return self._get_mat(self._lib.mfgp_get_L, "mfgp_get_L")
+
+    def get_Linv(self):
+        return self._get_mat(self._lib.mfgp_get_Linv, "mfgp_get_Linv")
+
+    def get_Kinv(self):
+        return self._get_mat(self._lib.mfgp_get_Kinv, "mfgp_get_Kinv")
+
+    def get_alpha(self):
+        out = np.empty(self.n)
+        self._check(self._lib.mfgp_get_alpha(self._h, _dptr(out)), "mfgp_get_alpha")
+        return out
+
+    def timings(self):
+        t = Timings()
+        self._check(self._lib.mfgp_get_timings(self._h, ctypes.byref(t)), "mfgp_get_timings")
+        return t.as_dict()
+
+    # -- kernel-level test hooks ----------------------------------------------------------------
+    def dbg_gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, tile=128):
+        A, B = _c64(A), _c64(B)
+        C = np.array(C, dtype=np.float64, order="C", copy=True)
+        M, K = A.shape
+        N = B.shape[0]
+        self._check(self._lib.mfgp_dbg_gemm_nt(self._h, _dptr(A), _dptr(B), _dptr(C), M, N, K, float(alpha),
+                                               float(beta), int(tile)), "mfgp_dbg_gemm_nt")
+        return C
+
+    def dbg_leaf(self, A):
+        A = _c64(A)
+        L = np.empty((128, 128))
+        X = np.empty((128, 128))
+        ld = ctypes.c_double()
+        rc = self._lib.mfgp_dbg_leaf(self._h, _dptr(A), _dptr(L), _dptr(X), ctypes.byref(ld))
+        if rc < 0:
+            self._check(rc, "mfgp_dbg_leaf")
+        return L, X, ld.value, rc
+
+    def dbg_probe(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.mfgp_dbg_probe(self._h, ctypes.byref(a), ctypes.byref(b)), "mfgp_dbg_probe")
+        return a.value, b.value

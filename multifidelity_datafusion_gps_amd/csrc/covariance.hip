@@ -1,0 +1,383 @@
+// covariance.hip -- covariance-matrix construction and the fused NLML-gradient reduction.
+//
+// Replaces GPy's RBF.K / Matern32.K / Matern52.K, Prod.K, Add.K (call sites
+// src/abstractMFGP.py:60,77-80) and kern.update_gradients_full + Gaussian.exact_inference_gradients
+// (a8).  GPy forms r^2 as |x|^2+|x'|^2-2x.x' through a DGEMM and several N^2 temporaries; here each
+// 64x64 output tile stages its two 64xD row blocks of X in LDS (transposed, so a thread reads its
+// 4 rows / 4 columns with wide conflict-free LDS reads) and accumulates the squared differences
+// directly -- one pass, 8 B written per element, nothing else touches HBM.
+//
+// Covariance structure (mfgp_kern_part): K = sum_terms prod_{f in term} var_f * shape_f(r_f / l_f),
+// r_f^2 over the factor's column range; factors with the same range share r^2 ("leader").
+#include "mfgp_internal.h"
+
+namespace mfgp {
+
+constexpr int KT = 64;        // tile edge
+constexpr int XP = KT + 2;    // LDS pitch of the transposed X blocks
+constexpr int MAXG = MFGP_MAX_GROUPS;  // distinct column ranges supported
+
+struct FactorConst {
+    double var[MFGP_MAX_PARTS];
+    double inv_l2[MFGP_MAX_PARTS];
+};
+
+__device__ __forceinline__ void load_consts(const KernSpecDev& sp, const double* params, FactorConst& fc) {
+#pragma unroll
+    for (int f = 0; f < MFGP_MAX_PARTS; ++f) {
+        if (f < sp.nf) {
+            fc.var[f] = params[2 * f];
+            const double l = params[2 * f + 1];
+            fc.inv_l2[f] = 1.0 / (l * l);
+        } else {
+            fc.var[f] = 0.0;
+            fc.inv_l2[f] = 0.0;
+        }
+    }
+}
+
+// value of one factor (without its variance) and, optionally, g = (dk/dl) * l / k
+template <bool GRAD>
+__device__ __forceinline__ double shape_eval(int type, double rs2, double& g) {
+    if (type == MFGP_KERN_RBF) {
+        if (GRAD) g = rs2;
+        return exp(-0.5 * rs2);
+    } else if (type == MFGP_KERN_MATERN32) {
+        const double s3r = 1.7320508075688772 * sqrt(rs2);
+        if (GRAD) g = 3.0 * rs2 / (1.0 + s3r);
+        return (1.0 + s3r) * exp(-s3r);
+    } else {
+        const double s5r = 2.23606797749979 * sqrt(rs2);
+        const double p = 1.0 + s5r + (5.0 / 3.0) * rs2;
+        if (GRAD) g = (5.0 / 3.0) * rs2 * (1.0 + s5r) / p;
+        return p * exp(-s5r);
+    }
+}
+
+// stage rows [row0, row0+64) of X (row-major, D columns) transposed into LDS: sx[d*XP + r]
+__device__ __forceinline__ void stage_rows(const double* __restrict__ X, int64_t row0, int D, double* sx) {
+    const double* src = X + row0 * D;
+    for (int e = threadIdx.x; e < KT * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        sx[d * XP + r] = src[e];
+    }
+}
+
+// column index of a thread's c-th output column: two 16-byte pairs, 256 B contiguous per 16 lanes
+__device__ __forceinline__ int col_of(int tx, int c) { return (c < 2) ? (2 * tx + c) : (32 + 2 * tx + (c - 2)); }
+
+// squared distances of the 4x4 pairs for every distance group
+__device__ __forceinline__ void pair_r2(const KernSpecDev& sp, const double* sxi, const double* sxj, int ty,
+                                        int tx, double (&r2)[MAXG][16]) {
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r2[g][e] = 0.0;
+        if (g < sp.ng) {
+            for (int d = sp.gc0[g]; d < sp.gc1[g]; ++d) {
+                const d2_t xi0 = *reinterpret_cast<const d2_t*>(sxi + d * XP + 4 * ty);
+                const d2_t xi1 = *reinterpret_cast<const d2_t*>(sxi + d * XP + 4 * ty + 2);
+                const d2_t xa = *reinterpret_cast<const d2_t*>(sxj + d * XP + 2 * tx);
+                const d2_t xb = *reinterpret_cast<const d2_t*>(sxj + d * XP + 32 + 2 * tx);
+                const double xi[4] = {xi0.x, xi0.y, xi1.x, xi1.y};
+                const double xj[4] = {xa.x, xa.y, xb.x, xb.y};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double df = xi[r] - xj[c];
+                        r2[g][r * 4 + c] += df * df;
+                    }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double pick(const double (&r2)[MAXG][16], int g, int e) {
+    double v = r2[0][e];
+    if (g == 1) v = r2[1][e];
+    if (g == 2) v = r2[2][e];
+    return v;
+}
+
+// K value of one pair
+__device__ __forceinline__ double cov_value(const KernSpecDev& sp, const FactorConst& fc,
+                                            const double (&r2)[MAXG][16], int e) {
+    double K = 0.0, prod = 1.0;
+    int cur = sp.term[0];
+#pragma unroll
+    for (int f = 0; f < MFGP_MAX_PARTS; ++f) {
+        if (f < sp.nf) {
+            if (sp.term[f] != cur) {
+                K += prod;
+                prod = 1.0;
+                cur = sp.term[f];
+            }
+            double g;
+            prod *= fc.var[f] * shape_eval<false>(sp.type[f], pick(r2, sp.gidx[f], e) * fc.inv_l2[f], g);
+        }
+    }
+    return K + prod;
+}
+
+enum { MODE_TRI = 0, MODE_PANEL = 1, MODE_FULL = 2 };
+
+// MODE_TRI   : lower-triangle tiles of Ky = K + (noise+jitter) I on the padded Np grid (identity padding)
+// MODE_PANEL : Kx[r][c] = k(Xs[r], X[c]); rows from Xs (Nrows padded rows), 0 for c >= N
+// MODE_FULL  : full K (no noise) into an N x N buffer, bounds-checked
+template <int MODE>
+__global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const double* __restrict__ Xr,
+                                                       const double* __restrict__ Xc,
+                                                       const double* __restrict__ params, int N, int Np,
+                                                       double* __restrict__ out, int ld) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sxi = smem;
+    double* sxj = smem + sp.D * XP;
+    int bi, bj;
+    if (MODE == MODE_TRI) {
+        const int b = blockIdx.x;
+        int i = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= b) ++i;
+        while (i * (i + 1) / 2 > b) --i;
+        bi = i;
+        bj = b - i * (i + 1) / 2;
+    } else {
+        bi = blockIdx.y;
+        bj = blockIdx.x;
+    }
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    FactorConst fc;
+    load_consts(sp, params, fc);
+    stage_rows(Xr, (int64_t)bi * KT, sp.D, sxi);
+    stage_rows(Xc, (int64_t)bj * KT, sp.D, sxj);
+    __syncthreads();
+
+    double r2[MAXG][16];
+    pair_r2(sp, sxi, sxj, ty, tx, r2);
+    const double diag_add = (MODE == MODE_TRI) ? (params[2 * sp.nf] + params[2 * sp.nf + 1]) : 0.0;
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = bi * KT + 4 * ty + r;
+        double v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int gj = bj * KT + col_of(tx, c);
+            double k = cov_value(sp, fc, r2, r * 4 + c);
+            if (MODE == MODE_TRI) {
+                if (gi >= N || gj >= N) k = (gi == gj) ? 1.0 : 0.0;
+                else if (gi == gj) k += diag_add;
+            } else if (MODE == MODE_PANEL) {
+                if (gj >= N) k = 0.0;
+            }
+            v[c] = k;
+        }
+        if (MODE == MODE_FULL) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int gj = bj * KT + col_of(tx, c);
+                if (gi < N && gj < N) out[(int64_t)gi * ld + gj] = v[c];
+            }
+        } else {
+            double* p = out + (int64_t)gi * ld + bj * KT;
+            *reinterpret_cast<d2_t*>(p + 2 * tx) = (d2_t){v[0], v[1]};
+            *reinterpret_cast<d2_t*>(p + 32 + 2 * tx) = (d2_t){v[2], v[3]};
+        }
+    }
+}
+
+static size_t kb_lds(int D) { return (size_t)2 * D * XP * sizeof(double); }
+
+void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+                       int N, int Np, double* A, int ld) {
+    const int nt = Np / KT;
+    hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_TRI>), dim3(nt * (nt + 1) / 2), dim3(256), kb_lds(spec.D), s,
+                       spec, X, X, params, N, Np, A, ld);
+}
+void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
+                         const double* X, const double* params, int N, int Np, double* Kx, int ld) {
+    hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_PANEL>), dim3(Np / KT, Nsp / KT), dim3(256), kb_lds(spec.D), s,
+                       spec, Xs, X, params, N, Np, Kx, ld);
+}
+void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+                        int N, int Np, double* out, int ld) {
+    hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_FULL>), dim3(Np / KT, Np / KT), dim3(256), kb_lds(spec.D), s,
+                       spec, X, X, params, N, Np, out, ld);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient reduction: with G = alpha alpha^T - Ky^-1 (lower-triangle tiles, off-diagonal tiles x2)
+//   Sv_f = sum G_ij * termprod_f(i,j)          -> dNLML/dvar_f = -0.5 * Sv_f / var_f
+//   Sl_f = sum G_ij * termprod_f(i,j) * g_f    -> dNLML/dl_f   = -0.5 * Sl_f / l_f
+//   Sn   = sum_i G_ii                          -> dNLML/dnoise = -0.5 * Sn
+// Per-tile partials go to `partials`; a second single-block kernel adds them in a fixed order
+// (bitwise reproducible) and applies the factors.
+// ------------------------------------------------------------------------------------------------
+constexpr int NSUM = 2 * MFGP_MAX_PARTS + 1;
+
+__global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const double* __restrict__ X,
+                                                           const double* __restrict__ params,
+                                                           const double* __restrict__ Kinv, int ld,
+                                                           const double* __restrict__ alpha, int N,
+                                                           double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sxi = smem;
+    double* sxj = smem + sp.D * XP;
+    double* red = smem + 2 * sp.D * XP;  // 4 waves x NSUM
+    const int b = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+    while (bi * (bi + 1) / 2 > b) --bi;
+    const int bj = b - bi * (bi + 1) / 2;
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    FactorConst fc;
+    load_consts(sp, params, fc);
+    stage_rows(X, (int64_t)bi * KT, sp.D, sxi);
+    stage_rows(X, (int64_t)bj * KT, sp.D, sxj);
+    __syncthreads();
+    double r2[MAXG][16];
+    pair_r2(sp, sxi, sxj, ty, tx, r2);
+
+    double sv[MFGP_MAX_PARTS], sl[MFGP_MAX_PARTS], sn = 0.0;
+#pragma unroll
+    for (int f = 0; f < MFGP_MAX_PARTS; ++f) sv[f] = sl[f] = 0.0;
+    const double w = (bi == bj) ? 1.0 : 2.0;
+
+    double aj[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int gj = bj * KT + col_of(tx, c);
+        aj[c] = alpha[gj];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = bi * KT + 4 * ty + r;
+        const double ai = alpha[gi];
+        const double* kp = Kinv + (int64_t)gi * ld + bj * KT;
+        const d2_t k01 = *reinterpret_cast<const d2_t*>(kp + 2 * tx);
+        const d2_t k23 = *reinterpret_cast<const d2_t*>(kp + 32 + 2 * tx);
+        const double kin[4] = {k01.x, k01.y, k23.x, k23.y};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int gj = bj * KT + col_of(tx, c);
+            if (gi < N && gj < N) {
+                const double G = w * (ai * aj[c] - kin[c]);
+                if (gi == gj) sn += G;
+                const int e = r * 4 + c;
+                // factor values, term products
+                double kf[MFGP_MAX_PARTS], gf[MFGP_MAX_PARTS];
+#pragma unroll
+                for (int f = 0; f < MFGP_MAX_PARTS; ++f) {
+                    kf[f] = 1.0;
+                    gf[f] = 0.0;
+                    if (f < sp.nf) {
+                        double g;
+                        kf[f] = fc.var[f] *
+                                shape_eval<true>(sp.type[f], pick(r2, sp.gidx[f], e) * fc.inv_l2[f], g);
+                        gf[f] = g;
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < MFGP_MAX_PARTS; ++f) {
+                    if (f < sp.nf) {
+                        double tp = 1.0;
+#pragma unroll
+                        for (int h = 0; h < MFGP_MAX_PARTS; ++h)
+                            if (h < sp.nf && sp.term[h] == sp.term[f]) tp *= kf[h];
+                        sv[f] += G * tp;
+                        sl[f] += G * tp * gf[f];
+                    }
+                }
+            }
+        }
+    }
+    // block reduction (fixed order)
+    double vals[NSUM];
+#pragma unroll
+    for (int f = 0; f < MFGP_MAX_PARTS; ++f) {
+        vals[2 * f] = sv[f];
+        vals[2 * f + 1] = sl[f];
+    }
+    vals[NSUM - 1] = sn;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NSUM; ++i) {
+        double v = vals[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[wave * NSUM + i] = v;
+    }
+    __syncthreads();
+    if (tid < NSUM)
+        partials[(int64_t)b * NSUM + tid] =
+            (red[tid] + red[NSUM + tid]) + (red[2 * NSUM + tid] + red[3 * NSUM + tid]);
+}
+
+__global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp, const double* __restrict__ params,
+                                                            const double* __restrict__ partials, int nblocks,
+                                                            double* __restrict__ out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    for (int i = 0; i < NSUM; ++i) {
+        double s = 0.0;
+        for (int b = tid; b < nblocks; b += 256) s += partials[(int64_t)b * NSUM + i];
+        red[tid] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double S = red[0];
+            if (i == NSUM - 1) out[2 * sp.nf] = -0.5 * S;
+            else if (i / 2 < sp.nf) out[i] = -0.5 * S / params[i];  // params[2f]=var_f, params[2f+1]=l_f
+        }
+        __syncthreads();
+    }
+}
+
+int grad_num_partials(int Np) {
+    const int nt = Np / KT;
+    return nt * (nt + 1) / 2;
+}
+
+void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+                 const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
+                 double* out) {
+    const int nb = grad_num_partials(Np);
+    const size_t lds = kb_lds(spec.D) + (size_t)4 * NSUM * sizeof(double);
+    hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, params, Kinv, ld, alpha, N,
+                       partials);
+    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(1), dim3(256), 0, s, spec, params, partials, nb, out);
+}
+
+// var[i] = max(kss - ss[i], 1e-15) + add,  kss = sum_terms prod var_f  (GPy Kdiag of a stationary kernel)
+__global__ void mfgp_finish_var_f64(KernSpecDev sp, const double* __restrict__ params,
+                                    const double* __restrict__ ss, double* __restrict__ var, int n, double add) {
+    double kss = 0.0, prod = 1.0;
+    int cur = sp.term[0];
+    for (int f = 0; f < sp.nf; ++f) {
+        if (sp.term[f] != cur) {
+            kss += prod;
+            prod = 1.0;
+            cur = sp.term[f];
+        }
+        prod *= params[2 * f];
+    }
+    kss += prod;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double v = kss - ss[i];
+        if (!(v > 1e-15)) v = 1e-15;
+        var[i] = v + add;
+    }
+}
+
+void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* params, const double* ss,
+                       double* var, int n, double add) {
+    hipLaunchKernelGGL(mfgp_finish_var_f64, dim3((n + 255) / 256), dim3(256), 0, s, spec, params, ss, var, n, add);
+}
+
+}  // namespace mfgp

@@ -1,0 +1,181 @@
+// gemm_f64.hip -- the fp64 MFMA tile-GEMM kernel every level-3 step of the GP evaluation runs on.
+//
+// One workgroup (4 waves, 2x2) computes one BM x BN output tile described by a GemmTask:
+//     C = beta*C + alpha * A[i0.., k0..k0+klen) * B[j0.., k0'..)^T          ("NT": both K-contiguous)
+// on v_mfma_f64_16x16x4_f64.  Cholesky panel solves (as products with the running inverse), SYRK
+// trailing updates, the triangular inverse, K^-1 = L^-T L^-1 and the predictive-variance product
+// are all expressed as lists of such tasks (see plan.cpp); triangular structure = trimmed K ranges
+// plus one masked diagonal window.
+//
+// Replaces LAPACK dpotrf/dtrtri/dpotri/dgemm behind GPy's pdinv / Posterior (SURVEY.md 8(a) a4,a7,a11).
+//
+// Data path: global -> registers (16 B per lane, rows of 256 B fully coalesced) -> LDS with a
+// 16-byte-chunk XOR swizzle (chunk ^= row & 15) so that the MFMA fragment reads (16 rows x 2 k per
+// 32-lane group, ds_read_b64) are bank-conflict free without padding -> MFMA.  LDS is double
+// buffered: the global loads of K-step t+1 are in flight while step t is on the matrix cores.
+#include "mfgp_internal.h"
+
+namespace mfgp {
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64(const GemmTask* __restrict__ tasks,
+                                                           const double* A, const double* B,
+                                                           double* C, double* C2, int ld) {
+    constexpr int TM = BM / 32;   // 16-row MFMA blocks per wave along M (wave grid is 2 x 2)
+    constexpr int TN = BN / 32;
+    constexpr int NA = BM / 16;   // 16-byte chunks per thread per K-step (BM*16 chunks / 256 threads)
+    constexpr int NBC = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                  // [2][BM*BK]
+    double* Bs = smem + 2 * BM * BK;    // [2][BN*BK]
+
+    const GemmTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15;  // fragment row / output column within a 16-block
+    const int q = lane >> 4;   // k sub-index of the fragment / output row group
+
+    const double* Ap = A + t.a_off;
+    const double* Bp = B + t.b_off;
+    const int nk = t.klen / BK;
+    const bool a_lo = t.flags & TF_A_LOWER, a_up = t.flags & TF_A_UPPER;
+    const bool b_lo = t.flags & TF_B_LOWER, b_up = t.flags & TF_B_UPPER;
+    const int a_lo_shift = t.klen - BM, b_lo_shift = t.klen - BN;
+
+    d2_t ra[NA], rb[NBC];
+    d4_t acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int g = tid + 256 * u;
+            const int row = g >> 4, c = g & 15;
+            const int k = kt * BK + 2 * c;
+            d2_t v = *reinterpret_cast<const d2_t*>(Ap + (int64_t)row * ld + k);
+            if (a_lo) {
+                if (k > row + a_lo_shift) v.x = 0.0;
+                if (k + 1 > row + a_lo_shift) v.y = 0.0;
+            }
+            if (a_up) {
+                if (k < row) v.x = 0.0;
+                if (k + 1 < row) v.y = 0.0;
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int g = tid + 256 * u;
+            const int row = g >> 4, c = g & 15;
+            const int k = kt * BK + 2 * c;
+            d2_t v = *reinterpret_cast<const d2_t*>(Bp + (int64_t)row * ld + k);
+            if (b_lo) {
+                if (k > row + b_lo_shift) v.x = 0.0;
+                if (k + 1 > row + b_lo_shift) v.y = 0.0;
+            }
+            if (b_up) {
+                if (k < row) v.x = 0.0;
+                if (k + 1 < row) v.y = 0.0;
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        double* as = As + buf * (BM * BK);
+        double* bs = Bs + buf * (BN * BK);
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int g = tid + 256 * u;
+            const int row = g >> 4, c = g & 15;
+            *reinterpret_cast<d2_t*>(as + row * BK + ((c ^ (row & 15)) << 1)) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int g = tid + 256 * u;
+            const int row = g >> 4, c = g & 15;
+            *reinterpret_cast<d2_t*>(bs + row * BK + ((c ^ (row & 15)) << 1)) = rb[u];
+        }
+    };
+    auto compute = [&](int buf) {
+        const double* as = As + buf * (BM * BK) + (wm * (BM / 2) + fr) * BK + (q & 1);
+        const double* bs = Bs + buf * (BN * BK) + (wn * (BN / 2) + fr) * BK + (q & 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            // lane (fr, q) supplies element [row fr][k = 4*kk + q]: 16-byte chunk 2*kk + (q>>1), half q&1
+            const int sw = ((2 * kk + (q >> 1)) ^ fr) << 1;
+            double a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = as[mi * 16 * BK + sw];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[ni] = bs[ni * 16 * BK + sw];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) load_tiles(kt + 1);
+        compute(kt & 1);
+        if (more) store_tiles((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: v_mfma_f64_16x16x4 C/D layout: D[row = q + 4*reg][col = fr]
+    double* Cp = C + t.c_off;
+    const double alpha = t.alpha, beta = t.beta;
+    const bool use_beta = (beta != 0.0);
+    const bool mirror = (t.c2_off >= 0);
+    double* C2p = C2 + (mirror ? t.c2_off : 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * (BM / 2) + mi * 16 + q + 4 * r;
+                const int col = wn * (BN / 2) + ni * 16 + fr;
+                double v = alpha * acc[mi][ni][r];
+                double* p = Cp + (int64_t)row * ld + col;
+                if (use_beta) v += beta * (*p);
+                *p = v;
+                if (mirror) C2p[(int64_t)col * ld + row] = v;
+            }
+        }
+    }
+}
+
+size_t gemm_lds_bytes(int tile) { return (size_t)2 * (tile + tile) * BK * sizeof(double); }
+
+void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
+                 const double* B, double* C, double* C2, int ld) {
+    if (ntasks <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_gemm_nt_f64<128, 128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_gemm_nt_f64<64, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(64));
+        attr_set = true;
+    }
+    if (tile == 128) {
+        hipLaunchKernelGGL((mfgp_gemm_nt_f64<128, 128>), dim3(ntasks), dim3(256), gemm_lds_bytes(128), s,
+                           tasks, A, B, C, C2, ld);
+    } else {
+        hipLaunchKernelGGL((mfgp_gemm_nt_f64<64, 64>), dim3(ntasks), dim3(256), gemm_lds_bytes(64), s,
+                           tasks, A, B, C, C2, ld);
+    }
+}
+
+}  // namespace mfgp

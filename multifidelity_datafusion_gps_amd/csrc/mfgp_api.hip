@@ -1,0 +1,723 @@
+// mfgp_api.hip -- host side of libmfgp_hip.so: the C-ABI of include/mfgp.h, device-memory
+// ownership, and the planner that turns "factorise / invert / predict" into lists of tile-GEMM
+// tasks (gemm_f64.hip) and leaf launches (leaf_f64.hip).
+//
+// Algorithm of one evaluation (i.e. GPy ExactGaussianInference.inference +
+// kern.update_gradients_full, restated MI355X-first):
+//   A  <- lower(K(theta)) + (noise+jitter) I                     [1 launch, HBM bound]
+//   (L, X=L^-1) <- cholinv(A)   recursive on 128-blocks:          [leaf + MFMA tile GEMMs]
+//        cholinv(A11); L21 = A21 X11^T; A22 -= L21 L21^T; cholinv(A22); X21 = -X22 (L21 X11)
+//      the inverse is kept "mirrored" in S (S = X + X^T - diag) so that every product in the
+//      recursion, K^-1 = X^T X and the predictive V = Kx X^T are K-contiguous "NT" tile GEMMs.
+//   z = X y ; alpha = X^T z ; logdet = 2 sum log diag(L) ; nlml = .5 (N log 2pi + logdet + z.z)
+//   Kinv <- lower(X^T X)                                          [1 launch, MFMA bound, N^3/3 flops]
+//   grad <- -0.5 sum (alpha alpha^T - Kinv) o dK/dtheta           [fused tile reduction]
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include "mfgp_internal.h"
+
+using namespace mfgp;
+
+namespace {
+thread_local std::string g_err;
+
+enum Buf { BUF_A = 0, BUF_L = 1, BUF_S = 2, BUF_W = 3 };
+
+struct Step {
+    int kind;  // 0 = leaf, 1 = gemm
+    int blk;   // leaf block
+    int tile, first, count, a, b, c, c2;  // gemm
+};
+}  // namespace
+
+struct mfgp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err, info_str;
+    int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
+    int D = 0, nblk = 0;
+    double* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *dX = nullptr, *dXs = nullptr, *dY = nullptr, *dz = nullptr, *dalpha = nullptr;
+    double *dparams = nullptr, *dlogdet = nullptr, *dres = nullptr, *dpart = nullptr, *dvec = nullptr,
+           *dvec2 = nullptr;
+    int* dinfo = nullptr;
+    GemmTask* dtasks = nullptr;
+    size_t tasks_cap = 0;
+    int xs_cap_rows = 0, xs_cap_D = 0;
+    double* hres = nullptr;  // pinned
+    int* hinfo = nullptr;    // pinned
+    std::vector<GemmTask> tasks;
+    std::vector<Step> plan;         // cholinv
+    Step kinv_step{}, predv_step{};
+    int predv_rows = 0;
+    KernSpecDev spec{};
+    bool have_kernel = false, have_data = false, factorized = false, kinv_valid = false, grad_valid = false,
+         params_set = false;
+    double theta[2 * MFGP_MAX_PARTS] = {0};
+    double noise = 0, jitter = 0;
+    double quad = 0, logdet = 0;
+    double grad[2 * MFGP_MAX_PARTS + 1] = {0};
+    hipEvent_t ev[10];
+    mfgp_timings tm{};
+    int64_t launches = 0;
+};
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            if (h) (h)->err = m_; else g_err = m_;                                              \
+            return -2;                                                                          \
+        }                                                                                       \
+    } while (0)
+
+static int fail(mfgp_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_err = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------------
+// planner
+// ------------------------------------------------------------------------------------------------
+static int pick_tile(int ntiles128) { return ntiles128 >= 160 ? 128 : 64; }
+
+static void add_gemm(mfgp_handle* h, std::vector<Step>& plan, int tile, int first, int a, int b, int c, int c2) {
+    Step s{};
+    s.kind = 1;
+    s.tile = tile;
+    s.first = first;
+    s.count = (int)h->tasks.size() - first;
+    s.a = a; s.b = b; s.c = c; s.c2 = c2;
+    if (s.count > 0) plan.push_back(s);
+}
+
+// recursive Cholesky + inverse over leaf blocks [b0, b1)
+static void plan_cholinv(mfgp_handle* h, int b0, int b1) {
+    const int64_t ld = h->Np;
+    if (b1 - b0 == 1) {
+        Step s{};
+        s.kind = 0;
+        s.blk = b0;
+        h->plan.push_back(s);
+        return;
+    }
+    const int bm = b0 + (b1 - b0 + 1) / 2;
+    plan_cholinv(h, b0, bm);
+    const int n1 = bm - b0, n2 = b1 - bm;
+    const int T = pick_tile(n1 * n2);
+    const int sc = NB / T;
+    const int64_t k0 = (int64_t)b0 * NB, km = (int64_t)bm * NB;
+    // L21 = A21 * X11^T      (A: A, B: S lower rows j, C: L)
+    {
+        const int first = (int)h->tasks.size();
+        for (int j = b0 * sc; j < bm * sc; ++j)       // long K first
+            for (int i = bm * sc; i < b1 * sc; ++i) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T * ld + k0;
+                t.b_off = (int64_t)j * T * ld + k0;
+                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c2_off = -1;
+                t.klen = (int)((int64_t)(j + 1) * T - k0);
+                t.flags = TF_B_LOWER;
+                t.alpha = 1.0; t.beta = 0.0;
+                h->tasks.push_back(t);
+            }
+        // descending K length for load balance
+        std::stable_sort(h->tasks.begin() + first, h->tasks.end(),
+                         [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+        add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
+    }
+    // A22 -= L21 L21^T       (A: L, B: L, C: A), lower tiles only
+    {
+        const int T2 = pick_tile(n2 * (n2 + 1) / 2);
+        const int s2 = NB / T2;
+        const int first = (int)h->tasks.size();
+        for (int i = bm * s2; i < b1 * s2; ++i)
+            for (int j = bm * s2; j <= i; ++j) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T2 * ld + k0;
+                t.b_off = (int64_t)j * T2 * ld + k0;
+                t.c_off = (int64_t)i * T2 * ld + (int64_t)j * T2;
+                t.c2_off = -1;
+                t.klen = n1 * NB;
+                t.flags = 0;
+                t.alpha = -1.0; t.beta = 1.0;
+                h->tasks.push_back(t);
+            }
+        add_gemm(h, h->plan, T2, first, BUF_L, BUF_L, BUF_A, -1);
+    }
+    plan_cholinv(h, bm, b1);
+    // P^T[j][i] = sum_{k>=j} X11^T[j][k] L21[i][k]     (A: S upper rows j, B: L rows i, C: W[j][i])
+    {
+        const int first = (int)h->tasks.size();
+        for (int j = b0 * sc; j < bm * sc; ++j)
+            for (int i = bm * sc; i < b1 * sc; ++i) {
+                GemmTask t{};
+                t.a_off = (int64_t)j * T * ld + (int64_t)j * T;
+                t.b_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c_off = (int64_t)j * T * ld + (int64_t)i * T;
+                t.c2_off = -1;
+                t.klen = (int)(km - (int64_t)j * T);
+                t.flags = TF_A_UPPER;
+                t.alpha = 1.0; t.beta = 0.0;
+                h->tasks.push_back(t);
+            }
+        add_gemm(h, h->plan, T, first, BUF_S, BUF_L, BUF_W, -1);
+    }
+    // X21[i][j] = - sum_{k<=i} X22[i][k] P^T[j][k]     (A: S lower rows i, B: W rows j, C: S lower + mirror)
+    {
+        const int first = (int)h->tasks.size();
+        for (int i = b1 * sc - 1; i >= bm * sc; --i)  // long K first
+            for (int j = b0 * sc; j < bm * sc; ++j) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T * ld + km;
+                t.b_off = (int64_t)j * T * ld + km;
+                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c2_off = (int64_t)j * T * ld + (int64_t)i * T;
+                t.klen = (int)((int64_t)(i + 1) * T - km);
+                t.flags = TF_A_LOWER;
+                t.alpha = -1.0; t.beta = 0.0;
+                h->tasks.push_back(t);
+            }
+        add_gemm(h, h->plan, T, first, BUF_S, BUF_W, BUF_S, BUF_S);
+    }
+}
+
+static void plan_kinv(mfgp_handle* h) {
+    const int64_t ld = h->Np;
+    const int nb = h->nblk;
+    const int T = pick_tile(nb * (nb + 1) / 2);
+    const int sc = NB / T;
+    const int first = (int)h->tasks.size();
+    for (int i = 0; i < nb * sc; ++i)  // small i = long K first
+        for (int j = 0; j <= i; ++j) {
+            GemmTask t{};
+            t.a_off = (int64_t)i * T * ld + (int64_t)i * T;
+            t.b_off = (int64_t)j * T * ld + (int64_t)i * T;
+            t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+            t.c2_off = -1;
+            t.klen = (int)(h->Np - (int64_t)i * T);
+            t.flags = TF_A_UPPER | (i == j ? TF_B_UPPER : 0);
+            t.alpha = 1.0; t.beta = 0.0;
+            h->tasks.push_back(t);
+        }
+    std::vector<Step> tmp;
+    add_gemm(h, tmp, T, first, BUF_S, BUF_S, BUF_A, -1);
+    h->kinv_step = tmp.empty() ? Step{} : tmp[0];
+}
+
+// V[r][i] = sum_{k<=i} Kx[r][k] X[i][k]   (A: W = Kx panel, B: S lower rows i, C: A)
+static void plan_predv(mfgp_handle* h, int rows_p) {
+    const int64_t ld = h->Np;
+    const int nb = h->nblk, rb = rows_p / NB;
+    const int T = pick_tile(nb * rb);
+    const int sc = NB / T;
+    const int first = (int)h->tasks.size();
+    for (int i = nb * sc - 1; i >= 0; --i)
+        for (int r = 0; r < rb * sc; ++r) {
+            GemmTask t{};
+            t.a_off = (int64_t)r * T * ld;
+            t.b_off = (int64_t)i * T * ld;
+            t.c_off = (int64_t)r * T * ld + (int64_t)i * T;
+            t.c2_off = -1;
+            t.klen = (int)((int64_t)(i + 1) * T);
+            t.flags = TF_B_LOWER;
+            t.alpha = 1.0; t.beta = 0.0;
+            h->tasks.push_back(t);
+        }
+    std::vector<Step> tmp;
+    add_gemm(h, tmp, T, first, BUF_W, BUF_S, BUF_A, -1);
+    h->predv_step = tmp.empty() ? Step{} : tmp[0];
+    h->predv_rows = rows_p;
+}
+
+static int upload_tasks(mfgp_handle* h) {
+    const size_t need = h->tasks.size();
+    if (need > h->tasks_cap) {
+        if (h->dtasks) HIPCHK(h, hipFree(h->dtasks));
+        h->tasks_cap = need + need / 2 + 1024;
+        HIPCHK(h, hipMalloc(&h->dtasks, h->tasks_cap * sizeof(GemmTask)));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->dtasks, h->tasks.data(), need * sizeof(GemmTask), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static void run_step(mfgp_handle* h, const Step& s) {
+    if (s.kind == 0) {
+        launch_leaf(h->stream, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
+    } else {
+        launch_gemm(h->stream, s.tile, h->dtasks + s.first, s.count, h->buf[s.a], h->buf[s.b], h->buf[s.c],
+                    s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np);
+    }
+    h->launches++;
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mfgp_last_error(mfgp_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int32_t mfgp_create(int32_t device_id, mfgp_handle** out) {
+    if (!out) return fail(nullptr, -1, "mfgp_create: out is NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, -3, std::string("mfgp_create: no HIP device available (") +
+                                     (e != hipSuccess ? hipGetErrorString(e) : "device count 0") + ")");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, -1, "mfgp_create: bad device id");
+    mfgp_handle* h = new mfgp_handle();
+    h->device = device_id;
+    HIPCHK(h, hipSetDevice(device_id));
+    HIPCHK(h, hipStreamCreate(&h->stream));
+    for (auto& ev : h->ev) HIPCHK(h, hipEventCreate(&ev));
+    HIPCHK(h, hipMalloc(&h->dparams, 32 * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->dres, 64 * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->dinfo, sizeof(int)));
+    HIPCHK(h, hipHostMalloc(&h->hres, 64 * sizeof(double)));
+    HIPCHK(h, hipHostMalloc(&h->hinfo, sizeof(int)));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device_id));
+    char tmp[256];
+    snprintf(tmp, sizeof tmp, "mfgp_hip %s %s CUs=%d", prop.gcnArchName, prop.name, prop.multiProcessorCount);
+    h->info_str = tmp;
+    *out = h;
+    return 0;
+}
+
+const char* mfgp_device_info(mfgp_handle* h) { return h ? h->info_str.c_str() : ""; }
+
+static void free_mats(mfgp_handle* h) {
+    for (auto& b : h->buf) { if (b) hipFree(b); b = nullptr; }
+    for (double** p : {&h->dX, &h->dY, &h->dz, &h->dalpha, &h->dlogdet, &h->dpart, &h->dvec, &h->dvec2}) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    h->cap = 0;
+}
+
+int32_t mfgp_destroy(mfgp_handle* h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    free_mats(h);
+    if (h->dXs) hipFree(h->dXs);
+    if (h->dtasks) hipFree(h->dtasks);
+    hipFree(h->dparams); hipFree(h->dres); hipFree(h->dinfo);
+    hipHostFree(h->hres); hipHostFree(h->hinfo);
+    for (auto& ev : h->ev) hipEventDestroy(ev);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+static int build_plans(mfgp_handle* h) {
+    h->tasks.clear();
+    h->plan.clear();
+    plan_cholinv(h, 0, h->nblk);
+    plan_kinv(h);
+    h->predv_rows = 0;
+    return upload_tasks(h);
+}
+
+int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, const double* Y) {
+    if (!h || !X || !Y) return fail(h, -1, "mfgp_set_data: NULL argument");
+    if (N < 1 || D < 1 || D > 64) return fail(h, -1, "mfgp_set_data: need N >= 1 and 1 <= D <= 64");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t Np = (N + NB - 1) / NB * NB;
+    if (Np > h->cap || D != h->D) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const int64_t cap = std::max(Np, h->cap);
+        free_mats(h);
+        for (auto& b : h->buf) HIPCHK(h, hipMalloc(&b, (size_t)cap * cap * sizeof(double)));
+        HIPCHK(h, hipMalloc(&h->dX, (size_t)cap * D * sizeof(double)));
+        for (double** p : {&h->dY, &h->dz, &h->dalpha, &h->dvec, &h->dvec2})
+            HIPCHK(h, hipMalloc(p, (size_t)cap * sizeof(double)));
+        HIPCHK(h, hipMalloc(&h->dlogdet, (size_t)(cap / NB) * sizeof(double)));
+        HIPCHK(h, hipMalloc(&h->dpart, (size_t)grad_num_partials((int)cap) * (2 * MFGP_MAX_PARTS + 1) * sizeof(double)));
+        h->cap = cap;
+    }
+    const bool replan = (Np != h->Np);
+    h->N = N; h->Np = Np; h->D = D; h->nblk = (int)(Np / NB);
+    HIPCHK(h, hipMemsetAsync(h->dX, 0, (size_t)Np * D * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->dY, 0, (size_t)Np * sizeof(double), h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->dY, Y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_data = true;
+    h->factorized = h->kinv_valid = h->grad_valid = false;
+    h->spec.D = D;
+    if (replan) return build_plans(h);
+    return 0;
+}
+
+int32_t mfgp_set_kernel(mfgp_handle* h, const mfgp_kern_part* parts, int32_t n_parts) {
+    if (!h || !parts) return fail(h, -1, "mfgp_set_kernel: NULL argument");
+    if (n_parts < 1 || n_parts > MFGP_MAX_PARTS) return fail(h, -1, "mfgp_set_kernel: 1..6 parts supported");
+    KernSpecDev sp{};
+    sp.nf = n_parts;
+    sp.D = h->D;
+    sp.ng = 0;
+    for (int f = 0; f < n_parts; ++f) {
+        const mfgp_kern_part& p = parts[f];
+        if (p.type < 0 || p.type > MFGP_KERN_MATERN52) return fail(h, -1, "mfgp_set_kernel: unknown kernel type");
+        if (p.col_begin < 0 || p.col_end <= p.col_begin || p.col_end > 64)
+            return fail(h, -1, "mfgp_set_kernel: bad column range");
+        if (f > 0 && p.term < parts[f - 1].term) return fail(h, -1, "mfgp_set_kernel: term ids must be ascending");
+        sp.type[f] = p.type; sp.c0[f] = p.col_begin; sp.c1[f] = p.col_end; sp.term[f] = p.term;
+        int g = -1;
+        for (int k = 0; k < sp.ng; ++k)
+            if (sp.gc0[k] == p.col_begin && sp.gc1[k] == p.col_end) g = k;
+        if (g < 0) {
+            if (sp.ng == MFGP_MAX_GROUPS) return fail(h, -1, "mfgp_set_kernel: at most 3 distinct column ranges");
+            g = sp.ng++;
+            sp.gc0[g] = p.col_begin; sp.gc1[g] = p.col_end;
+        }
+        sp.gidx[f] = g;
+    }
+    h->spec = sp;
+    h->have_kernel = true;
+    h->factorized = h->kinv_valid = h->grad_valid = false;
+    return 0;
+}
+
+static int check_ready(mfgp_handle* h, const char* who) {
+    if (!h) return fail(nullptr, -1, std::string(who) + ": NULL handle");
+    if (!h->have_data) return fail(h, -1, std::string(who) + ": mfgp_set_data not called");
+    if (!h->have_kernel) return fail(h, -1, std::string(who) + ": mfgp_set_kernel not called");
+    for (int f = 0; f < h->spec.nf; ++f)
+        if (h->spec.c1[f] > h->D) return fail(h, -1, std::string(who) + ": kernel column range exceeds D");
+    h->spec.D = h->D;
+    return 0;
+}
+
+// enqueue K-build + cholinv + solve (+ K^-1 + gradient); no host sync
+static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, double jitter, bool want_grad) {
+    const int nf = h->spec.nf;
+    for (int i = 0; i < 2 * nf; ++i) {
+        if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "mfgp_eval: parameters must be positive and finite");
+        h->theta[i] = theta[i];
+        h->hres[32 + i] = theta[i];
+    }
+    if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "mfgp_eval: noise and jitter must be >= 0");
+    h->noise = noise; h->jitter = jitter;
+    h->params_set = true;
+    h->hres[32 + 2 * nf] = noise;
+    h->hres[32 + 2 * nf + 1] = jitter;
+    hipStream_t s = h->stream;
+    h->launches = 0;
+    HIPCHK(h, hipMemcpyAsync(h->dparams, h->hres + 32, (2 * nf + 2) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
+    HIPCHK(h, hipEventRecord(h->ev[0], s));
+    launch_kbuild_tri(s, h->spec, h->dX, h->dparams, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
+    h->launches++;
+    HIPCHK(h, hipEventRecord(h->ev[1], s));
+    for (const Step& st : h->plan) run_step(h, st);
+    HIPCHK(h, hipEventRecord(h->ev[2], s));
+    launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dY, h->dz, (int)h->Np, (int)h->Np, 0);       // z = X y
+    launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dz, h->dalpha, (int)h->Np, (int)h->Np, 1);   // alpha = X^T z
+    launch_finish_solve(s, h->dz, (int)h->Np, h->dlogdet, h->nblk, h->dres);
+    h->launches += 3;
+    HIPCHK(h, hipEventRecord(h->ev[3], s));
+    if (want_grad) {
+        run_step(h, h->kinv_step);
+        HIPCHK(h, hipEventRecord(h->ev[4], s));
+        launch_grad(s, h->spec, h->dX, h->dparams, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
+                    h->dpart, h->dres + 2);
+        h->launches += 2;
+        HIPCHK(h, hipEventRecord(h->ev[5], s));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, 32 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->hinfo, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+static int finish_eval(mfgp_handle* h, bool want_grad) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    mfgp_timings& t = h->tm;
+    memset(&t, 0, sizeof t);
+    t.kbuild_ms = ev_ms(h->ev[0], h->ev[1]);
+    t.cholinv_ms = ev_ms(h->ev[1], h->ev[2]);
+    t.solve_ms = ev_ms(h->ev[2], h->ev[3]);
+    t.total_ms = ev_ms(h->ev[0], h->ev[3]);
+    if (want_grad) {
+        t.kinv_ms = ev_ms(h->ev[3], h->ev[4]);
+        t.grad_ms = ev_ms(h->ev[4], h->ev[5]);
+        t.total_ms = ev_ms(h->ev[0], h->ev[5]);
+    }
+    const double np = (double)h->Np;
+    t.kbuild_bytes = 4.0 * np * (np + 64.0);
+    t.kinv_flops = np * np * np / 3.0;
+    t.cholinv_flops = 2.0 * np * np * np / 3.0;
+    t.n_launches = h->launches;
+    h->quad = h->hres[0];
+    h->logdet = h->hres[1];
+    h->kinv_valid = want_grad;
+    h->grad_valid = want_grad;
+    if (want_grad)
+        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) h->grad[i] = h->hres[2 + i];
+    const int info = *h->hinfo;
+    if (info != 0) {
+        h->factorized = false;
+        h->kinv_valid = h->grad_valid = false;
+        h->err = "Cholesky failed: non-positive pivot at index " + std::to_string(info);
+        return info;
+    }
+    h->factorized = true;
+    return 0;
+}
+
+int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad,
+                  double* nlml, double* grad) {
+    int rc = check_ready(h, "mfgp_eval");
+    if (rc) return rc;
+    if (!theta) return fail(h, -1, "mfgp_eval: theta is NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = enqueue_eval(h, theta, noise, jitter, want_grad != 0);
+    if (rc) return rc;
+    rc = finish_eval(h, want_grad != 0);
+    if (rc) return rc;
+    if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
+    if (want_grad && grad)
+        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) grad[i] = h->grad[i];
+    return 0;
+}
+
+int32_t mfgp_factorize(mfgp_handle* h, const double* theta, double noise, double jitter) {
+    return mfgp_eval(h, theta, noise, jitter, 0, nullptr, nullptr);
+}
+
+int32_t mfgp_nlml(mfgp_handle* h, double* value) {
+    if (!h || !value) return fail(h, -1, "mfgp_nlml: NULL argument");
+    if (!h->factorized) return fail(h, -1, "mfgp_nlml: no valid factorisation");
+    *value = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
+    return 0;
+}
+
+int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
+    if (!h || !grad) return fail(h, -1, "mfgp_nlml_grad: NULL argument");
+    if (!h->factorized) return fail(h, -1, "mfgp_nlml_grad: no valid factorisation");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->grad_valid) {
+        hipStream_t s = h->stream;
+        HIPCHK(h, hipEventRecord(h->ev[3], s));
+        run_step(h, h->kinv_step);
+        HIPCHK(h, hipEventRecord(h->ev[4], s));
+        launch_grad(s, h->spec, h->dX, h->dparams, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
+                    h->dpart, h->dres + 2);
+        HIPCHK(h, hipEventRecord(h->ev[5], s));
+        HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, 32 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        HIPCHK(h, hipGetLastError());
+        h->tm.kinv_ms = ev_ms(h->ev[3], h->ev[4]);
+        h->tm.grad_ms = ev_ms(h->ev[4], h->ev[5]);
+        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) h->grad[i] = h->hres[2 + i];
+        h->kinv_valid = h->grad_valid = true;
+    }
+    for (int i = 0; i < 2 * h->spec.nf + 1; ++i) grad[i] = h->grad[i];
+    return 0;
+}
+
+int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double* mean, double* var,
+                     int32_t want_var, int32_t include_noise) {
+    int rc = check_ready(h, "mfgp_predict");
+    if (rc) return rc;
+    if (!Xstar || !mean || (want_var && !var)) return fail(h, -1, "mfgp_predict: NULL argument");
+    if (Nstar < 1) return fail(h, -1, "mfgp_predict: Nstar < 1");
+    if (!h->factorized) return fail(h, -1, "mfgp_predict: no valid factorisation (call mfgp_factorize / mfgp_eval)");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int D = h->D;
+    const int64_t Np = h->Np;
+    double pan_ms = 0, var_ms = 0;
+    h->launches = 0;
+    for (int64_t r0 = 0; r0 < Nstar; r0 += Np) {
+        const int64_t rows = std::min(Np, Nstar - r0);
+        const int rows_p = (int)((rows + NB - 1) / NB * NB);
+        if (rows_p > h->xs_cap_rows || D != h->xs_cap_D) {
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (h->dXs) HIPCHK(h, hipFree(h->dXs));
+            h->xs_cap_rows = std::max(rows_p, h->xs_cap_rows);
+            h->xs_cap_D = D;
+            HIPCHK(h, hipMalloc(&h->dXs, (size_t)h->xs_cap_rows * D * sizeof(double)));
+        }
+        HIPCHK(h, hipMemsetAsync(h->dXs, 0, (size_t)rows_p * D * sizeof(double), s));
+        HIPCHK(h, hipMemcpyAsync(h->dXs, Xstar + r0 * D, (size_t)rows * D * sizeof(double), hipMemcpyHostToDevice, s));
+        if (want_var && h->predv_rows != rows_p) {
+            // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
+            h->tasks.resize((size_t)h->kinv_step.first + h->kinv_step.count);
+            plan_predv(h, rows_p);
+            rc = upload_tasks(h);
+            if (rc) return rc;
+        }
+        HIPCHK(h, hipEventRecord(h->ev[6], s));
+        launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, h->dparams, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
+        launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, h->dvec, rows_p, (int)Np, 2);
+        h->launches += 2;
+        HIPCHK(h, hipEventRecord(h->ev[7], s));
+        HIPCHK(h, hipMemcpyAsync(mean + r0, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (want_var) {
+            h->kinv_valid = false;  // V overwrites the K^-1 storage
+            run_step(h, h->predv_step);
+            launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, rows_p, (int)Np);
+            launch_finish_var(s, h->spec, h->dparams, h->dvec2, h->dvec2, rows_p, include_noise ? h->noise : 0.0);
+            h->launches += 2;
+            HIPCHK(h, hipEventRecord(h->ev[8], s));
+            HIPCHK(h, hipMemcpyAsync(var + r0, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(h, hipStreamSynchronize(s));
+        HIPCHK(h, hipGetLastError());
+        pan_ms += ev_ms(h->ev[6], h->ev[7]);
+        if (want_var) var_ms += ev_ms(h->ev[7], h->ev[8]);
+    }
+    h->tm.predict_panel_ms = pan_ms;
+    h->tm.predict_var_ms = var_ms;
+    h->tm.n_launches = h->launches;
+    return 0;
+}
+
+// ---- read-back ---------------------------------------------------------------------------------------
+static int copy_block(mfgp_handle* h, const double* dsrc, double* out, int mode) {
+    // mode 0: lower triangle only (zeros above); 1: symmetric from lower; 2: as stored
+    const int64_t N = h->N, Np = h->Np;
+    std::vector<double> tmp((size_t)Np * Np);
+    HIPCHK(h, hipMemcpy(tmp.data(), dsrc, (size_t)Np * Np * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j < N; ++j) {
+            double v;
+            if (mode == 0) v = (j <= i) ? tmp[i * Np + j] : 0.0;
+            else if (mode == 1) v = (j <= i) ? tmp[i * Np + j] : tmp[j * Np + i];
+            else v = tmp[i * Np + j];
+            out[i * N + j] = v;
+        }
+    return 0;
+}
+
+int32_t mfgp_get_K(mfgp_handle* h, double* out) {
+    int rc = check_ready(h, "mfgp_get_K");
+    if (rc) return rc;
+    if (!out) return fail(h, -1, "mfgp_get_K: NULL");
+    if (!h->params_set) return fail(h, -1, "mfgp_get_K: no parameters yet (call mfgp_eval / mfgp_factorize first)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t N = h->N;
+    double* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, (size_t)N * N * sizeof(double)));
+    launch_kbuild_full(h->stream, h->spec, h->dX, h->dparams, (int)N, (int)h->Np, d, (int)N);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, d, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipFree(d));
+    return 0;
+}
+int32_t mfgp_get_L(mfgp_handle* h, double* out) {
+    if (!h || !out) return fail(h, -1, "mfgp_get_L: NULL");
+    if (!h->factorized) return fail(h, -1, "mfgp_get_L: no valid factorisation");
+    HIPCHK(h, hipSetDevice(h->device));
+    return copy_block(h, h->buf[BUF_L], out, 0);
+}
+int32_t mfgp_get_Linv(mfgp_handle* h, double* out) {
+    if (!h || !out) return fail(h, -1, "mfgp_get_Linv: NULL");
+    if (!h->factorized) return fail(h, -1, "mfgp_get_Linv: no valid factorisation");
+    HIPCHK(h, hipSetDevice(h->device));
+    return copy_block(h, h->buf[BUF_S], out, 0);
+}
+int32_t mfgp_get_Kinv(mfgp_handle* h, double* out) {
+    if (!h || !out) return fail(h, -1, "mfgp_get_Kinv: NULL");
+    if (!h->factorized || !h->kinv_valid) return fail(h, -1, "mfgp_get_Kinv: K^-1 not available (evaluate with want_grad)");
+    HIPCHK(h, hipSetDevice(h->device));
+    return copy_block(h, h->buf[BUF_A], out, 1);
+}
+int32_t mfgp_get_alpha(mfgp_handle* h, double* out) {
+    if (!h || !out) return fail(h, -1, "mfgp_get_alpha: NULL");
+    if (!h->factorized) return fail(h, -1, "mfgp_get_alpha: no valid factorisation");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(out, h->dalpha, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out) {
+    if (!h || !out) return fail(h, -1, "mfgp_get_timings: NULL");
+    *out = h->tm;
+    return 0;
+}
+
+// ---- test hooks ---------------------------------------------------------------------------------------
+int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, double* C, int32_t M, int32_t N,
+                         int32_t K, double alpha, double beta, int32_t tile) {
+    if (!h || !A || !B || !C) return fail(h, -1, "mfgp_dbg_gemm_nt: NULL");
+    if ((tile != 128 && tile != 64) || M % tile || N % tile || K % BK || K < BK)
+        return fail(h, -1, "mfgp_dbg_gemm_nt: M, N must be multiples of the tile and K of 32");
+    HIPCHK(h, hipSetDevice(h->device));
+    // one common leading dimension
+    const int ld = std::max(K, N);
+    double *dA, *dB, *dC;
+    GemmTask* dt;
+    HIPCHK(h, hipMalloc(&dA, (size_t)M * ld * 8));
+    HIPCHK(h, hipMalloc(&dB, (size_t)N * ld * 8));
+    HIPCHK(h, hipMalloc(&dC, (size_t)M * ld * 8));
+    HIPCHK(h, hipMemcpy2D(dA, (size_t)ld * 8, A, (size_t)K * 8, (size_t)K * 8, M, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy2D(dB, (size_t)ld * 8, B, (size_t)K * 8, (size_t)K * 8, N, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy2D(dC, (size_t)ld * 8, C, (size_t)N * 8, (size_t)N * 8, M, hipMemcpyHostToDevice));
+    std::vector<GemmTask> ts;
+    for (int i = 0; i < M / tile; ++i)
+        for (int j = 0; j < N / tile; ++j) {
+            GemmTask t{};
+            t.a_off = (int64_t)i * tile * ld;
+            t.b_off = (int64_t)j * tile * ld;
+            t.c_off = (int64_t)i * tile * ld + j * tile;
+            t.c2_off = -1;
+            t.klen = K;
+            t.alpha = alpha; t.beta = beta;
+            ts.push_back(t);
+        }
+    HIPCHK(h, hipMalloc(&dt, ts.size() * sizeof(GemmTask)));
+    HIPCHK(h, hipMemcpy(dt, ts.data(), ts.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+    launch_gemm(h->stream, tile, dt, (int)ts.size(), dA, dB, dC, nullptr, ld);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpy2D(C, (size_t)N * 8, dC, (size_t)ld * 8, (size_t)N * 8, M, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dt);
+    return 0;
+}
+
+int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xout, double* logdet_half) {
+    if (!h || !A || !Lout || !Xout || !logdet_half) return fail(h, -1, "mfgp_dbg_leaf: NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    double *dA, *dL, *dS, *dl;
+    int* di;
+    const size_t bytes = (size_t)NB * NB * 8;
+    HIPCHK(h, hipMalloc(&dA, bytes)); HIPCHK(h, hipMalloc(&dL, bytes)); HIPCHK(h, hipMalloc(&dS, bytes));
+    HIPCHK(h, hipMalloc(&dl, 8)); HIPCHK(h, hipMalloc(&di, 4));
+    HIPCHK(h, hipMemcpy(dA, A, bytes, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(di, 0, 4));
+    launch_leaf(h->stream, dA, dL, dS, NB, 0, dl, di);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    int info = 0;
+    HIPCHK(h, hipMemcpy(Lout, dL, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(Xout, dS, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(logdet_half, dl, 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&info, di, 4, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dL); hipFree(dS); hipFree(dl); hipFree(di);
+    return info;
+}
+
+int32_t mfgp_dbg_probe(mfgp_handle* h, double* mfma_f64_tflops, double* copy_gbs) {
+    if (!h || !mfma_f64_tflops || !copy_gbs) return fail(h, -1, "mfgp_dbg_probe: NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    run_probe(h->stream, mfma_f64_tflops, copy_gbs);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

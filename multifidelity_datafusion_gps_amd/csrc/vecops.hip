@@ -1,0 +1,143 @@
+// vecops.hip -- the bandwidth-bound vector pieces: triangular mat-vecs with the explicit inverse
+// factor (alpha = L^-T (L^-1 y), replacing LAPACK dpotrs behind GPy's exact inference, SURVEY 8(a)
+// a5), row sums of squares for the predictive variance (a11), the log-det / quadratic-form finish
+// (a6) and the peak probes used by bench.py.
+#include "mfgp_internal.h"
+
+namespace mfgp {
+
+// one wave per row, 16 B per lane, rows fully coalesced; mode 0: k<=i, 1: k>=i, 2: all
+__global__ __launch_bounds__(256) void mfgp_rowdot_f64(const double* __restrict__ M, int ld,
+                                                       const double* __restrict__ x, double* __restrict__ y,
+                                                       int nrows, int ncols, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    int k0 = 0, k1 = ncols;  // [k0, k1)
+    if (mode == 0) k1 = row + 1;
+    if (mode == 1) k0 = row;
+    const double* mp = M + (int64_t)row * ld;
+    double s = 0.0;
+    const int ka = k0 & ~1;  // aligned start (pairs)
+    for (int k = ka + 2 * lane; k < k1; k += 128) {
+        const d2_t m = *reinterpret_cast<const d2_t*>(mp + k);
+        const d2_t v = *reinterpret_cast<const d2_t*>(x + k);
+        if (k >= k0) s += m.x * v.x;
+        if (k + 1 >= k0 && k + 1 < k1) s += m.y * v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) y[row] = s;
+}
+
+__global__ __launch_bounds__(256) void mfgp_rowsumsq_f64(const double* __restrict__ M, int ld,
+                                                         double* __restrict__ out, int nrows, int ncols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const double* mp = M + (int64_t)row * ld;
+    double s = 0.0;
+    for (int k = 2 * lane; k < ncols; k += 128) {
+        const d2_t m = *reinterpret_cast<const d2_t*>(mp + k);
+        s += m.x * m.x + m.y * m.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void mfgp_finish_solve_f64(const double* __restrict__ z, int Np,
+                                                             const double* __restrict__ logdet_part, int nblk,
+                                                             double* __restrict__ scalars) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < Np; i += 256) s += z[i] * z[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        scalars[0] = red[0];
+        double ld = 0.0;
+        for (int b = 0; b < nblk; ++b) ld += logdet_part[b];
+        scalars[1] = 2.0 * ld;
+    }
+}
+
+void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
+                   int ncols, int mode) {
+    hipLaunchKernelGGL(mfgp_rowdot_f64, dim3((nrows + 3) / 4), dim3(256), 0, s, M, ld, x, y, nrows, ncols, mode);
+}
+void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols) {
+    hipLaunchKernelGGL(mfgp_rowsumsq_f64, dim3((nrows + 3) / 4), dim3(256), 0, s, M, ld, out, nrows, ncols);
+}
+void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* logdet_part, int nblk,
+                         double* scalars) {
+    hipLaunchKernelGGL(mfgp_finish_solve_f64, dim3(1), dim3(256), 0, s, z, Np, logdet_part, nblk, scalars);
+}
+
+// ---- probes ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfgp_probe_mfma_f64(double* out, int iters) {
+    d4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;  // keep the loop alive
+}
+
+__global__ __launch_bounds__(256) void mfgp_probe_copy(const d2_t* __restrict__ src, d2_t* __restrict__ dst,
+                                                       int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    double* dummy = nullptr;
+    hipMalloc(&dummy, 64);
+    // MFMA: 256 CUs x 4 blocks x 4 waves, 8 independent accumulators each
+    const int iters = 20000, blocks = 1024;
+    hipLaunchKernelGGL(mfgp_probe_mfma_f64, dim3(blocks), dim3(256), 0, s, dummy, 100);  // warm
+    hipEventRecord(e0, s);
+    hipLaunchKernelGGL(mfgp_probe_mfma_f64, dim3(blocks), dim3(256), 0, s, dummy, iters);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
+    *mfma_tflops = flops / (ms * 1e-3) / 1e12;
+    // copy 1 GiB
+    const int64_t bytes = (int64_t)1 << 30;
+    d2_t *src = nullptr, *dst = nullptr;
+    hipMalloc(&src, bytes);
+    hipMalloc(&dst, bytes);
+    hipMemsetAsync(src, 1, bytes, s);
+    hipLaunchKernelGGL(mfgp_probe_copy, dim3(4096), dim3(256), 0, s, src, dst, bytes / 16);
+    hipEventRecord(e0, s);
+    for (int r = 0; r < 5; ++r)
+        hipLaunchKernelGGL(mfgp_probe_copy, dim3(4096), dim3(256), 0, s, src, dst, bytes / 16);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    *copy_gbs = 5.0 * 2.0 * (double)bytes / (ms * 1e-3) / 1e9;
+    hipFree(src);
+    hipFree(dst);
+    hipFree(dummy);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+}
+
+}  // namespace mfgp

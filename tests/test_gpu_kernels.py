@@ -1,0 +1,73 @@
+"""Kernel-level GPU tests through the C-ABI test hooks (include/mfgp.h: mfgp_dbg_*)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_is_gfx950(engine):
+    assert "gfx950" in engine.device_info, engine.device_info
+
+
+@pytest.mark.parametrize("tile", [128, 64])
+def test_mfma_layout_identity_times_asymmetric(engine, tile):
+    """A = I with an ASYMMETRIC B catches a swapped C/D lane map (guide: cdna_hip_programming.md section 3)."""
+    n = 128
+    A = np.eye(n)
+    B = np.arange(n * n, dtype=float).reshape(n, n) / 7.0  # B[j][k], asymmetric
+    C = engine.dbg_gemm_nt(A, B, np.zeros((n, n)), tile=tile)
+    np.testing.assert_array_equal(C, B.T)  # C[i][j] = sum_k I[i][k] B[j][k] = B[j][i]
+
+
+@pytest.mark.parametrize("tile,M,N,K", [(128, 128, 128, 32), (128, 256, 384, 160), (64, 64, 192, 96), (64, 320, 128, 512)])
+def test_gemm_nt_against_numpy(engine, tile, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K))
+    C0 = rng.standard_normal((M, N))
+    C = engine.dbg_gemm_nt(A, B, C0, alpha=-1.5, beta=0.75, tile=tile)
+    ref = -1.5 * A @ B.T + 0.75 * C0
+    err = np.abs(C - ref).max()
+    assert err < 1e-12 * K, err
+    # beta = 0 must not read C (NaN garbage in the output buffer is legal)
+    Cn = engine.dbg_gemm_nt(A, B, np.full((M, N), np.nan), alpha=1.0, beta=0.0, tile=tile)
+    assert np.isfinite(Cn).all()
+    assert np.abs(Cn - A @ B.T).max() < 1e-12 * K
+
+
+def _spd(n, rng, cond=1e3):
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    w = np.logspace(0, np.log10(cond), n)
+    return (Q * w) @ Q.T
+
+
+@pytest.mark.parametrize("cond", [1e2, 1e8])
+def test_leaf_cholesky_and_inverse(engine, cond):
+    rng = np.random.default_rng(int(np.log10(cond)))
+    A = _spd(128, rng, cond)
+    Ain = A.copy()
+    Ain[np.triu_indices(128, 1)] = np.nan  # the leaf must never read above the diagonal
+    L, S, half_logdet, info = engine.dbg_leaf(Ain)
+    assert info == 0
+    Lref = np.linalg.cholesky(A)
+    assert np.all(np.triu(L, 1) == 0)
+    assert np.abs(L @ L.T - A).max() / np.abs(A).max() < 1e-14 * 128
+    assert np.abs(L - Lref).max() / np.abs(Lref).max() < 1e-10 * np.sqrt(cond)
+    assert half_logdet == pytest.approx(np.log(np.diag(Lref)).sum(), rel=1e-12)
+    X = np.tril(S)
+    np.testing.assert_array_equal(S, S.T)  # stored mirrored
+    assert np.abs(X @ L - np.eye(128)).max() < 1e-13 * np.sqrt(cond) * 128
+
+
+def test_leaf_reports_non_positive_pivot(engine):
+    A = np.eye(128)
+    A[40, 40] = -1.0
+    _, _, _, info = engine.dbg_leaf(A)
+    assert info == 41
+
+
+def test_probe_peaks(engine):
+    tf, gbs = engine.dbg_probe()
+    print("fp64 MFMA probe: %.1f TFLOP/s, copy probe: %.0f GB/s" % (tf, gbs))
+    assert tf > 30.0
+    assert gbs > 2000.0

@@ -1,0 +1,220 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at the bench size -- through
+size-independent properties.
+
+Stated fp64 tolerances (the oracle is "parity unpinned" w.r.t. GPy itself):
+  K entries      abs <= 2e-13 * sigma^2 * (1 + 1/l^2)  (GPy's |x|^2+|x'|^2-2x.x' form loses ~eps|x|^2/l^2; ours does not)
+  logdet, NLML   rel <= 1e-10 (noise >= 1e-4 var), <= 1e-7 in the add_noise regime (noise = 1e-6)
+  gradient       rel <= 1e-8 of the gradient's max-norm (1e-5 in the add_noise regime)
+  mean / var     abs <= 1e-9 * max(1, |y|_inf) (1e-6 in the add_noise regime)
+  L, alpha only through residuals: |L L^T - Ky|_F / |Ky|_F <= 1e-14 N ; |Ky alpha - y| / |y| <= 1e-12 * cond-ish
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as orc
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _run(engine, parts, theta, noise, X, Y, Xs):
+    engine.set_data(X, Y)
+    engine.set_kernel(parts)
+    nlml, grad = engine.eval(theta, noise, 1e-8, want_grad=True)
+    mean, var = engine.predict(Xs, want_var=True, include_noise=True)
+    return nlml, grad, mean, var
+
+
+@pytest.mark.parametrize("name", cases.GOLDEN_CASES)
+def test_golden_vectors(engine, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    parts = [tuple(int(v) for v in p) for p in g["parts"]]
+    theta, noise = g["theta"], float(g["noise"])
+    tight = noise >= 1e-4
+    nlml, grad, mean, var = _run(engine, parts, theta, noise, g["X"], g["Y"], g["Xs"])
+    K = engine.get_K()
+    lmin = theta[1::2].min()
+    assert np.abs(K - g["K"]).max() <= 2e-13 * theta[0::2].max() ** 2 * (1 + 1 / lmin ** 2)
+    N = len(g["Y"])
+    Ky = g["K"] + (noise + 1e-8) * np.eye(N)
+    L = engine.get_L()
+    assert np.linalg.norm(L @ L.T - Ky) / np.linalg.norm(Ky) <= 1e-14 * N
+    alpha = engine.get_alpha()
+    assert np.linalg.norm(Ky @ alpha - g["Y"]) / np.linalg.norm(g["Y"]) <= 1e-11 * (1 if tight else 1e3)
+    assert nlml == pytest.approx(float(g["nlml"]), rel=1e-10 if tight else 1e-7)
+    gtol = (1e-8 if tight else 1e-5) * np.abs(g["grad"]).max()
+    np.testing.assert_allclose(grad, g["grad"], rtol=0, atol=gtol)
+    ytol = (1e-9 if tight else 1e-6) * max(1.0, np.abs(g["Y"]).max())
+    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=ytol)
+    np.testing.assert_allclose(var, g["var"], rtol=0, atol=ytol)
+
+
+def test_kinv_and_state_machine(engine):
+    c = cases.make_case("nargp_4d_n64")
+    engine.set_data(c["X"], c["Y"])
+    engine.set_kernel(c["parts"])
+    with pytest.raises(RuntimeError):
+        engine.predict(c["Xs"])  # no factorisation yet
+    engine.factorize(c["theta"], c["noise"], 1e-8)
+    st = orc.inference(c["parts"], np.array(c["theta"]), c["noise"], c["X"], c["Y"])
+    assert engine.nlml() == pytest.approx(st["nlml"], rel=1e-10)
+    with pytest.raises(RuntimeError):
+        engine.get_Kinv()  # not computed yet
+    g = engine.nlml_grad()  # lazily runs K^-1 + reduction
+    np.testing.assert_allclose(g, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    Kinv = engine.get_Kinv()
+    np.testing.assert_allclose(Kinv, st["Kinv"], rtol=0, atol=1e-9 * np.abs(st["Kinv"]).max())
+    engine.predict(c["Xs"])
+    with pytest.raises(RuntimeError):
+        engine.get_Kinv()  # predict's V overwrote the storage: refused, not silently wrong
+
+
+@pytest.mark.parametrize("N", [1, 2, 5, 63, 64, 65, 127, 128, 129, 200, 256, 300, 515])
+def test_ragged_sizes_against_oracle(engine, N):
+    """padding / tile-edge cases: every N around the 64/128 granules, single RBF and composite."""
+    rng = np.random.default_rng(N)
+    X = rng.uniform(size=(N, 3))
+    Y = cases.hf_3d(X) - 5.0
+    Xs = rng.uniform(size=(7, 3))
+    for parts, theta in ((cases.single(cases.RBF, 3), [1.1, 0.4]),
+                         (cases.composite(2, 1), [1.2, 0.9, 0.8, 0.5, 0.3, 0.7])):
+        theta = np.array(theta)
+        noise = 0.05
+        st = orc.inference(parts, theta, noise, X, Y)
+        mu, var = orc.predict(parts, theta, noise, X, st, Xs)
+        nlml, grad, mean, v = _run(engine, parts, theta, noise, X, Y, Xs)
+        assert nlml == pytest.approx(st["nlml"], rel=1e-10, abs=1e-10)
+        np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * max(1.0, np.abs(st["grad"]).max()))
+        np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(v, var, rtol=0, atol=1e-9)
+
+
+def test_predict_many_rows_chunks_and_noise_flag(engine):
+    """N* > N (several panels), N* = 1 (the DIRECT callback shape), include_noise on/off, mean-only."""
+    c = cases.make_case("rbf_3d_n50")
+    theta = np.array(c["theta"])
+    st = orc.inference(c["parts"], theta, c["noise"], c["X"], c["Y"])
+    engine.set_data(c["X"], c["Y"])
+    engine.set_kernel(c["parts"])
+    engine.factorize(theta, c["noise"], 1e-8)
+    Xs = np.random.default_rng(5).uniform(size=(1000, 3))
+    mu, var = orc.predict(c["parts"], theta, c["noise"], c["X"], st, Xs, include_noise=False)
+    m, v = engine.predict(Xs, want_var=True, include_noise=False)
+    np.testing.assert_allclose(m, mu, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v, var, rtol=0, atol=1e-9)
+    m1, v1 = engine.predict(Xs[:1], want_var=True, include_noise=True)
+    assert m1[0] == pytest.approx(mu[0], abs=1e-9) and v1[0] == pytest.approx(var[0] + c["noise"], abs=1e-9)
+    m2, v2 = engine.predict(Xs[:33], want_var=False)
+    assert v2 is None
+    np.testing.assert_allclose(m2, mu[:33], rtol=0, atol=1e-9)
+
+
+def test_not_positive_definite_is_reported(engine):
+    """duplicate rows + zero noise + zero jitter -> singular Ky -> status > 0 (GPy's jitchol retry is the caller's policy)."""
+    from multifidelity_datafusion_gps_amd._lib import NotPositiveDefinite
+    X = np.random.default_rng(1).uniform(size=(40, 2))
+    X[7] = X[3]
+    X[20] = X[3]
+    engine.set_data(X, np.ones(40))
+    engine.set_kernel(cases.single(cases.RBF, 2))
+    with pytest.raises(NotPositiveDefinite) as ei:
+        engine.eval([1.0, 0.5], 0.0, 0.0)
+    assert 1 <= ei.value.info <= 40
+    nlml, _ = engine.eval([1.0, 0.5], 0.0, 1e-6)  # retry with jitter succeeds
+    assert np.isfinite(nlml)
+
+
+def test_argument_errors(engine):
+    with pytest.raises(RuntimeError):
+        engine.eval([1.0, 1.0], 0.1)  # no data
+    engine.set_data(np.zeros((4, 2)), np.zeros(4))
+    with pytest.raises(RuntimeError):
+        engine.set_kernel([(0, 0, 2, 0)] * 7)  # too many parts
+    engine.set_kernel([(0, 0, 3, 0)])
+    with pytest.raises(RuntimeError):
+        engine.eval([1.0, 1.0], 0.1)  # column range exceeds D
+    engine.set_kernel([(0, 0, 2, 0)])
+    with pytest.raises(RuntimeError):
+        engine.eval([1.0, -1.0], 0.1)  # non-positive lengthscale
+
+
+def test_refit_with_new_sizes_reuses_handle(engine):
+    """the adaptation loop refits with N growing by one row per step (src/abstractMFGP.py:320,354)."""
+    rng = np.random.default_rng(3)
+    Xall = rng.uniform(size=(140, 2))
+    Yall = cases.hf_2d(Xall)
+    parts, theta = cases.single(cases.RBF, 2), np.array([0.8, 0.3])
+    engine.set_kernel(parts)
+    for n in (126, 127, 128, 129, 130, 60):
+        engine.set_data(Xall[:n], Yall[:n])
+        nlml, grad = engine.eval(theta, 0.01)
+        st = orc.inference(parts, theta, 0.01, Xall[:n], Yall[:n])
+        assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+        np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+
+
+def test_medium_size_all_tile_paths(engine):
+    """N = 2500 (Np = 2560, 20 leaf blocks: odd splits, both tile sizes) against the oracle."""
+    rng = np.random.default_rng(11)
+    N = 2500
+    X = rng.uniform(size=(N, 4))
+    Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    st = orc.inference(parts, theta, noise, Xa, Y)
+    Xs = rng.uniform(size=(300, 4))
+    Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
+    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
+    nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
+    print("N=2500 timings:", engine.timings())
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
+
+
+def test_bench_size_properties(engine):
+    """N = 8192 (BASELINE.json north-star size): size-independent properties instead of an O(N^3) CPU run.
+       * L^-1 really inverts L on random probe vectors:  X (L u) = u
+       * alpha solves the system: |Ky alpha - y| small (Ky applied through the returned K rows on a sample)
+       * NLML is permutation invariant; gradient matches a central difference of the HIP objective itself
+    """
+    rng = np.random.default_rng(8192)
+    N = 8192
+    X = rng.uniform(size=(N, 4))
+    Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    engine.set_data(Xa, Y)
+    engine.set_kernel(parts)
+    nlml, grad = engine.eval(theta, noise)
+    print("N=8192 timings:", engine.timings())
+    alpha = engine.get_alpha()
+    # residual on a sample of rows, rows of Ky from the oracle's kernel
+    rows = rng.choice(N, 64, replace=False)
+    Krows = orc.cov(parts, theta, Xa[rows], Xa)
+    res = Krows @ alpha + (noise + 1e-8) * alpha[rows] - Y[rows]
+    assert np.abs(res).max() <= 1e-9 * np.abs(Y).max()
+    # permutation invariance
+    perm = rng.permutation(N)
+    engine.set_data(Xa[perm], Y[perm])
+    nlml_p, grad_p = engine.eval(theta, noise)
+    assert nlml_p == pytest.approx(nlml, rel=1e-10)
+    np.testing.assert_allclose(grad_p, grad, rtol=0, atol=1e-7 * np.abs(grad).max())
+    # directional central difference of the HIP objective
+    d = rng.standard_normal(7)
+    d /= np.linalg.norm(d)
+    p = np.concatenate([theta, [noise]])
+    h = 1e-5
+    fp = engine.eval((p + h * d * p)[:-1], (p + h * d * p)[-1], want_grad=False)
+    fm = engine.eval((p - h * d * p)[:-1], (p - h * d * p)[-1], want_grad=False)
+    assert (fp - fm) / (2 * h) == pytest.approx(float(grad_p @ (d * p)), rel=2e-4)
+    # variance is within [0, kss] and mean interpolates the data at training inputs
+    engine.eval(theta, noise, want_grad=False)
+    m, v = engine.predict(Xa[perm][:256], include_noise=False)
+    assert np.all(v >= 1e-15) and np.all(v <= theta[0] * theta[2] + theta[4] + 1e-12)
+    assert np.abs(m - Y[perm][:256]).max() < 0.2
