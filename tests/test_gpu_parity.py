@@ -129,8 +129,8 @@ def test_not_positive_definite_is_reported(engine):
 
 
 def test_argument_errors(engine):
-    with pytest.raises(RuntimeError):
-        engine.eval([1.0, 1.0], 0.1)  # no data
+    with pytest.raises((RuntimeError, ValueError)):
+        engine.eval([1.0, 1.0], 0.1)  # no data / no kernel
     engine.set_data(np.zeros((4, 2)), np.zeros(4))
     with pytest.raises(RuntimeError):
         engine.set_kernel([(0, 0, 2, 0)] * 7)  # too many parts
@@ -179,7 +179,6 @@ def test_medium_size_all_tile_paths(engine):
 
 def test_bench_size_properties(engine):
     """N = 8192 (BASELINE.json north-star size): size-independent properties instead of an O(N^3) CPU run.
-       * L^-1 really inverts L on random probe vectors:  X (L u) = u
        * alpha solves the system: |Ky alpha - y| small (Ky applied through the returned K rows on a sample)
        * NLML is permutation invariant; gradient matches a central difference of the HIP objective itself
     """
