@@ -65,6 +65,14 @@ typedef struct mfgp_timings {
     int64_t n_launches;  /* kernel launches issued by the call                                          */
 } mfgp_timings;
 
+/* running sums over every mfgp_eval / mfgp_predict since the last reset: lets a benchmark attribute
+ * the timed region to kernels with HIP events recorded on the engine's own stream. */
+typedef struct mfgp_counters {
+    double evals, grad_evals, predicts, predict_rows;
+    double kbuild_ms, cholinv_ms, solve_ms, kinv_ms, grad_ms, total_ms, predict_ms;
+    double kbuild_bytes, kinv_flops, cholinv_flops;
+} mfgp_counters;
+
 /* ---- lifecycle --------------------------------------------------------------------------------- */
 
 /* create an engine on HIP device `device_id` (one stream). Fails loudly (<0) when no HIP device. */
@@ -114,6 +122,7 @@ int32_t mfgp_get_Linv(mfgp_handle* h, double* out);   /* L^-1 lower             
 int32_t mfgp_get_Kinv(mfgp_handle* h, double* out);   /* Ky^-1 full symmetric (valid after a gradient)    */
 int32_t mfgp_get_alpha(mfgp_handle* h, double* out);  /* alpha (N)                                        */
 int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out);
+int32_t mfgp_get_counters(mfgp_handle* h, mfgp_counters* out, int32_t reset);
 
 /* ---- kernel-level test hooks (tests/ only) -------------------------------------------------------- */
 /* C = alpha * A B^T + beta * C on Mp x Np x Kp host matrices (multiples of 128) through the MFMA
@@ -125,6 +134,10 @@ int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xou
 /* peak probes: returns achieved TFLOP/s of a bare v_mfma_f64_16x16x4_f64 loop and GB/s of a
  * 1 GiB device copy (used by bench.py to sanity-check the roofline denominators). */
 int32_t mfgp_dbg_probe(mfgp_handle* h, double* mfma_f64_tflops, double* copy_gbs);
+/* out12[3*c + {0,1,2}] = {TFLOP/s, shader cycles per v_mfma_f64_16x16x4_f64 per wave, shader clock GHz} for
+ * c = 0: 1 wave/SIMD x 8 accumulators, 1: 2 waves/SIMD, 2: 4 waves/SIMD, 3: 1 wave/SIMD x 1 (dependent chain);
+ * out[12..15] = v_fma_f64 VALU TFLOP/s at 2 / 4 waves per SIMD, and VALU+MFMA mixed-issue totals (2 / 4 waves). out has 16 entries. */
+int32_t mfgp_dbg_probe_detail(mfgp_handle* h, double* out16);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,8 @@ EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
     "mfgp_set_kernel", "mfgp_eval", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_predict",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
-    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_probe",
+    "mfgp_get_counters",
+    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_probe", "mfgp_dbg_probe_detail",
 ]
 
 
@@ -45,6 +46,15 @@ class Timings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in (
         "kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms", "grad_ms", "predict_panel_ms", "predict_var_ms",
         "total_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops")] + [("n_launches", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in (
+        "evals", "grad_evals", "predicts", "predict_rows", "kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms",
+        "grad_ms", "total_ms", "predict_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -88,9 +98,11 @@ def load_library(path=None):
         "mfgp_get_Kinv": (i32, [H, dp]),
         "mfgp_get_alpha": (i32, [H, dp]),
         "mfgp_get_timings": (i32, [H, ctypes.POINTER(Timings)]),
+        "mfgp_get_counters": (i32, [H, ctypes.POINTER(Counters), i32]),
         "mfgp_dbg_gemm_nt": (i32, [H, dp, dp, dp, i32, i32, i32, f64, f64, i32]),
         "mfgp_dbg_leaf": (i32, [H, dp, dp, dp, dp]),
         "mfgp_dbg_probe": (i32, [H, dp, dp]),
+        "mfgp_dbg_probe_detail": (i32, [H, dp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -231,6 +243,11 @@ class Engine:
         self._check(self._lib.mfgp_get_timings(self._h, ctypes.byref(t)), "mfgp_get_timings")
         return t.as_dict()
 
+    def counters(self, reset=False):
+        c = Counters()
+        self._check(self._lib.mfgp_get_counters(self._h, ctypes.byref(c), int(bool(reset))), "mfgp_get_counters")
+        return c.as_dict()
+
     # -- kernel-level test hooks ----------------------------------------------------------------
     def dbg_gemm_nt(self, A, B, C, alpha=1.0, beta=0.0, tile=128):
         A, B = _c64(A), _c64(B)
@@ -250,6 +267,16 @@ class Engine:
         if rc < 0:
             self._check(rc, "mfgp_dbg_leaf")
         return L, X, ld.value, rc
+
+    def dbg_probe_detail(self):
+        out = np.zeros(16)
+        self._check(self._lib.mfgp_dbg_probe_detail(self._h, _dptr(out)), "mfgp_dbg_probe_detail")
+        names = ["1w/SIMD x8acc", "2w/SIMD x8acc", "4w/SIMD x8acc", "1w/SIMD x1acc"]
+        d = {n: dict(tflops=out[3 * i], cycles_per_mfma=out[3 * i + 1], clock_ghz=out[3 * i + 2])
+             for i, n in enumerate(names)}
+        d["valu_fma_f64_tflops"] = {"2w/SIMD": out[12], "4w/SIMD": out[13]}
+        d["valu_plus_mfma_tflops"] = {"2w/SIMD": out[14], "4w/SIMD": out[15]}
+        return d
 
     def dbg_probe(self):
         a, b = ctypes.c_double(), ctypes.c_double()

@@ -18,9 +18,8 @@
 namespace mfgp {
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64(const GemmTask* __restrict__ tasks,
-                                                           const double* A, const double* B,
-                                                           double* C, double* C2, int ld) {
+__device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks, const double* A, const double* B,
+                                             double* C, double* C2, int ld) {
     constexpr int TM = BM / 32;   // 16-row MFMA blocks per wave along M (wave grid is 2 x 2)
     constexpr int TN = BN / 32;
     constexpr int NA = BM / 16;   // 16-byte chunks per thread per K-step (BM*16 chunks / 256 threads)
@@ -156,26 +155,56 @@ __global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64(const GemmTask* __res
     }
 }
 
+// Named entry points over the same tile body, so that a kernel trace separates the roles:
+//   mfgp_gemm_nt_f64_t128 / _t64 : the many launches of the recursive Cholesky + inverse
+//   mfgp_kinv_syrk_f64           : the ONE launch per evaluation that forms K^-1 = L^-T L^-1 (N^3/3 flops)
+//   mfgp_predvar_f64             : the predictive-variance product V = K(X*,X) L^-T
+__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64_t128(const GemmTask* __restrict__ tasks, const double* A,
+                                                                const double* B, double* C, double* C2, int ld) {
+    gemm_nt_tile<128, 128>(tasks, A, B, C, C2, ld);
+}
+__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
+                                                               const double* B, double* C, double* C2, int ld) {
+    gemm_nt_tile<64, 64>(tasks, A, B, C, C2, ld);
+}
+__global__ __launch_bounds__(256, 1) void mfgp_kinv_syrk_f64(const GemmTask* __restrict__ tasks, const double* A,
+                                                             const double* B, double* C, double* C2, int ld) {
+    gemm_nt_tile<128, 128>(tasks, A, B, C, C2, ld);
+}
+__global__ __launch_bounds__(256, 1) void mfgp_kinv_syrk_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
+                                                                 const double* B, double* C, double* C2, int ld) {
+    gemm_nt_tile<64, 64>(tasks, A, B, C, C2, ld);
+}
+__global__ __launch_bounds__(256, 1) void mfgp_predvar_f64(const GemmTask* __restrict__ tasks, const double* A,
+                                                           const double* B, double* C, double* C2, int ld) {
+    gemm_nt_tile<128, 128>(tasks, A, B, C, C2, ld);
+}
+__global__ __launch_bounds__(256, 1) void mfgp_predvar_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
+                                                               const double* B, double* C, double* C2, int ld) {
+    gemm_nt_tile<64, 64>(tasks, A, B, C, C2, ld);
+}
+
 size_t gemm_lds_bytes(int tile) { return (size_t)2 * (tile + tile) * BK * sizeof(double); }
 
+typedef void (*gemm_kernel_t)(const GemmTask*, const double*, const double*, double*, double*, int);
+
 void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
-                 const double* B, double* C, double* C2, int ld) {
+                 const double* B, double* C, double* C2, int ld, int role) {
     if (ntasks <= 0) return;
+    static const gemm_kernel_t table[3][2] = {{mfgp_gemm_nt_f64_t128, mfgp_gemm_nt_f64_t64},
+                                              {mfgp_kinv_syrk_f64, mfgp_kinv_syrk_f64_t64},
+                                              {mfgp_predvar_f64, mfgp_predvar_f64_t64}};
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_gemm_nt_f64<128, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_gemm_nt_f64<64, 64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(64));
+        for (int r = 0; r < 3; ++r)
+            for (int t = 0; t < 2; ++t)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[r][t]),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)gemm_lds_bytes(t == 0 ? 128 : 64));
         attr_set = true;
     }
-    if (tile == 128) {
-        hipLaunchKernelGGL((mfgp_gemm_nt_f64<128, 128>), dim3(ntasks), dim3(256), gemm_lds_bytes(128), s,
-                           tasks, A, B, C, C2, ld);
-    } else {
-        hipLaunchKernelGGL((mfgp_gemm_nt_f64<64, 64>), dim3(ntasks), dim3(256), gemm_lds_bytes(64), s,
-                           tasks, A, B, C, C2, ld);
-    }
+    const gemm_kernel_t k = table[role][tile == 128 ? 0 : 1];
+    hipLaunchKernelGGL(k, dim3(ntasks), dim3(256), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld);
 }
 
 }  // namespace mfgp

@@ -26,6 +26,7 @@ enum Buf { BUF_A = 0, BUF_L = 1, BUF_S = 2, BUF_W = 3 };
 
 struct Step {
     int kind;  // 0 = leaf, 1 = gemm
+    int role;  // gemm kernel symbol: 0 recursion, 1 K^-1, 2 predictive variance
     int blk;   // leaf block
     int tile, first, count, a, b, c, c2;  // gemm
 };
@@ -60,6 +61,7 @@ struct mfgp_handle {
     double grad[2 * MFGP_MAX_PARTS + 1] = {0};
     hipEvent_t ev[10];
     mfgp_timings tm{};
+    mfgp_counters cum{};
     int64_t launches = 0;
 };
 
@@ -206,6 +208,7 @@ static void plan_kinv(mfgp_handle* h) {
     std::vector<Step> tmp;
     add_gemm(h, tmp, T, first, BUF_S, BUF_S, BUF_A, -1);
     h->kinv_step = tmp.empty() ? Step{} : tmp[0];
+    h->kinv_step.role = 1;
 }
 
 // V[r][i] = sum_{k<=i} Kx[r][k] X[i][k]   (A: W = Kx panel, B: S lower rows i, C: A)
@@ -230,6 +233,7 @@ static void plan_predv(mfgp_handle* h, int rows_p) {
     std::vector<Step> tmp;
     add_gemm(h, tmp, T, first, BUF_W, BUF_S, BUF_A, -1);
     h->predv_step = tmp.empty() ? Step{} : tmp[0];
+    h->predv_step.role = 2;
     h->predv_rows = rows_p;
 }
 
@@ -250,7 +254,7 @@ static void run_step(mfgp_handle* h, const Step& s) {
         launch_leaf(h->stream, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
     } else {
         launch_gemm(h->stream, s.tile, h->dtasks + s.first, s.count, h->buf[s.a], h->buf[s.b], h->buf[s.c],
-                    s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np);
+                    s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np, s.role);
     }
     h->launches++;
 }
@@ -462,6 +466,17 @@ static int finish_eval(mfgp_handle* h, bool want_grad) {
     t.kinv_flops = np * np * np / 3.0;
     t.cholinv_flops = 2.0 * np * np * np / 3.0;
     t.n_launches = h->launches;
+    h->cum.evals += 1;
+    h->cum.grad_evals += want_grad ? 1 : 0;
+    h->cum.kbuild_ms += t.kbuild_ms;
+    h->cum.cholinv_ms += t.cholinv_ms;
+    h->cum.solve_ms += t.solve_ms;
+    h->cum.kinv_ms += t.kinv_ms;
+    h->cum.grad_ms += t.grad_ms;
+    h->cum.total_ms += t.total_ms;
+    h->cum.kbuild_bytes += t.kbuild_bytes;
+    h->cum.kinv_flops += want_grad ? t.kinv_flops : 0.0;
+    h->cum.cholinv_flops += t.cholinv_flops;
     h->quad = h->hres[0];
     h->logdet = h->hres[1];
     h->kinv_valid = want_grad;
@@ -584,6 +599,9 @@ int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double*
     }
     h->tm.predict_panel_ms = pan_ms;
     h->tm.predict_var_ms = var_ms;
+    h->cum.predicts += 1;
+    h->cum.predict_rows += (double)Nstar;
+    h->cum.predict_ms += pan_ms + var_ms;
     h->tm.n_launches = h->launches;
     return 0;
 }
@@ -643,6 +661,12 @@ int32_t mfgp_get_alpha(mfgp_handle* h, double* out) {
     if (!h->factorized) return fail(h, -1, "mfgp_get_alpha: no valid factorisation");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(out, h->dalpha, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+int32_t mfgp_get_counters(mfgp_handle* h, mfgp_counters* out, int32_t reset) {
+    if (!h || !out) return fail(h, -1, "mfgp_get_counters: NULL");
+    *out = h->cum;
+    if (reset) memset(&h->cum, 0, sizeof h->cum);
     return 0;
 }
 int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out) {
@@ -716,6 +740,15 @@ int32_t mfgp_dbg_probe(mfgp_handle* h, double* mfma_f64_tflops, double* copy_gbs
     if (!h || !mfma_f64_tflops || !copy_gbs) return fail(h, -1, "mfgp_dbg_probe: NULL");
     HIPCHK(h, hipSetDevice(h->device));
     run_probe(h->stream, mfma_f64_tflops, copy_gbs);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int32_t mfgp_dbg_probe_detail(mfgp_handle* h, double* out12) {
+    if (!h || !out12) return fail(h, -1, "mfgp_dbg_probe_detail: NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    run_probe_detail(h->stream, out12);
+    run_probe_valu(h->stream, out12 + 12);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

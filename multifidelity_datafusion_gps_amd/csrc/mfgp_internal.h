@@ -60,8 +60,9 @@ constexpr int MFGP_MAX_GROUPS = 3;
 
 // ---- launchers (implemented in the .hip files) -------------------------------------------------
 // tile: 128 or 64.  tasks = device pointer to ntasks GemmTask.
+// role: 0 = recursion GEMMs, 1 = the K^-1 SYRK launch, 2 = predictive-variance product (distinct kernel symbols)
 void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
-                 const double* B, double* C, double* C2, int ld);
+                 const double* B, double* C, double* C2, int ld, int role = 0);
 size_t gemm_lds_bytes(int tile);
 
 // leaf: Cholesky + inverse of the 128x128 diagonal block `blk` of A (ld), in LDS.
@@ -101,5 +102,7 @@ void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* par
 
 // probes
 void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs);
+void run_probe_detail(hipStream_t s, double* out12);
+void run_probe_valu(hipStream_t s, double* out4);
 
 }  // namespace mfgp

@@ -2,6 +2,8 @@
 // factor (alpha = L^-T (L^-1 y), replacing LAPACK dpotrs behind GPy's exact inference, SURVEY 8(a)
 // a5), row sums of squares for the predictive variance (a11), the log-det / quadratic-form finish
 // (a6) and the peak probes used by bench.py.
+#include <algorithm>
+#include <vector>
 #include "mfgp_internal.h"
 
 namespace mfgp {
@@ -100,6 +102,128 @@ __global__ __launch_bounds__(256) void mfgp_probe_copy(const d2_t* __restrict__ 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// detailed MFMA probe: per-wave shader cycles (s_memtime) and 100 MHz real time around the loop
+template <int NACC>
+__global__ __launch_bounds__(256) void mfgp_probe_mfma_detail(unsigned long long* out, int iters) {
+    d4_t acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        out[2 * w] = t1 - t0 + (s == 12345.678 ? 1 : 0);
+        out[2 * w + 1] = r1 - r0;
+    }
+}
+
+// VALU probe: NCH independent v_fma_f64 chains per lane; MIX: also issue MFMAs from the same wave
+template <int NCH, bool MIX>
+__global__ __launch_bounds__(256) void mfgp_probe_valu_f64(double* out, int iters) {
+    double x[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) x[i] = 1.0 + 1e-3 * (threadIdx.x + i);
+    const double a = 1.0 - 1e-9, b = 1e-9;
+    d4_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) x[i] = __builtin_fma(x[i], a, b);
+        if (MIX) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) s += x[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 12345.678) out[0] = s;
+}
+
+// out4: {VALU-only TFLOP/s (2 waves/SIMD), VALU-only (4 waves/SIMD), mixed total TFLOP/s (2 waves/SIMD: 32 fma + 4 mfma per iter), mixed 4 waves/SIMD}
+void run_probe_valu(hipStream_t s, double* out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    double* dummy = nullptr;
+    hipMalloc(&dummy, 64);
+    const int iters = 20000;
+    for (int c = 0; c < 4; ++c) {
+        const int blocks = (c & 1) ? 1024 : 512;
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, s);
+            if (c < 2) hipLaunchKernelGGL((mfgp_probe_valu_f64<32, false>), dim3(blocks), dim3(256), 0, s, dummy, iters);
+            else hipLaunchKernelGGL((mfgp_probe_valu_f64<32, true>), dim3(blocks), dim3(256), 0, s, dummy, iters);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        const double waves = blocks * 4.0;
+        double flops = waves * iters * 32.0 * 64.0 * 2.0;
+        if (c >= 2) flops += waves * iters * 4.0 * 2048.0;
+        out[c] = flops / (ms * 1e-3) / 1e12;
+    }
+    hipFree(dummy);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+}
+
+// out[3*c + 0..2] = {TFLOP/s, shader cycles per MFMA per wave (median), shader clock GHz} for the configs
+//   c=0: 1 wave/SIMD x 8 acc, c=1: 2 waves/SIMD x 8 acc, c=2: 4 waves/SIMD x 8 acc, c=3: 1 wave/SIMD x 1 acc (dependent)
+void run_probe_detail(hipStream_t s, double* out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    unsigned long long* dbuf = nullptr;
+    const int maxw = 1024 * 4;
+    hipMalloc(&dbuf, sizeof(unsigned long long) * 2 * maxw);
+    std::vector<unsigned long long> hb(2 * maxw);
+    const int iters = 4000;
+    for (int c = 0; c < 4; ++c) {
+        const int blocks = (c == 1) ? 512 : (c == 2) ? 1024 : 256;
+        const int nacc = (c == 3) ? 1 : 8;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, s);
+            if (nacc == 8) hipLaunchKernelGGL((mfgp_probe_mfma_detail<8>), dim3(blocks), dim3(256), 0, s, dbuf, iters);
+            else hipLaunchKernelGGL((mfgp_probe_mfma_detail<1>), dim3(blocks), dim3(256), 0, s, dbuf, iters * 8);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+        }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const int nw = blocks * 4;
+        hipMemcpy(hb.data(), dbuf, sizeof(unsigned long long) * 2 * nw, hipMemcpyDeviceToHost);
+        std::vector<double> cyc(nw), clk(nw);
+        const double nm = (double)iters * 8.0;
+        for (int w = 0; w < nw; ++w) {
+            cyc[w] = (double)hb[2 * w] / nm;
+            clk[w] = (double)hb[2 * w] / ((double)hb[2 * w + 1] * 10.0) ;  // cycles per ns = GHz (realtime ticks are 10 ns)
+        }
+        std::sort(cyc.begin(), cyc.end());
+        std::sort(clk.begin(), clk.end());
+        out[3 * c + 0] = (double)nw * nm * 2048.0 / (ms * 1e-3) / 1e12;
+        out[3 * c + 1] = cyc[nw / 2];
+        out[3 * c + 2] = clk[nw / 2];
+    }
+    hipFree(dbuf);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
 }
 
 void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs) {

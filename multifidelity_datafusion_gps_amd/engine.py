@@ -1,0 +1,541 @@
+"""GPRegression-shaped host objects over the HIP engine: the drop-in for the slice of the GPy API the
+reference touches.
+
+What the reference calls, and where (all under /root/reference):
+  * GPy.kern.RBF(input_dim, active_dims=...), k*k, k+k                 src/abstractMFGP.py:60,77-80
+  * GPy.models.GPRegression(X=, Y=, kernel=, initialize=True)          src/MFDataFusion.py:93-98, src/abstractMFGP.py:100-102
+  * model[".*Gaussian_noise"] = v / .fix() / .unfix() / .constrain_positive(), model.Y
+                                                                       src/abstractMFGP.py:132-136
+  * model.optimize(max_iters=), model.optimize_restarts(n, optimizer="bfgs", max_iters=, verbose=)
+                                                                       src/abstractMFGP.py:103,134,137
+  * model.likelihood.variance = 1e-6                                   src/MFDataFusion.py:155
+  * model.predict(X*) -> (mean (N*,1), variance incl. noise (N*,1))     src/MFDataFusion.py:156, src/abstractMFGP.py:104
+  * kernel.to_dict()["parts"]...["lengthscale"]                        src/models/GPDFC.py:26-29
+
+Semantics restated from GPy 1.9.9 / paramz 0.9.5 (not vendored; statements tagged [GPy-recall]):
+positive parameters live in a softplus ("Logexp") optimizer space; the objective is the negative log
+marginal likelihood; L-BFGS-B (scipy fmin_l_bfgs_b, max_iters -> maxfun and maxiter) drives it;
+optimize_restarts keeps restart 0 at the current point, randomizes the others with N(0,1) draws in
+optimizer space and installs the best; a failed Cholesky is retried with jitter mean(diag)*1e-6*10^k.
+
+All arithmetic (K build, Cholesky, solves, log-det, gradient, prediction) runs in libmfgp_hip.so on
+the GPU through _lib.Engine.  There is no CPU fallback.  The evaluation is LAZY: changing a parameter
+only marks the model dirty; the factorisation happens at the next query (GPy re-runs inference eagerly
+on every assignment -- same results, fewer O(N^3) passes).
+"""
+import re
+
+import numpy as np
+from scipy import optimize as _sciopt
+
+from . import _lib
+from ._lib import KERN_MATERN32, KERN_MATERN52, KERN_RBF, NotPositiveDefinite
+
+_LIM_VAL = 36.0
+_EPS = np.finfo(np.float64).resolution
+CONST_JITTER = 1e-8  # GPy adds this to the diagonal in exact inference [GPy-recall]
+
+
+# ------------------------------------------------------------------------------------------------
+# parameters
+# ------------------------------------------------------------------------------------------------
+def _logexp_f(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x > _LIM_VAL, x, np.log1p(np.exp(np.clip(x, -_LIM_VAL, _LIM_VAL)))) + _EPS
+
+
+def _logexp_finv(f):
+    f = np.asarray(f, dtype=np.float64)
+    return np.where(f > _LIM_VAL, f, np.log(np.expm1(f)))
+
+
+def _logexp_gradfactor(f, df):
+    f = np.asarray(f, dtype=np.float64)
+    return df * np.where(f > _LIM_VAL, 1.0, -np.expm1(-f))
+
+
+class Param:
+    """One positive scalar hyper-parameter (variance, lengthscale, noise variance)."""
+
+    def __init__(self, name, value, owner=None):
+        self.name = name
+        self._value = float(value)
+        self.fixed = False
+        self.gradient = 0.0
+        self._observers = []
+        if owner is not None:
+            self._observers.append(owner)
+
+    @property
+    def value(self):
+        return self._value
+
+    @value.setter
+    def value(self, v):
+        v = float(np.asarray(v).reshape(-1)[0])
+        self._value = v
+        for o in self._observers:
+            o._param_changed(self)
+
+    # GPy-style handles
+    def fix(self):
+        self.fixed = True
+        return self
+
+    def unfix(self):
+        self.fixed = False
+        return self
+
+    def constrain_positive(self):  # every parameter here already lives in the positive (Logexp) domain
+        return self
+
+    def __float__(self):
+        return self._value
+
+    def __getitem__(self, i):  # GPy params are arrays: kern.lengthscale[0]
+        return np.atleast_1d(self._value)[i]
+
+    def __repr__(self):
+        return "Param(%s=%.6g%s)" % (self.name, self._value, ", fixed" if self.fixed else "")
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel specification objects
+# ------------------------------------------------------------------------------------------------
+class Kern:
+    """Base of the kernel *spec* objects: they hold parameters and column sets; the GPU evaluates them."""
+
+    def __mul__(self, other):
+        return Prod([self, other])
+
+    def __add__(self, other):
+        return Add([self, other])
+
+    def _terms(self):
+        """-> list of terms, each a list of Stationary factors (sum of products expansion)."""
+        raise NotImplementedError
+
+    def parameters(self):
+        """distinct Param objects in a stable order"""
+        out = []
+        for term in self._terms():
+            for f in term:
+                for p in (f.variance, f.lengthscale):
+                    if not any(p is q for q in out):
+                        out.append(p)
+        return out
+
+    def engine_parts(self):
+        """flatten to the C-ABI description: parts [(type, c0, c1, term)], and per part (variance, lengthscale) Params"""
+        parts, plist = [], []
+        for t, term in enumerate(self._terms()):
+            for f in term:
+                parts.append((f.ktype, f.col_begin, f.col_end, t))
+                plist.append((f.variance, f.lengthscale))
+        if len(parts) > _lib.MAX_PARTS:
+            raise NotImplementedError("kernel expands to %d factors; the engine supports %d" % (len(parts), _lib.MAX_PARTS))
+        return parts, plist
+
+    def _set_owner(self, owner):
+        # a kernel object is linked to one live model at a time (the reference re-uses self.kernel for
+        # every refit, src/MFDataFusion.py:69,96: hyper-parameters warm-start; the previous model lets go)
+        for p in self.parameters():
+            p._observers = [owner]
+
+    def Kdiag_value(self):
+        return sum(np.prod([f.variance.value for f in term]) for term in self._terms())
+
+
+class Stationary(Kern):
+    ktype = None
+    _default_name = "stationary"
+
+    def __init__(self, input_dim, variance=1.0, lengthscale=1.0, ARD=False, active_dims=None, name=None):
+        if ARD:
+            raise NotImplementedError("ARD lengthscales are not used by the reference (src/abstractMFGP.py:60 passes none)")
+        self.input_dim = int(input_dim)
+        if active_dims is None:
+            active_dims = np.arange(self.input_dim)
+        active_dims = np.asarray(active_dims, dtype=int).reshape(-1)
+        if len(active_dims) != self.input_dim:
+            raise ValueError("len(active_dims) must equal input_dim")
+        if len(active_dims) > 1 and np.any(np.diff(active_dims) != 1):
+            raise NotImplementedError("active_dims must be a contiguous, ascending column range")
+        self.active_dims = active_dims
+        self.col_begin = int(active_dims[0])
+        self.col_end = int(active_dims[-1]) + 1
+        self.name = name or self._default_name
+        self.variance = Param("variance", variance)
+        self.lengthscale = Param("lengthscale", lengthscale)
+
+    def _terms(self):
+        return [[self]]
+
+    def to_dict(self):
+        return {"class": "GPy.kern." + type(self).__name__, "name": self.name, "input_dim": self.input_dim,
+                "active_dims": self.active_dims.tolist(), "variance": [self.variance.value],
+                "lengthscale": [self.lengthscale.value], "ARD": False}
+
+
+class RBF(Stationary):
+    ktype = KERN_RBF
+    _default_name = "rbf"
+
+
+class Matern32(Stationary):
+    ktype = KERN_MATERN32
+    _default_name = "Mat32"
+
+
+class Matern52(Stationary):
+    ktype = KERN_MATERN52
+    _default_name = "Mat52"
+
+
+class _Combination(Kern):
+    def __init__(self, parts, name):
+        self.parts = list(parts)
+        self.name = name
+
+    def to_dict(self):
+        return {"class": "GPy.kern." + type(self).__name__, "name": self.name,
+                "parts": {i: p.to_dict() for i, p in enumerate(self.parts)}}
+
+
+class Prod(_Combination):
+    def __init__(self, parts, name="mul"):
+        flat = []
+        for p in parts:
+            flat.extend(p.parts if isinstance(p, Prod) else [p])
+        super().__init__(flat, name)
+
+    def _terms(self):
+        terms = [[]]
+        for p in self.parts:  # distribute products over sums
+            terms = [a + b for a in terms for b in p._terms()]
+        return terms
+
+
+class Add(_Combination):
+    def __init__(self, parts, name="sum"):
+        flat = []
+        for p in parts:
+            flat.extend(p.parts if isinstance(p, Add) else [p])
+        super().__init__(flat, name)
+
+    def _terms(self):
+        out = []
+        for p in self.parts:
+            out.extend(p._terms())
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# likelihood
+# ------------------------------------------------------------------------------------------------
+class Gaussian:
+    """Gaussian likelihood: one noise variance (GPy.likelihoods.Gaussian, name 'Gaussian_noise')."""
+
+    def __init__(self, variance=1.0, owner=None):
+        self._variance = Param("Gaussian_noise.variance", variance, owner)
+
+    @property
+    def variance(self):
+        return self._variance
+
+    @variance.setter
+    def variance(self, v):  # model.likelihood.variance = 1e-6 (src/MFDataFusion.py:155)
+        self._variance.value = v
+
+
+class _ParamSelection:
+    """result of model['regex']: forwards fix/unfix/constrain_positive to the matched parameters"""
+
+    def __init__(self, params):
+        self.params = params
+
+    def fix(self):
+        for p in self.params:
+            p.fix()
+        return self
+
+    def unfix(self):
+        for p in self.params:
+            p.unfix()
+        return self
+
+    def constrain_positive(self):
+        return self
+
+    @property
+    def values(self):
+        return np.array([p.value for p in self.params])
+
+    def __len__(self):
+        return len(self.params)
+
+
+# ------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------
+class _OptRun:
+    def __init__(self, x_opt, f_opt, n_evals, status):
+        self.x_opt, self.f_opt, self.n_evals, self.status = x_opt, f_opt, n_evals, status
+
+
+class GPRegression:
+    """Exact GP regression with a Gaussian likelihood on the HIP engine (GPy.models.GPRegression stand-in)."""
+
+    _allowed_failures = 10  # paramz tolerates this many failed objective evaluations per model [GPy-recall]
+
+    def __init__(self, X, Y, kernel=None, noise_var=1.0, initialize=True, engine=None, name="GP regression"):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("X must be (N, D)")
+        if Y.ndim == 1:
+            Y = Y[:, None]
+        if Y.shape != (X.shape[0], 1):
+            raise ValueError("Y must be (N, 1)")
+        self.name = name
+        self.X, self.Y = X, Y
+        self.kern = kernel if kernel is not None else RBF(X.shape[1])
+        self.likelihood = Gaussian(noise_var, owner=self)
+        self.Gaussian_noise = self.likelihood
+        self.kern._set_owner(self)
+        self._engine = engine if engine is not None else _lib.Engine()
+        self._owns_engine = engine is None
+        self._parts, self._part_params = self.kern.engine_parts()
+        self._engine.set_data(self.X, self.Y[:, 0])
+        self._engine.set_kernel(self._parts)
+        self._dirty = True
+        self._have_grad = False
+        self._nlml = None
+        self._grad_nat = None
+        self._jitter_used = CONST_JITTER
+        self._fail_count = 0
+        self.optimization_runs = []
+        self.n_evals = 0           # objective(+gradient) evaluations issued to the GPU
+        self.update_model = True
+
+    # ---- parameter plumbing ----------------------------------------------------------------------
+    def _param_changed(self, p):
+        self._dirty = True
+
+    def parameters(self):
+        return self.kern.parameters() + [self.likelihood.variance]
+
+    def _named_parameters(self):
+        out = []
+        for i, (v, l) in enumerate(self._part_params):
+            for p, n in ((v, "variance"), (l, "lengthscale")):
+                if not any(p is q for _, q in out):
+                    out.append(("%s.kern_%d.%s" % (self.name, i, n), p))
+        out.append(("%s.Gaussian_noise.variance" % self.name, self.likelihood.variance))
+        return out
+
+    def _match(self, pattern):
+        rx = re.compile(pattern)
+        hits = [p for n, p in self._named_parameters() if rx.search(n)]
+        if not hits:
+            raise KeyError("no parameter matches %r" % pattern)
+        return hits
+
+    def __getitem__(self, pattern):
+        return _ParamSelection(self._match(pattern))
+
+    def __setitem__(self, pattern, value):
+        for p in self._match(pattern):
+            p.value = value
+
+    # named equivalents (SURVEY 8(b) recommends these for fresh callers)
+    def set_noise(self, v):
+        self.likelihood.variance = v
+
+    def fix_noise(self):
+        self.likelihood.variance.fix()
+
+    def unfix_noise(self):
+        self.likelihood.variance.unfix()
+
+    def _free_params(self):
+        return [p for p in self.parameters() if not p.fixed]
+
+    @property
+    def optimizer_array(self):
+        return _logexp_finv(np.array([p.value for p in self._free_params()]))
+
+    @optimizer_array.setter
+    def optimizer_array(self, x):
+        vals = _logexp_f(np.asarray(x, dtype=np.float64))
+        for p, v in zip(self._free_params(), vals):
+            p._value = float(v)
+        self._dirty = True
+
+    def randomize(self, rand_gen=None):
+        """N(0,1) draws in optimizer space for every free parameter [GPy-recall: paramz randomize]."""
+        n = len(self._free_params())
+        x = rand_gen(size=n) if rand_gen is not None else np.random.normal(size=n)
+        self.optimizer_array = x
+
+    # ---- evaluation --------------------------------------------------------------------------------
+    def _theta(self):
+        th = []
+        for v, l in self._part_params:
+            th += [v.value, l.value]
+        return np.array(th)
+
+    def _ensure(self, want_grad):
+        """(re)factorise if parameters changed; GPy's jitchol retry policy on failure."""
+        if not self._dirty and (self._have_grad or not want_grad):
+            return
+        theta, noise = self._theta(), self.likelihood.variance.value
+        if not self._dirty and want_grad:
+            self._grad_nat = self._engine.nlml_grad()
+            self._have_grad = True
+            return
+        jitter_extra, tries = 0.0, 0
+        while True:
+            try:
+                res = self._engine.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=want_grad)
+                self.n_evals += 1
+                break
+            except NotPositiveDefinite:
+                self.n_evals += 1
+                tries += 1
+                diag_mean = self.kern.Kdiag_value() + noise + CONST_JITTER
+                if tries > 5 or not np.isfinite(diag_mean):
+                    raise np.linalg.LinAlgError("not positive definite, even with jitter.")
+                jitter_extra = diag_mean * 1e-6 * 10 ** (tries - 1)
+        if want_grad:
+            self._nlml, self._grad_nat = res
+        else:
+            self._nlml, self._grad_nat = res, None
+        self._have_grad = want_grad
+        self._jitter_used = CONST_JITTER + jitter_extra
+        self._dirty = False
+
+    def objective_function(self):
+        self._ensure(False)
+        return self._nlml
+
+    def log_likelihood(self):
+        return -self.objective_function()
+
+    def _natural_gradients(self):
+        """dNLML/d(param) for every distinct Param (shared params accumulate)"""
+        self._ensure(True)
+        g = self._grad_nat
+        acc = {}
+        for i, (v, l) in enumerate(self._part_params):
+            acc[id(v)] = acc.get(id(v), 0.0) + g[2 * i]
+            acc[id(l)] = acc.get(id(l), 0.0) + g[2 * i + 1]
+        acc[id(self.likelihood.variance)] = g[-1]
+        for p in self.parameters():
+            p.gradient = -acc[id(p)]  # GPy stores d log-likelihood / d param
+        return acc
+
+    def objective_function_gradients(self):
+        acc = self._natural_gradients()
+        free = self._free_params()
+        g = np.array([acc[id(p)] for p in free])
+        return _logexp_gradfactor(np.array([p.value for p in free]), g)
+
+    def _objective_grads(self, x):
+        try:
+            self.optimizer_array = x
+            f = self.objective_function()
+            g = self.objective_function_gradients()
+            self._fail_count = 0
+        except (np.linalg.LinAlgError, ZeroDivisionError, ValueError):
+            if self._fail_count >= self._allowed_failures:
+                raise
+            self._fail_count += 1
+            return np.inf, np.clip(np.zeros_like(x), -1e100, 1e100)
+        return f, np.clip(g, -1e100, 1e100)
+
+    # ---- optimisation --------------------------------------------------------------------------------
+    def optimize(self, optimizer=None, max_iters=1000, messages=False, **kwargs):
+        """L-BFGS-B on the softplus-transformed free parameters (paramz opt_lbfgsb [GPy-recall]:
+        fmin_l_bfgs_b(f_fp, x0, maxfun=max_iters, maxiter=max_iters), scipy defaults m=10, factr=1e7, pgtol=1e-5)."""
+        if optimizer is not None and "bfgs" not in str(optimizer).lower() and str(optimizer).lower() != "scg":
+            raise NotImplementedError("only the (L-)BFGS(-B) optimiser of the reference recipe is provided")
+        x0 = self.optimizer_array.copy()
+        if x0.size == 0:
+            return None
+        n0 = self.n_evals
+        x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(self._objective_grads, x0, maxfun=int(max_iters), maxiter=int(max_iters),
+                                                iprint=1 if messages else -1)
+        self.optimizer_array = x_opt
+        run = _OptRun(np.array(x_opt), float(f_opt), self.n_evals - n0, d.get("task", d.get("warnflag")))
+        self.optimization_runs.append(run)
+        return run
+
+    def optimize_restarts(self, num_restarts=10, robust=False, verbose=True, parallel=False, num_processes=None,
+                          rand_gen=None, comm=None, **kwargs):
+        """Restart 0 continues from the current point; restarts 1.. randomize first; the best f_opt wins
+        (paramz Model.optimize_restarts [GPy-recall]; call site src/abstractMFGP.py:137).
+
+        comm: optional sharding.Comm -- the restarts are independent L-BFGS-B runs on the same (X, Y),
+        so rank r runs restarts r, r+size, ... and the (f_opt, x_opt) pairs are all-gathered.
+        With a seeded per-restart `rand_gen(i)` the winner does not depend on the number of ranks."""
+        initial_parameters = self.optimizer_array.copy()
+        rank, size = (comm.rank, comm.size) if comm is not None else (0, 1)
+        mine = []
+        for i in range(num_restarts):
+            if i % size != rank:
+                continue
+            try:
+                self.optimizer_array = initial_parameters
+                if i > 0:
+                    if callable(rand_gen):
+                        self.randomize(rand_gen(i))
+                    else:
+                        self.randomize(None)
+                run = self.optimize(**kwargs)
+                if run is not None:
+                    mine.append((run.f_opt, run.x_opt, i))
+                if verbose:
+                    print("Optimization restart %d/%d, f = %s" % (i + 1, num_restarts, run.f_opt if run else None))
+            except Exception as e:  # noqa: BLE001 - mirrors paramz' robust mode
+                if robust:
+                    print("Warning - optimization restart %d/%d failed: %s" % (i + 1, num_restarts, e))
+                else:
+                    raise
+        runs = mine
+        if comm is not None and size > 1:
+            runs = [r for part in comm.allgather_object(mine) for r in part]
+        if runs:
+            best = min(runs, key=lambda r: (r[0], r[2]))
+            self.optimizer_array = best[1]
+        else:
+            self.optimizer_array = initial_parameters
+
+    # ---- prediction ------------------------------------------------------------------------------------
+    def predict(self, Xnew, full_cov=False, Y_metadata=None, kern=None, likelihood=None, include_likelihood=True):
+        """-> (mean (N*,1), variance (N*,1)); the variance includes the noise variance and its latent
+        part is floored at 1e-15 (GPy Posterior._raw_predict + Gaussian.predictive_values [GPy-recall])."""
+        if full_cov:
+            raise NotImplementedError("full_cov is not used by the reference")
+        Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
+        self._ensure(False)
+        mean, var = self._engine.predict(Xnew, want_var=True, include_noise=include_likelihood)
+        return mean[:, None], var[:, None]
+
+    def predict_mean(self, Xnew):
+        """mean only (what `lambda t: lf_model.predict(t)[0]` needs, src/abstractMFGP.py:104): skips the O(N^2 N*) variance"""
+        Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
+        self._ensure(False)
+        mean, _ = self._engine.predict(Xnew, want_var=False)
+        return mean[:, None]
+
+    def timings(self):
+        return self._engine.timings()
+
+    def close(self):
+        if self._owns_engine:
+            self._engine.close()
+
+    def __str__(self):
+        rows = ["%-40s %.6g%s" % (n, p.value, "  (fixed)" if p.fixed else "") for n, p in self._named_parameters()]
+        return "Name : %s\nObjective : %s\n" % (self.name, self._nlml) + "\n".join(rows)

@@ -1,0 +1,138 @@
+"""GPU tests of the host layer that mirrors the reference surface (engine.GPRegression, NARGP/GPDF/GPDFC,
+adaptation) -- these read like the reference's own scripts (tests/utils.py:38-47, tests/MFDF_tests.py:10-26)."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as orc
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def hf2(x):
+    return cases.hf_2d(x)[:, None]
+
+
+def lf2(x):
+    return cases.lf_2d(x)[:, None]
+
+
+def test_gpregression_objective_gradient_and_transform_match_oracle():
+    from multifidelity_datafusion_gps_amd import engine as gp
+    c = cases.make_case("nargp_4d_n64")
+    k = gp.RBF(1, active_dims=[4]) * gp.RBF(4, active_dims=[0, 1, 2, 3]) + gp.RBF(4, active_dims=[0, 1, 2, 3])
+    m = gp.GPRegression(c["X"], c["Y"][:, None], kernel=k)
+    # defaults: all variances / lengthscales 1, noise 1 (GPy defaults)
+    x = m.optimizer_array.copy()
+    f, g = m._objective_grads(x)
+    fo, go = orc.objective_transformed(c["parts"], x, c["X"], c["Y"])
+    assert f == pytest.approx(fo, rel=1e-10)
+    np.testing.assert_allclose(g, go, rtol=0, atol=1e-8 * np.abs(go).max())
+    # fixing the noise removes it from the optimizer vector; regex access like the reference's ARD
+    m[".*Gaussian_noise"] = 0.05
+    m[".*Gaussian_noise"].fix()
+    assert len(m.optimizer_array) == 6
+    f2, g2 = m._objective_grads(m.optimizer_array)
+    fo2, go2 = orc.objective_transformed(c["parts"], m.optimizer_array, c["X"], c["Y"], fixed_noise=0.05)
+    assert f2 == pytest.approx(fo2, rel=1e-10)
+    np.testing.assert_allclose(g2, go2, rtol=0, atol=1e-8 * np.abs(go2).max())
+    m.close()
+
+
+def test_optimize_lowers_objective_and_matches_cpu_driver():
+    """same L-BFGS-B driver on the GPU objective and on the oracle objective from the same start:
+    trajectories agree to optimiser tolerance on this well-conditioned case."""
+    from scipy.optimize import fmin_l_bfgs_b
+    from multifidelity_datafusion_gps_amd import engine as gp
+    c = cases.make_case("rbf_3d_n50")
+    m = gp.GPRegression(c["X"], c["Y"][:, None])
+    f0 = m.objective_function()
+    run = m.optimize(max_iters=200)
+    assert run.f_opt < f0
+    x0 = orc.logexp_finv(np.array([1.0, 1.0, 1.0]))
+    xo, fo, _ = fmin_l_bfgs_b(lambda x: orc.objective_transformed(c["parts"], x, c["X"], c["Y"]), x0, maxfun=200, maxiter=200)
+    assert run.f_opt == pytest.approx(fo, rel=1e-6)
+    mean, var = m.predict(c["Xs"])
+    assert mean.shape == (16, 1) and var.shape == (16, 1) and np.all(var > 0)
+    m.close()
+
+
+@pytest.mark.parametrize("method", ["NARGP", "GPDF", "GPDFC"])
+def test_models_fit_predict_like_reference_scripts(method):
+    """create_mfgp_obj of the reference's tests/utils.py:38-47: GPDF(dim, 0.001, 2, hf, lf), NARGP(dim, hf, lf), GPDFC(...)"""
+    import multifidelity_datafusion_gps_amd as mf
+    dim = 2
+    rng = np.random.default_rng(10)
+    X_hf = rng.uniform(size=(25, dim))
+    if method == "GPDF":
+        model = mf.GPDF(dim, 0.001, 2, hf2, lf2, add_noise=True, seed=1)
+    elif method == "NARGP":
+        model = mf.NARGP(dim, hf2, lf2, add_noise=True, seed=1)
+    else:
+        model = mf.GPDFC(dim, 0.001, 2, hf2, lf2, add_noise=True, seed=1)
+    model.first_run_max_iters, model.restart_max_iters = 60, 60
+    model.fit(X_hf)
+    assert model.hf_model.X.shape == (25, dim + model.augm_iterator.new_entries_count())
+    X_test = rng.uniform(size=(100, dim))
+    mean, var = model.predict(X_test)
+    assert mean.shape == (100, 1) and var.shape == (100, 1)
+    assert model.hf_model.likelihood.variance.value == 1e-6  # add_noise overwrote the learned noise (src/MFDataFusion.py:154-155)
+    assert np.all(var >= 1e-6)
+    mse = model.get_mse(X_test, hf2(X_test))
+    assert mse < 0.05, mse
+    # predictions agree with the oracle evaluated at the fitted hyper-parameters (looser: noise = 1e-6 regime)
+    parts, plist = model.kernel.engine_parts()
+    theta = np.array([p.value for pair in plist for p in pair])
+    Xa = model.hf_model.X
+    st = orc.inference(parts, theta, 1e-6, Xa, model.hf_Y)
+    mu, v = orc.predict_stable(parts, theta, 1e-6, Xa, st, model._augment_data(X_test))
+    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-6)
+    if method == "GPDFC":
+        assert len(model.lengthscale_hyperparams()) == 3
+    model.close()
+
+
+def test_data_driven_low_fidelity_level_and_batched_augmentation():
+    """lf_X / lf_Y given instead of f_low: the LF GP's posterior mean becomes f_low (src/abstractMFGP.py:97-104)."""
+    import multifidelity_datafusion_gps_amd as mf
+    rng = np.random.default_rng(4)
+    X_lf = rng.uniform(size=(80, 2))
+    model = mf.NARGP(2, hf2, None, lf_X=X_lf, lf_Y=lf2(X_lf), seed=2)
+    model.first_run_max_iters, model.restart_max_iters = 40, 40
+    X_hf = rng.uniform(size=(20, 2))
+    model.fit(X_hf)
+    aug = model._augment_data(X_hf)
+    np.testing.assert_allclose(aug[:, 2:], model.lf_model.predict(X_hf)[0], atol=1e-12)
+    model.batched_augmentation = False  # the reference's one-call-per-row form gives the same matrix
+    np.testing.assert_allclose(model._augment_data(X_hf), aug, atol=1e-12)
+    Xt = rng.uniform(size=(50, 2))
+    assert model.get_mse(Xt, hf2(Xt)) < 0.1
+    model.close()
+
+
+def test_adaptation_improves_mse():
+    """the one behavioural property the reference states (tests/MFDF_tests.py:10-26): adapt(5) lowers the test MSE,
+    on sin^2(10 x0) + cos(10 x1) with lf = 1.5 hf + 3 (src/data/exampleCurves2D.py:8-16)."""
+    import multifidelity_datafusion_gps_amd as mf
+
+    def f_high(X):
+        return (np.sin(10 * X[:, 0]) ** 2 + np.cos(10 * X[:, 1]))[:, None]
+
+    def f_low(X):
+        return 1.5 * f_high(X) + 3
+
+    rng = np.random.default_rng(42)
+    X_train_hf = rng.uniform(size=(5, 2))
+    X_test = rng.uniform(size=(200, 2))
+    model = mf.MultifidelityDataFusion(name='model', input_dim=2, tau=.001, num_derivatives=2, f_exact=f_high,
+                                       f_low=f_low, use_composite_kernel=True, seed=0,
+                                       adapt_maximizer=mf.DIRECT1Maximizer())
+    model.first_run_max_iters, model.restart_max_iters = 50, 50
+    model.fit(X_train_hf)
+    mse_before = model.get_mse(X_test, f_high(X_test))
+    model.adapt(5)
+    mse_after = model.get_mse(X_test, f_high(X_test))
+    assert len(model.hf_X) == 10
+    assert mse_after < mse_before
+    model.close()
