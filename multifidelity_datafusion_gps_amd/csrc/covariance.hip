@@ -320,21 +320,19 @@ __global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp, cons
                                                             double* __restrict__ out) {
     __shared__ double red[256];
     const int tid = threadIdx.x;
-    for (int i = 0; i < NSUM; ++i) {
-        double s = 0.0;
-        for (int b = tid; b < nblocks; b += 256) s += partials[(int64_t)b * NSUM + i];
-        red[tid] = s;
+    const int i = blockIdx.x;  // one block per sum, fixed summation order -> bitwise reproducible
+    double s = 0.0;
+    for (int b = tid; b < nblocks; b += 256) s += partials[(int64_t)b * NSUM + i];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) red[tid] += red[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const double S = red[0];
-            if (i == NSUM - 1) out[2 * sp.nf] = -0.5 * S;
-            else if (i / 2 < sp.nf) out[i] = -0.5 * S / params[i];  // params[2f]=var_f, params[2f+1]=l_f
-        }
-        __syncthreads();
+    }
+    if (tid == 0) {
+        const double S = red[0];
+        if (i == NSUM - 1) out[2 * sp.nf] = -0.5 * S;
+        else if (i / 2 < sp.nf) out[i] = -0.5 * S / params[i];  // params[2f]=var_f, params[2f+1]=l_f
     }
 }
 
@@ -350,7 +348,7 @@ void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X, const 
     const size_t lds = kb_lds(spec.D) + (size_t)4 * NSUM * sizeof(double);
     hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, params, Kinv, ld, alpha, N,
                        partials);
-    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(1), dim3(256), 0, s, spec, params, partials, nb, out);
+    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(NSUM), dim3(256), 0, s, spec, params, partials, nb, out);
 }
 
 // var[i] = max(kss - ss[i], 1e-15) + add,  kss = sum_terms prod var_f  (GPy Kdiag of a stationary kernel)

@@ -1,6 +1,6 @@
 // gemm_f64.hip -- the fp64 MFMA tile-GEMM kernel every level-3 step of the GP evaluation runs on.
 //
-// One workgroup (4 waves, 2x2) computes one BM x BN output tile described by a GemmTask:
+// One workgroup (8 waves, 4x2) computes one BM x BN output tile described by a GemmTask:
 //     C = beta*C + alpha * A[i0.., k0..k0+klen) * B[j0.., k0'..)^T          ("NT": both K-contiguous)
 // on v_mfma_f64_16x16x4_f64.  Cholesky panel solves (as products with the running inverse), SYRK
 // trailing updates, the triangular inverse, K^-1 = L^-T L^-1 and the predictive-variance product
@@ -17,13 +17,14 @@
 
 namespace mfgp {
 
-template <int BM, int BN>
+template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks, const double* A, const double* B,
                                              double* C, double* C2, int ld) {
-    constexpr int TM = BM / 32;   // 16-row MFMA blocks per wave along M (wave grid is 2 x 2)
-    constexpr int TN = BN / 32;
-    constexpr int NA = BM / 16;   // 16-byte chunks per thread per K-step (BM*16 chunks / 256 threads)
-    constexpr int NBC = BN / 16;
+    constexpr int NT = 64 * WM * WN;      // threads per workgroup (wave grid WM x WN)
+    constexpr int TM = BM / (16 * WM);    // 16-row MFMA blocks per wave along M
+    constexpr int TN = BN / (16 * WN);
+    constexpr int NA = BM * 16 / NT;      // 16-byte chunks per thread per K-step
+    constexpr int NBC = BN * 16 / NT;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;                  // [2][BM*BK]
     double* Bs = smem + 2 * BM * BK;    // [2][BN*BK]
@@ -32,7 +33,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15;  // fragment row / output column within a 16-block
     const int q = lane >> 4;   // k sub-index of the fragment / output row group
 
@@ -53,7 +54,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
     auto load_tiles = [&](int kt) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int g = tid + 256 * u;
+            const int g = tid + NT * u;
             const int row = g >> 4, c = g & 15;
             const int k = kt * BK + 2 * c;
             d2_t v = *reinterpret_cast<const d2_t*>(Ap + (int64_t)row * ld + k);
@@ -69,7 +70,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
         }
 #pragma unroll
         for (int u = 0; u < NBC; ++u) {
-            const int g = tid + 256 * u;
+            const int g = tid + NT * u;
             const int row = g >> 4, c = g & 15;
             const int k = kt * BK + 2 * c;
             d2_t v = *reinterpret_cast<const d2_t*>(Bp + (int64_t)row * ld + k);
@@ -89,20 +90,20 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
         double* bs = Bs + buf * (BN * BK);
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int g = tid + 256 * u;
+            const int g = tid + NT * u;
             const int row = g >> 4, c = g & 15;
             *reinterpret_cast<d2_t*>(as + row * BK + ((c ^ (row & 15)) << 1)) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < NBC; ++u) {
-            const int g = tid + 256 * u;
+            const int g = tid + NT * u;
             const int row = g >> 4, c = g & 15;
             *reinterpret_cast<d2_t*>(bs + row * BK + ((c ^ (row & 15)) << 1)) = rb[u];
         }
     };
     auto compute = [&](int buf) {
-        const double* as = As + buf * (BM * BK) + (wm * (BM / 2) + fr) * BK + (q & 1);
-        const double* bs = Bs + buf * (BN * BK) + (wn * (BN / 2) + fr) * BK + (q & 1);
+        const double* as = As + buf * (BM * BK) + (wm * (BM / WM) + fr) * BK + (q & 1);
+        const double* bs = Bs + buf * (BN * BK) + (wn * (BN / WN) + fr) * BK + (q & 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             // lane (fr, q) supplies element [row fr][k = 4*kk + q]: 16-byte chunk 2*kk + (q>>1), half q&1
@@ -143,8 +144,8 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wm * (BM / 2) + mi * 16 + q + 4 * r;
-                const int col = wn * (BN / 2) + ni * 16 + fr;
+                const int row = wm * (BM / WM) + mi * 16 + q + 4 * r;
+                const int col = wn * (BN / WN) + ni * 16 + fr;
                 double v = alpha * acc[mi][ni][r];
                 double* p = Cp + (int64_t)row * ld + col;
                 if (use_beta) v += beta * (*p);
@@ -155,33 +156,36 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
     }
 }
 
+constexpr int GW_M = 4, GW_N = 2;                 // 8 waves per workgroup = 2 per SIMD: one wave alone cannot keep
+constexpr int GEMM_THREADS = 64 * GW_M * GW_N;    // the fp64 MFMA pipe busy (probe: 140 vs ~103 cycles per MFMA)
+
 // Named entry points over the same tile body, so that a kernel trace separates the roles:
 //   mfgp_gemm_nt_f64_t128 / _t64 : the many launches of the recursive Cholesky + inverse
 //   mfgp_kinv_syrk_f64           : the ONE launch per evaluation that forms K^-1 = L^-T L^-1 (N^3/3 flops)
 //   mfgp_predvar_f64             : the predictive-variance product V = K(X*,X) L^-T
-__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64_t128(const GemmTask* __restrict__ tasks, const double* A,
+__global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_t128(const GemmTask* __restrict__ tasks, const double* A,
                                                                 const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<128, 128>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks, A, B, C, C2, ld);
 }
-__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
+__global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
                                                                const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<64, 64>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks, A, B, C, C2, ld);
 }
-__global__ __launch_bounds__(256, 1) void mfgp_kinv_syrk_f64(const GemmTask* __restrict__ tasks, const double* A,
+__global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_kinv_syrk_f64(const GemmTask* __restrict__ tasks, const double* A,
                                                              const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<128, 128>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks, A, B, C, C2, ld);
 }
-__global__ __launch_bounds__(256, 1) void mfgp_kinv_syrk_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
+__global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_kinv_syrk_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
                                                                  const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<64, 64>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks, A, B, C, C2, ld);
 }
-__global__ __launch_bounds__(256, 1) void mfgp_predvar_f64(const GemmTask* __restrict__ tasks, const double* A,
+__global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_predvar_f64(const GemmTask* __restrict__ tasks, const double* A,
                                                            const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<128, 128>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks, A, B, C, C2, ld);
 }
-__global__ __launch_bounds__(256, 1) void mfgp_predvar_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
+__global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_predvar_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
                                                                const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<64, 64>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks, A, B, C, C2, ld);
 }
 
 size_t gemm_lds_bytes(int tile) { return (size_t)2 * (tile + tile) * BK * sizeof(double); }
@@ -204,7 +208,7 @@ void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, con
         attr_set = true;
     }
     const gemm_kernel_t k = table[role][tile == 128 ? 0 : 1];
-    hipLaunchKernelGGL(k, dim3(ntasks), dim3(256), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld);
+    hipLaunchKernelGGL(k, dim3(ntasks), dim3(GEMM_THREADS), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld);
 }
 
 }  // namespace mfgp

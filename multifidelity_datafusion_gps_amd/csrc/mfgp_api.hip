@@ -540,6 +540,11 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
         h->tm.grad_ms = ev_ms(h->ev[4], h->ev[5]);
         for (int i = 0; i < 2 * h->spec.nf + 1; ++i) h->grad[i] = h->hres[2 + i];
         h->kinv_valid = h->grad_valid = true;
+        h->cum.grad_evals += 1;
+        h->cum.kinv_ms += h->tm.kinv_ms;
+        h->cum.grad_ms += h->tm.grad_ms;
+        h->cum.total_ms += h->tm.kinv_ms + h->tm.grad_ms;
+        h->cum.kinv_flops += (double)h->Np * h->Np * h->Np / 3.0;
     }
     for (int i = 0; i < 2 * h->spec.nf + 1; ++i) grad[i] = h->grad[i];
     return 0;

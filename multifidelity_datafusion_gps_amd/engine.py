@@ -444,6 +444,7 @@ class GPRegression:
     def _objective_grads(self, x):
         try:
             self.optimizer_array = x
+            self._ensure(True)  # ONE fused GPU evaluation: objective and gradient together
             f = self.objective_function()
             g = self.objective_function_gradients()
             self._fail_count = 0
