@@ -13,6 +13,8 @@
 //   Kinv <- lower(X^T X)                                          [1 launch, MFMA bound, N^3/3 flops]
 //   grad <- -0.5 sum (alpha alpha^T - Kinv) o dK/dtheta           [fused tile reduction]
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "mfgp_internal.h"
@@ -187,6 +189,129 @@ static void plan_cholinv(mfgp_handle* h, int b0, int b1) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// plan B (default): right-looking blocked Cholesky (NB = 128) followed by a level-batched recursive
+// triangular inverse.  Per block column k: leaf(k) factorises AND inverts the diagonal block, the
+// panel below becomes L[i,k] = A[i,k] X_kk^T (tile GEMMs, K = 128), then the trailing SYRK update.
+// The inverse X = L^-1 is then assembled bottom-up: every node of one tree level is independent, so a
+// level is TWO launches (P^T = X11^T L21^T ; X21 = -X22 P) however many nodes it has.
+// ------------------------------------------------------------------------------------------------
+static void plan_potrf_rl(mfgp_handle* h) {
+    const int64_t ld = h->Np;
+    const int nb = h->nblk;
+    for (int k = 0; k < nb; ++k) {
+        Step s{};
+        s.kind = 0;
+        s.blk = k;
+        h->plan.push_back(s);
+        const int rem = nb - 1 - k;
+        if (rem == 0) break;
+        const int64_t kc = (int64_t)k * NB;
+        {   // panel: L[i,k] = A[i,k] * X_kk^T
+            const int T = pick_tile(rem);
+            const int sc = NB / T;
+            const int first = (int)h->tasks.size();
+            for (int i = (k + 1) * sc; i < nb * sc; ++i)
+                for (int j = k * sc; j < (k + 1) * sc; ++j) {
+                    GemmTask t{};
+                    t.a_off = (int64_t)i * T * ld + kc;
+                    t.b_off = (int64_t)j * T * ld + kc;
+                    t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                    t.c2_off = -1;
+                    t.klen = (int)((int64_t)(j + 1) * T - kc);
+                    t.flags = TF_B_LOWER;
+                    t.alpha = 1.0; t.beta = 0.0;
+                    h->tasks.push_back(t);
+                }
+            add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
+        }
+        {   // trailing update: A[i,j] -= L[i,k] L[j,k]^T, k < j <= i
+            const int T = pick_tile(rem * (rem + 1) / 2);
+            const int sc = NB / T;
+            const int first = (int)h->tasks.size();
+            for (int j = (k + 1) * sc; j < nb * sc; ++j)      // column k+1 first: the next leaf needs it
+                for (int i = j; i < nb * sc; ++i) {
+                    GemmTask t{};
+                    t.a_off = (int64_t)i * T * ld + kc;
+                    t.b_off = (int64_t)j * T * ld + kc;
+                    t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                    t.c2_off = -1;
+                    t.klen = NB;
+                    t.flags = 0;
+                    t.alpha = -1.0; t.beta = 1.0;
+                    h->tasks.push_back(t);
+                }
+            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+        }
+    }
+}
+
+struct TriNode { int b0, bm, b1, level; };
+static int collect_nodes(int b0, int b1, std::vector<TriNode>& out) {
+    if (b1 - b0 <= 1) return 0;
+    const int bm = b0 + (b1 - b0 + 1) / 2;
+    const int l = std::max(collect_nodes(b0, bm, out), collect_nodes(bm, b1, out)) + 1;
+    out.push_back(TriNode{b0, bm, b1, l});
+    return l;
+}
+
+static void plan_trtri_levels(mfgp_handle* h) {
+    const int64_t ld = h->Np;
+    std::vector<TriNode> nodes;
+    const int top = collect_nodes(0, h->nblk, nodes);
+    for (int lev = 1; lev <= top; ++lev) {
+        int ntiles = 0;
+        for (const TriNode& n : nodes)
+            if (n.level == lev) ntiles += (n.bm - n.b0) * (n.b1 - n.bm);
+        const int T = pick_tile(ntiles);
+        const int sc = NB / T;
+        {   // P^T[j][i] = sum_{k>=j} X11^T[j][k] L21[i][k]
+            const int first = (int)h->tasks.size();
+            for (const TriNode& n : nodes) {
+                if (n.level != lev) continue;
+                const int64_t km = (int64_t)n.bm * NB;
+                for (int j = n.b0 * sc; j < n.bm * sc; ++j)
+                    for (int i = n.bm * sc; i < n.b1 * sc; ++i) {
+                        GemmTask t{};
+                        t.a_off = (int64_t)j * T * ld + (int64_t)j * T;
+                        t.b_off = (int64_t)i * T * ld + (int64_t)j * T;
+                        t.c_off = (int64_t)j * T * ld + (int64_t)i * T;
+                        t.c2_off = -1;
+                        t.klen = (int)(km - (int64_t)j * T);
+                        t.flags = TF_A_UPPER;
+                        t.alpha = 1.0; t.beta = 0.0;
+                        h->tasks.push_back(t);
+                    }
+            }
+            std::stable_sort(h->tasks.begin() + first, h->tasks.end(),
+                             [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+            add_gemm(h, h->plan, T, first, BUF_S, BUF_L, BUF_W, -1);
+        }
+        {   // X21[i][j] = - sum_{k<=i} X22[i][k] P^T[j][k]
+            const int first = (int)h->tasks.size();
+            for (const TriNode& n : nodes) {
+                if (n.level != lev) continue;
+                const int64_t km = (int64_t)n.bm * NB;
+                for (int i = n.bm * sc; i < n.b1 * sc; ++i)
+                    for (int j = n.b0 * sc; j < n.bm * sc; ++j) {
+                        GemmTask t{};
+                        t.a_off = (int64_t)i * T * ld + km;
+                        t.b_off = (int64_t)j * T * ld + km;
+                        t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                        t.c2_off = (int64_t)j * T * ld + (int64_t)i * T;
+                        t.klen = (int)((int64_t)(i + 1) * T - km);
+                        t.flags = TF_A_LOWER;
+                        t.alpha = -1.0; t.beta = 0.0;
+                        h->tasks.push_back(t);
+                    }
+            }
+            std::stable_sort(h->tasks.begin() + first, h->tasks.end(),
+                             [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+            add_gemm(h, h->plan, T, first, BUF_S, BUF_W, BUF_S, BUF_S);
+        }
+    }
+}
+
 static void plan_kinv(mfgp_handle* h) {
     const int64_t ld = h->Np;
     const int nb = h->nblk;
@@ -328,7 +453,13 @@ int32_t mfgp_destroy(mfgp_handle* h) {
 static int build_plans(mfgp_handle* h) {
     h->tasks.clear();
     h->plan.clear();
-    plan_cholinv(h, 0, h->nblk);
+    const char* pm = getenv("MFGP_PLAN");
+    if (pm && strcmp(pm, "recursive") == 0) {
+        plan_cholinv(h, 0, h->nblk);
+    } else {
+        plan_potrf_rl(h);
+        plan_trtri_levels(h);
+    }
     plan_kinv(h);
     h->predv_rows = 0;
     return upload_tasks(h);
@@ -729,8 +860,22 @@ int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xou
     HIPCHK(h, hipMalloc(&dl, 8)); HIPCHK(h, hipMalloc(&di, 4));
     HIPCHK(h, hipMemcpy(dA, A, bytes, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(di, 0, 4));
-    launch_leaf(h->stream, dA, dL, dS, NB, 0, dl, di);
+    unsigned long long* dst = nullptr;
+    HIPCHK(h, hipMalloc(&dst, 16 * sizeof(unsigned long long)));
+    launch_leaf(h->stream, dA, dL, dS, NB, 0, dl, di, dst);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+        unsigned long long st[16];
+        HIPCHK(h, hipMemcpy(st, dst, sizeof st, hipMemcpyDeviceToHost));
+        hipFree(dst);
+        if (getenv("MFGP_LEAF_STAMPS")) {
+            static const char* names[] = {"load", "micro0", "trsm0", "prio0", "micro1||update0", "rest of phase1",
+                                          "writeL+logdet", "diag inverses", "phase2 columns", "write S"};
+            fprintf(stderr, "leaf stamps (shader cycles):");
+            for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%llu", names[i], st[i + 1] - st[i]);
+            fprintf(stderr, " total=%llu\n", st[10] - st[0]);
+        }
+    }
     HIPCHK(h, hipGetLastError());
     int info = 0;
     HIPCHK(h, hipMemcpy(Lout, dL, bytes, hipMemcpyDeviceToHost));

@@ -69,7 +69,7 @@ size_t gemm_lds_bytes(int tile);
 //   L block (zeros above diag) -> Lout[blk,blk];  X = L^-1 -> S[blk,blk] stored mirrored (X + X^T - diag)
 //   half log-det partial -> logdet_part[blk];  first failing pivot (1-based global index) -> info (atomicMin style)
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
-                 double* logdet_part, int* info);
+                 double* logdet_part, int* info, unsigned long long* stamps = nullptr);
 
 // covariance builders
 //   tri: lower-triangle 64x64 tiles of Ky = K + (noise+jitter) I over padded Np (identity padding)
