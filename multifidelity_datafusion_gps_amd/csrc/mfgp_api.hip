@@ -199,48 +199,66 @@ static void plan_cholinv(mfgp_handle* h, int b0, int b1) {
 static void plan_potrf_rl(mfgp_handle* h) {
     const int64_t ld = h->Np;
     const int nb = h->nblk;
-    for (int k = 0; k < nb; ++k) {
-        Step s{};
-        s.kind = 0;
-        s.blk = k;
-        h->plan.push_back(s);
-        const int rem = nb - 1 - k;
-        if (rem == 0) break;
-        const int64_t kc = (int64_t)k * NB;
-        {   // panel: L[i,k] = A[i,k] * X_kk^T
-            const int T = pick_tile(rem);
-            const int sc = NB / T;
-            const int first = (int)h->tasks.size();
-            for (int i = (k + 1) * sc; i < nb * sc; ++i)
-                for (int j = k * sc; j < (k + 1) * sc; ++j) {
-                    GemmTask t{};
-                    t.a_off = (int64_t)i * T * ld + kc;
-                    t.b_off = (int64_t)j * T * ld + kc;
-                    t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                    t.c2_off = -1;
-                    t.klen = (int)((int64_t)(j + 1) * T - kc);
-                    t.flags = TF_B_LOWER;
-                    t.alpha = 1.0; t.beta = 0.0;
-                    h->tasks.push_back(t);
-                }
-            add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
+    int MB = 4;  // macro panel = MB leaf blocks: the bulk trailing update runs with K = MB*128
+    if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
+    auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
+        // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
+        const int sc = NB / T;
+        for (int j = jlo * sc; j < jhi * sc; ++j)
+            for (int i = j; i < nb * sc; ++i) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T * ld + (int64_t)klo * NB;
+                t.b_off = (int64_t)j * T * ld + (int64_t)klo * NB;
+                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c2_off = -1;
+                t.klen = (khi - klo) * NB;
+                t.flags = 0;
+                t.alpha = -1.0; t.beta = 1.0;
+                h->tasks.push_back(t);
+            }
+    };
+    for (int M0 = 0; M0 < nb; M0 += MB) {
+        const int M1 = std::min(M0 + MB, nb);
+        for (int k = M0; k < M1; ++k) {
+            Step s{};
+            s.kind = 0;
+            s.blk = k;
+            h->plan.push_back(s);
+            const int rem = nb - 1 - k;
+            if (rem == 0) break;
+            const int64_t kc = (int64_t)k * NB;
+            {   // panel: L[i,k] = A[i,k] * X_kk^T
+                const int T = pick_tile(rem);
+                const int sc = NB / T;
+                const int first = (int)h->tasks.size();
+                for (int i = (k + 1) * sc; i < nb * sc; ++i)
+                    for (int j = k * sc; j < (k + 1) * sc; ++j) {
+                        GemmTask t{};
+                        t.a_off = (int64_t)i * T * ld + kc;
+                        t.b_off = (int64_t)j * T * ld + kc;
+                        t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                        t.c2_off = -1;
+                        t.klen = (int)((int64_t)(j + 1) * T - kc);
+                        t.flags = TF_B_LOWER;
+                        t.alpha = 1.0; t.beta = 0.0;
+                        h->tasks.push_back(t);
+                    }
+                add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
+            }
+            if (k + 1 < M1) {   // narrow update: the remaining block columns of this macro panel, K = 128
+                int ntl = 0;
+                for (int j = k + 1; j < M1; ++j) ntl += nb - j;
+                const int T = pick_tile(ntl);
+                const int first = (int)h->tasks.size();
+                syrk_tasks(T, k + 1, M1, k, k + 1);
+                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+            }
         }
-        {   // trailing update: A[i,j] -= L[i,k] L[j,k]^T, k < j <= i
-            const int T = pick_tile(rem * (rem + 1) / 2);
-            const int sc = NB / T;
+        if (M1 < nb) {   // bulk trailing update with the whole macro panel, K = (M1-M0)*128
+            const int r = nb - M1;
+            const int T = pick_tile(r * (r + 1) / 2);
             const int first = (int)h->tasks.size();
-            for (int j = (k + 1) * sc; j < nb * sc; ++j)      // column k+1 first: the next leaf needs it
-                for (int i = j; i < nb * sc; ++i) {
-                    GemmTask t{};
-                    t.a_off = (int64_t)i * T * ld + kc;
-                    t.b_off = (int64_t)j * T * ld + kc;
-                    t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                    t.c2_off = -1;
-                    t.klen = NB;
-                    t.flags = 0;
-                    t.alpha = -1.0; t.beta = 1.0;
-                    h->tasks.push_back(t);
-                }
+            syrk_tasks(T, M1, nb, M0, M1);
             add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
         }
     }

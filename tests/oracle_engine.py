@@ -1,0 +1,40 @@
+"""TEST DOUBLE (tests/ only): an object with the _lib.Engine interface whose arithmetic is the CPU oracle.
+It exists so that the host logic around the engine (L-BFGS-B driving, restart sharding, predictive-row
+sharding, the model surface) can be exercised on CPU with gloo; the product never sees it."""
+import numpy as np
+
+from oracle import gp_oracle as orc
+
+
+class OracleEngine:
+    def __init__(self, device=None):
+        self.n = self.d = self.n_parts = 0
+        self.n_evals = 0
+
+    def close(self):
+        pass
+
+    def set_data(self, X, Y):
+        self.X, self.Y = np.asarray(X, float), np.asarray(Y, float).reshape(-1)
+        self.n, self.d = self.X.shape
+
+    def set_kernel(self, parts):
+        self.parts = [tuple(int(v) for v in p) for p in parts]
+        self.n_parts = len(self.parts)
+
+    def eval(self, theta, noise, jitter=1e-8, want_grad=True):
+        self.n_evals += 1
+        self.theta, self.noise = np.asarray(theta, float), float(noise)
+        self.st = orc.inference(self.parts, self.theta, self.noise, self.X, self.Y, want_grad=True, const_jitter=jitter)
+        return (self.st["nlml"], self.st["grad"]) if want_grad else self.st["nlml"]
+
+    def nlml_grad(self):
+        return self.st["grad"]
+
+    def predict(self, Xs, want_var=True, include_noise=True):
+        mu, var = orc.predict_stable(self.parts, self.theta, self.noise, self.X, self.st, np.asarray(Xs, float),
+                                     include_noise=include_noise)
+        return mu, (var if want_var else None)
+
+    def timings(self):
+        return {}
