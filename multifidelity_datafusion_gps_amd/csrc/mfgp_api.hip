@@ -29,6 +29,8 @@ enum Buf { BUF_A = 0, BUF_L = 1, BUF_S = 2, BUF_W = 3 };
 struct Step {
     int kind;  // 0 = leaf, 1 = gemm
     int role;  // gemm kernel symbol: 0 recursion, 1 K^-1, 2 predictive variance
+    int strm;  // 0 = main stream (the serial chain), 1 = bulk-update stream (look-ahead)
+    int wait_ev, rec_ev;  // 1-based indices into the event pool (0 = none): wait before / record after the launch
     int blk;   // leaf block
     int tile, first, count, a, b, c, c2;  // gemm
 };
@@ -37,6 +39,8 @@ struct Step {
 struct mfgp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // bulk trailing updates of the look-ahead Cholesky
+    std::vector<hipEvent_t> evpool;     // cross-stream dependencies of the plan
     std::string err, info_str;
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
     int D = 0, nblk = 0;
@@ -196,11 +200,24 @@ static void plan_cholinv(mfgp_handle* h, int b0, int b1) {
 // The inverse X = L^-1 is then assembled bottom-up: every node of one tree level is independent, so a
 // level is TWO launches (P^T = X11^T L21^T ; X21 = -X22 P) however many nodes it has.
 // ------------------------------------------------------------------------------------------------
+static int new_event(mfgp_handle* h, int& counter) {
+    ++counter;
+    while ((int)h->evpool.size() < counter) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        h->evpool.push_back(e);
+    }
+    return counter;  // 1-based
+}
+
 static void plan_potrf_rl(mfgp_handle* h) {
     const int64_t ld = h->Np;
     const int nb = h->nblk;
     int MB = 4;  // macro panel = MB leaf blocks: the bulk trailing update runs with K = MB*128
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
+    bool lookahead = true;  // bulk updates on a second stream, overlapped with the next macro panel's chain
+    if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
+    int nev = 0;
     auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
         // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
         const int sc = NB / T;
@@ -217,8 +234,12 @@ static void plan_potrf_rl(mfgp_handle* h) {
                 h->tasks.push_back(t);
             }
     };
+    auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
+    int ev_next_prev = 0;  // event recorded after the update of THIS macro panel's columns by the previous one
     for (int M0 = 0; M0 < nb; M0 += MB) {
         const int M1 = std::min(M0 + MB, nb);
+        const int M2 = std::min(M1 + MB, nb);
+        const size_t chain_begin = h->plan.size();
         for (int k = M0; k < M1; ++k) {
             Step s{};
             s.kind = 0;
@@ -246,20 +267,43 @@ static void plan_potrf_rl(mfgp_handle* h) {
                 add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
             }
             if (k + 1 < M1) {   // narrow update: the remaining block columns of this macro panel, K = 128
-                int ntl = 0;
-                for (int j = k + 1; j < M1; ++j) ntl += nb - j;
-                const int T = pick_tile(ntl);
+                const int T = pick_tile(ntiles_cols(k + 1, M1));
                 const int first = (int)h->tasks.size();
                 syrk_tasks(T, k + 1, M1, k, k + 1);
                 add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
             }
         }
+        if (lookahead && ev_next_prev > 0 && chain_begin < h->plan.size()) h->plan[chain_begin].wait_ev = ev_next_prev;
+        ev_next_prev = 0;
         if (M1 < nb) {   // bulk trailing update with the whole macro panel, K = (M1-M0)*128
-            const int r = nb - M1;
-            const int T = pick_tile(r * (r + 1) / 2);
-            const int first = (int)h->tasks.size();
-            syrk_tasks(T, M1, nb, M0, M1);
-            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+            if (!lookahead) {
+                const int r = nb - M1;
+                const int T = pick_tile(r * (r + 1) / 2);
+                const int first = (int)h->tasks.size();
+                syrk_tasks(T, M1, nb, M0, M1);
+                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+            } else {
+                const int ev_chain = new_event(h, nev);
+                h->plan.back().rec_ev = ev_chain;                 // chain(M) complete (main stream)
+                {   // the next macro panel's columns first ...
+                    const int T = pick_tile(ntiles_cols(M1, M2));
+                    const int first = (int)h->tasks.size();
+                    syrk_tasks(T, M1, M2, M0, M1);
+                    add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+                    Step& st = h->plan.back();
+                    st.strm = 1;
+                    st.wait_ev = ev_chain;
+                    ev_next_prev = new_event(h, nev);
+                    st.rec_ev = ev_next_prev;
+                }
+                if (M2 < nb) {   // ... then the rest, overlapped with the next macro panel's chain
+                    const int T = pick_tile(ntiles_cols(M2, nb));
+                    const int first = (int)h->tasks.size();
+                    syrk_tasks(T, M2, nb, M0, M1);
+                    add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+                    h->plan.back().strm = 1;
+                }
+            }
         }
     }
 }
@@ -393,12 +437,15 @@ static int upload_tasks(mfgp_handle* h) {
 }
 
 static void run_step(mfgp_handle* h, const Step& s) {
+    hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
+    if (s.wait_ev > 0) (void)hipStreamWaitEvent(st, h->evpool[s.wait_ev - 1], 0);
     if (s.kind == 0) {
-        launch_leaf(h->stream, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
+        launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
     } else {
-        launch_gemm(h->stream, s.tile, h->dtasks + s.first, s.count, h->buf[s.a], h->buf[s.b], h->buf[s.c],
+        launch_gemm(st, s.tile, h->dtasks + s.first, s.count, h->buf[s.a], h->buf[s.b], h->buf[s.c],
                     s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np, s.role);
     }
+    if (s.rec_ev > 0) (void)hipEventRecord(h->evpool[s.rec_ev - 1], st);
     h->launches++;
 }
 
@@ -426,7 +473,29 @@ int32_t mfgp_create(int32_t device_id, mfgp_handle** out) {
     mfgp_handle* h = new mfgp_handle();
     h->device = device_id;
     HIPCHK(h, hipSetDevice(device_id));
-    HIPCHK(h, hipStreamCreate(&h->stream));
+    int prio_lo = 0, prio_hi = 0;  // lo = least urgent (numerically greatest), hi = most urgent
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    // the main stream carries the serial chain (leaf -> panel -> narrow update): most urgent, so that its
+    // workgroups take the first CU a bulk-update workgroup vacates
+    HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+    {
+        // bulk-update stream; optionally keep a few CUs out of its reach so the serial chain always finds one
+        int reserve = 0;
+        if (const char* e = getenv("MFGP_U_RESERVE")) reserve = atoi(e);
+        hipDeviceProp_t pr;
+        HIPCHK(h, hipGetDeviceProperties(&pr, device_id));
+        const int ncu = pr.multiProcessorCount;
+        if (reserve > 0 && reserve < ncu) {
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0xffffffffu);
+            for (int r = 0; r < reserve; ++r) {
+                const int cu = (int)(((int64_t)r * ncu) / reserve);
+                mask[cu / 32] &= ~(1u << (cu % 32));
+            }
+            HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
+        } else {
+            HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+        }
+    }
     for (auto& ev : h->ev) HIPCHK(h, hipEventCreate(&ev));
     HIPCHK(h, hipMalloc(&h->dparams, 32 * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->dres, 64 * sizeof(double)));
@@ -463,6 +532,8 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     hipFree(h->dparams); hipFree(h->dres); hipFree(h->dinfo);
     hipHostFree(h->hres); hipHostFree(h->hinfo);
     for (auto& ev : h->ev) hipEventDestroy(ev);
+    for (auto& ev : h->evpool) hipEventDestroy(ev);
+    if (h->stream2) hipStreamDestroy(h->stream2);
     hipStreamDestroy(h->stream);
     delete h;
     return 0;
