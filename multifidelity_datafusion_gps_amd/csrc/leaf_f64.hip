@@ -23,6 +23,8 @@ constexpr int LP = 130;       // LDS pitch (doubles)
 constexpr int LEAF_THREADS = 512;
 constexpr int SC_RINV = 0;    // scratch: 1/l_kk for the 128 pivots
 constexpr int SC_RED = 128;   // 8 partial sums
+constexpr int SC_LT = 144;    // 16x16 transposed copy of the current diagonal factor: LT[m*16 + k] = L_jj[k][m]
+constexpr int SC_SIZE = SC_LT + 256;
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -46,7 +48,9 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 }
 
 // 16x16 Cholesky in the registers of one wave.  blk -> element (0,0) of the diagonal block in LDS.
-__device__ __forceinline__ void micro_chol16(double* blk, double* rinv_out, int lane, int* info, int pivot0) {
+// Branch-free inside the pivot loop: a failed pivot (d <= 0 or NaN) is replaced by 1 and its index kept.
+__device__ __forceinline__ void micro_chol16(double* blk, double* rinv_out, double* lt_out, int lane, int* info,
+                                             int pivot0) {
     const int i = lane & 15;
     double a[16];
 #pragma unroll
@@ -55,23 +59,28 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* rinv_out, int 
         a[k] = v.x;
         a[k + 1] = v.y;
     }
+    double my_rinv = 0.0;
+    int fail = 0;  // 1-based index of the first non-positive pivot inside this block (wave-uniform)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         double d = readlane_f64(a[j], j);
-        if (!(d > 0.0)) {  // wave-uniform: not positive definite (or NaN) -> record the first failing pivot
-            if (lane == 0 && *info == 0) *info = pivot0 + j + 1;
-            d = 1.0;
-        }
+        const bool ok = d > 0.0;
+        fail = (!ok && fail == 0) ? j + 1 : fail;
+        d = ok ? d : 1.0;
         const double y = fast_rsqrt(d);
-        a[j] = (i == j) ? d * y : a[j] * y;  // column j: l_ij for rows i >= j (rows above hold unused values)
-        if (lane == 0) rinv_out[j] = y;
+        a[j] *= y;                      // l_ij for rows i > j; row j itself: a_jj * y = sqrt(d) when ok
+        a[j] = (i == j && !ok) ? 1.0 : a[j];
+        my_rinv = (i == j) ? y : my_rinv;
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) {
             const double lkj = readlane_f64(a[j], k);
             a[k] = __builtin_fma(-a[j], lkj, a[k]);  // meaningful for rows i >= k
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 broadcasts in flight (SGPR pressure)
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (lane < 16) {
+        rinv_out[i] = my_rinv;
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
             d2_t v;
@@ -79,7 +88,10 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* rinv_out, int 
             v.y = (k + 1 <= i) ? a[k + 1] : 0.0;
             *reinterpret_cast<d2_t*>(blk + i * LP + k) = v;
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lt_out[k * 16 + i] = (k <= i) ? a[k] : 0.0;  // column k of L_jj, contiguous
     }
+    if (fail != 0 && lane == 0 && *info == 0) *info = pivot0 + fail;
 }
 
 // C[ib][kb] -= L[ib][jb] L[kb][jb]^T on 16x16 blocks of the LDS matrix
@@ -115,16 +127,27 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     STAMP(0);
 
     // ---- load (16 B per lane, whole rows coalesced) ------------------------------------------------
-    for (int e = tid; e < NB * NB / 2; e += LEAF_THREADS) {
-        const int row = e >> 6, c2 = e & 63;
-        const d2_t v = *reinterpret_cast<const d2_t*>(A + g0 + (int64_t)row * ld + 2 * c2);
-        *reinterpret_cast<d2_t*>(sL + row * LP + 2 * c2) = v;
+    {
+        constexpr int NLD = NB * NB / 2 / LEAF_THREADS;  // 16 loads in flight per thread before the first LDS store
+        d2_t v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = tid + u * LEAF_THREADS;
+            const int row = e >> 6, c2 = e & 63;
+            v[u] = *reinterpret_cast<const d2_t*>(A + g0 + (int64_t)row * ld + 2 * c2);
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = tid + u * LEAF_THREADS;
+            const int row = e >> 6, c2 = e & 63;
+            *reinterpret_cast<d2_t*>(sL + row * LP + 2 * c2) = v[u];
+        }
     }
     __syncthreads();
 
     STAMP(1);
     // ---- phase 1: blocked Cholesky with look-ahead ---------------------------------------------------
-    if (wave == 0) micro_chol16(sL, sc + SC_RINV, lane, info, blk * NB);
+    if (wave == 0) micro_chol16(sL, sc + SC_RINV, sc + SC_LT, lane, info, blk * NB);
     __syncthreads();
     STAMP(2);
     for (int jb = 0; jb < 8; ++jb) {
@@ -134,8 +157,12 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
             const int nrows = NB - base - 16;
             if (tid < nrows) {
                 double* rowp = sL + (base + 16 + tid) * LP + base;
-                const double* Lj = sL + base * LP + base;
-                const double* rinv = sc + SC_RINV + base;
+                // an opaque per-lane zero keeps the (wave-uniform) L_jj reads in VGPRs: hipcc otherwise moves every
+                // broadcast value to an SGPR with v_readfirstlane and spills ~130 SGPRs in this loop nest
+                int vz;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+                const double* LT = sc + SC_LT + vz;
+                const double* rinv = sc + SC_RINV + base + vz;
                 double x[16];
 #pragma unroll
                 for (int k = 0; k < 16; k += 2) {
@@ -143,12 +170,12 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
                     x[k] = v.x;
                     x[k + 1] = v.y;
                 }
+                // right-looking: after x[m] is final, eliminate it from every later unknown (independent FMAs)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    double s = x[k];
+                for (int m = 0; m < 16; ++m) {
+                    x[m] *= rinv[m];
 #pragma unroll
-                    for (int m = 0; m < k; ++m) s = __builtin_fma(-x[m], Lj[k * LP + m], s);
-                    x[k] = s * rinv[k];
+                    for (int k = m + 1; k < 16; ++k) x[k] = __builtin_fma(-x[m], LT[m * 16 + k], x[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < 16; k += 2)
@@ -167,7 +194,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
         if (jb == 0) STAMP(4);
         // wave 0 factorises the next diagonal block while waves 1-7 finish the trailing update
         if (wave == 0) {
-            micro_chol16(sL + (base + 16) * LP + base + 16, sc + SC_RINV + base + 16, lane, info,
+            micro_chol16(sL + (base + 16) * LP + base + 16, sc + SC_RINV + base + 16, sc + SC_LT, lane, info,
                          blk * NB + base + 16);
         } else {
             const int m = 6 - jb;  // block columns jb+2 .. 7
@@ -226,46 +253,51 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     }
     __syncthreads();
     STAMP(8);
-    // (b) block columns right to left
-    for (int jb = 6; jb >= 0; --jb) {
-        const int base = jb * 16;
-        // T[kb] = L[kb][jb] * X[jb][jb]   (in place, one block per wave)
-        {
-            const int kb = jb + 1 + wave;
-            if (kb < 8) {
-                d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-                double av[4];
+    // (b) recursive assembly X21 = -X22 (L21 X11) over node half-sizes hs = 1, 2, 4 blocks; all nodes of a
+    //     level are independent; one or two 16x16 outputs per wave, accumulated in registers (the products
+    //     read blocks that other waves overwrite, so each half-step is compute | barrier | write | barrier)
+    for (int hs = 1; hs <= 4; hs <<= 1) {
+        const int nout = 4 * hs;  // (8 / (2 hs)) nodes x hs^2 outputs
+        for (int half = 0; half < 2; ++half) {
+            d4_t acc[2];
+            int oi[2], oj[2];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) av[s] = sL[(kb * 16 + fr) * LP + base + 4 * s + q];
+            for (int u = 0; u < 2; ++u) {
+                acc[u] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                const int o = wave + 8 * u;
+                oi[u] = -1;
+                oj[u] = 0;
+                if (o < nout) {
+                    const int node = o / (hs * hs), w = o % (hs * hs);
+                    const int b0 = 2 * hs * node;
+                    const int i = b0 + hs + w / hs, j = b0 + w % hs;
+                    oi[u] = i;
+                    oj[u] = j;
+                    // half 0: T[i][j]   = sum_{k=j}^{b0+hs-1} L[i][k] X[k][j]
+                    // half 1: X21[i][j] = - sum_{k=b0+hs}^{i} X[i][k] T[k][j]
+                    const int k0 = half == 0 ? j : b0 + hs;
+                    const int k1 = half == 0 ? b0 + hs - 1 : i;
+                    for (int k = k0; k <= k1; ++k) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double bv = sL[(base + 4 * s + q) * LP + base + fr];  // X_jj[m = 4s+q][col fr]
-                    acc = mfma(av[s], bv, acc);
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            double a = sL[(i * 16 + fr) * LP + k * 16 + 4 * s4 + q];
+                            const double b = sL[(k * 16 + 4 * s4 + q) * LP + j * 16 + fr];
+                            if (half == 1) a = -a;
+                            acc[u] = mfma(a, b, acc[u]);
+                        }
+                    }
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sL[(kb * 16 + q + 4 * r) * LP + base + fr] = acc[r];
             }
-        }
-        __syncthreads();
-        // X[ib][jb] = - sum_{kb = jb+1..ib} X[ib][kb] * T[kb]   (accumulate in registers, then overwrite T)
-        const int ib = jb + 1 + wave;
-        d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-        if (ib < 8) {
-            for (int kb = jb + 1; kb <= ib; ++kb) {
+            __syncthreads();
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double a = -sL[(ib * 16 + fr) * LP + kb * 16 + 4 * s + q];
-                    const double b = sL[(kb * 16 + 4 * s + q) * LP + base + fr];
-                    acc = mfma(a, b, acc);
+            for (int u = 0; u < 2; ++u) {
+                if (oi[u] >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sL[(oi[u] * 16 + q + 4 * r) * LP + oj[u] * 16 + fr] = acc[u][r];
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (ib < 8) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + base + fr] = acc[r];
-        }
-        __syncthreads();
     }
 
     STAMP(9);
@@ -282,7 +314,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
 
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps) {
-    constexpr size_t lds = (size_t)(128 * LP + 160) * sizeof(double);
+    constexpr size_t lds = (size_t)(128 * LP + SC_SIZE) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_cholinv_f64),
