@@ -61,6 +61,7 @@ def one_step(args, comm, engines, data):
         first_run_max_iters = args.evals
         restart_max_iters = args.evals
         num_restarts = args.restarts
+        restart_concurrency = args.concurrency
 
     model = BudgetNARGP(4, f_exact=hf_4d, f_low=None, lf_X=X_lf, lf_Y=Y_lf, seed=args.seed, comm=comm,
                         engines=engines)
@@ -119,6 +120,8 @@ def main():
     ap.add_argument("--evals", type=int, default=20, help="objective evaluations per L-BFGS-B run")
     ap.add_argument("--restarts", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--concurrency", type=int, default=2,
+                    help="randomized restarts in flight beside the main run (auxiliary engine handles per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -145,6 +148,8 @@ def main():
 
     data = make_data(args.n, args.n, args.n)
     engines = {"lf": Engine(local_rank), "hf": Engine(local_rank)}
+    for j in range(1, args.concurrency + 1 if args.concurrency > 1 else 1):
+        engines["hf#%d" % j] = Engine(local_rank)
 
     for _ in range(args.warmup):
         one_step(args, comm, engines, data)
@@ -163,7 +168,12 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
 
     if rank == 0:
-        clf, chf = engines["lf"].counters(), engines["hf"].counters()
+        clf = engines["lf"].counters()
+        chf = engines["hf"].counters()
+        for k_, e_ in engines.items():
+            if k_.startswith("hf#"):
+                for kk, vv in e_.counters().items():
+                    chf[kk] += vv
         kinv_ms = clf["kinv_ms"] + chf["kinv_ms"]
         kinv_launches = clf["grad_evals"] + chf["grad_evals"]
         kinv_flops = clf["kinv_flops"] + chf["kinv_flops"]
@@ -184,6 +194,7 @@ def main():
                        "n": args.n, "evals_per_run": args.evals, "restarts": args.restarts,
                        "evals_issued_rank0_per_step": evals / args.steps,
                        "gpu_ms_per_evaluation": round(gpu_eval_ms, 3),
+                       "restart_concurrency": args.concurrency,
                        "sharding": "restarts + predictive rows over ranks; LF run and first HF run replicated"},
             "roofline": {"kernel": "mfgp_kinv_syrk_f64 (K^-1 = L^-T L^-1, one launch per evaluation)",
                          "bound": "mfma", "achieved": round(ach_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -25,6 +25,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     restart_max_iters = 1000    # :137
     num_restarts = 6            # src/MFDataFusion.py:100
     lf_max_iters = 1000         # lf_model.optimize() default budget (src/abstractMFGP.py:103)
+    restart_concurrency = 1     # >1: that many randomized restarts run concurrently with the first run / restart 0
 
     @abc.abstractmethod
     def __init__(self, name: str, input_dim: int, num_derivatives: int, tau: float, f_exact: callable,
@@ -140,14 +141,42 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
 
     def ARD(self, model, num_restarts):
         """noise := 0.01 Var(Y), fixed -> one L-BFGS-B run (500) -> free the noise -> `num_restarts`
-        restarts (1000 each), best wins (src/abstractMFGP.py:131-137).  1 + num_restarts runs per fit."""
+        restarts (1000 each), best wins (src/abstractMFGP.py:131-137).  1 + num_restarts runs per fit.
+
+        With `restart_concurrency` > 1 the randomized restarts 1.. (which, by paramz' semantics, start from fresh
+        N(0,1) draws and so do not depend on the first run) execute on auxiliary engine handles in background
+        threads WHILE the main thread does the first run and restart 0; same runs, same winner rule."""
         model[".*Gaussian_noise"] = model.Y.var() * self.noise_ratio
         model[".*Gaussian_noise"].fix()
+        conc = int(self.restart_concurrency)
+        rank, size = self.comm.rank, self.comm.size
+        mine_bg = [i for i in range(1, num_restarts) if i % size == rank]
+        if conc <= 1 or not mine_bg:
+            model.optimize(max_iters=self.first_run_max_iters)
+            model[".*Gaussian_noise"].unfix()
+            model[".*Gaussian_noise"].constrain_positive()
+            model.optimize_restarts(num_restarts, optimizer="bfgs", max_iters=self.restart_max_iters, verbose=False,
+                                    rand_gen=self._restart_rng(), comm=self.comm)
+            return
+        level = [k for k, e in self._engines.items() if e is model._engine]
+        tag = level[0] if level else "aux"
+        aux = [self._engine("%s#%d" % (tag, j)) for j in range(1, min(conc, len(mine_bg)) + 1)]
+        handle = model.start_background_restarts(mine_bg, aux, free=model.parameters(), rand_gen=self._restart_rng(),
+                                                 max_iters=self.restart_max_iters)
         model.optimize(max_iters=self.first_run_max_iters)
         model[".*Gaussian_noise"].unfix()
         model[".*Gaussian_noise"].constrain_positive()
-        model.optimize_restarts(num_restarts, optimizer="bfgs", max_iters=self.restart_max_iters, verbose=False,
-                                rand_gen=self._restart_rng(), comm=self.comm)
+        runs = []
+        if rank == 0:
+            r0 = model.optimize(max_iters=self.restart_max_iters)   # restart 0 continues from the current point
+            if r0 is not None:
+                runs.append((r0.f_opt, r0.x_opt, 0))
+        runs += handle.result()
+        if size > 1:
+            runs = [r for part in self.comm.allgather_object(runs) for r in part]
+        if runs:
+            best = min(runs, key=lambda r: (r[0], r[2]))
+            model.optimizer_array = best[1]
 
     # ---- adaptation loop ---------------------------------------------------------------------------------
     def adapt_and_plot(self, plot_means: bool = False, plot_uncertainties: bool = False, plot_error: bool = False,

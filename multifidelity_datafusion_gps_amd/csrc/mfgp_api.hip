@@ -297,7 +297,8 @@ static void plan_potrf_rl(mfgp_handle* h) {
                     st.rec_ev = ev_next_prev;
                 }
                 if (M2 < nb) {   // ... then the rest, overlapped with the next macro panel's chain
-                    const int T = pick_tile(ntiles_cols(M2, nb));
+                    int T = pick_tile(ntiles_cols(M2, nb));
+                    if (const char* e = getenv("MFGP_BULK_TILE")) T = atoi(e) == 64 ? 64 : T;
                     const int first = (int)h->tasks.size();
                     syrk_tasks(T, M2, nb, M0, M1);
                     add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);

@@ -472,6 +472,108 @@ class GPRegression:
         self.optimization_runs.append(run)
         return run
 
+    # ---- stateless objective: lets independent L-BFGS-B runs proceed concurrently on separate engines --------
+    def _stateless_objective(self, eng, free):
+        """-> f_fp(x) evaluating NLML and its optimizer-space gradient on `eng` WITHOUT touching the model's
+        Param objects (free = the parameters x stands for; every other parameter keeps its current value)."""
+        params = self.parameters()
+        base = {id(p): p.value for p in params}
+        free_ids = [id(p) for p in free]
+        part_ids = [(id(v), id(l)) for v, l in self._part_params]
+        term_ids = [[id(f.variance) for f in term] for term in self.kern._terms()]
+        noise_id = id(self.likelihood.variance)
+        state = {"fails": 0}
+
+        def f_fp(x):
+            vals = dict(base)
+            pv = _logexp_f(np.asarray(x, dtype=np.float64))
+            for k, v in zip(free_ids, pv):
+                vals[k] = float(v)
+            theta = np.array([vals[k] for pair in part_ids for k in pair])
+            noise = vals[noise_id]
+            jitter_extra, tries = 0.0, 0
+            try:
+                while True:
+                    try:
+                        nlml, g = eng.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=True)
+                        self.n_evals += 1
+                        break
+                    except NotPositiveDefinite:
+                        self.n_evals += 1
+                        tries += 1
+                        diag_mean = sum(np.prod([vals[k] for k in t]) for t in term_ids) + noise + CONST_JITTER
+                        if tries > 5 or not np.isfinite(diag_mean):
+                            raise np.linalg.LinAlgError("not positive definite, even with jitter.")
+                        jitter_extra = diag_mean * 1e-6 * 10 ** (tries - 1)
+                state["fails"] = 0
+            except (np.linalg.LinAlgError, ZeroDivisionError, ValueError):
+                if state["fails"] >= self._allowed_failures:
+                    raise
+                state["fails"] += 1
+                return np.inf, np.zeros_like(pv)
+            acc = {}
+            for i, (kv, kl) in enumerate(part_ids):
+                acc[kv] = acc.get(kv, 0.0) + g[2 * i]
+                acc[kl] = acc.get(kl, 0.0) + g[2 * i + 1]
+            acc[noise_id] = g[-1]
+            gf = _logexp_gradfactor(pv, np.array([acc[k] for k in free_ids]))
+            return nlml, np.clip(gf, -1e100, 1e100)
+
+        return f_fp
+
+    def start_background_restarts(self, indices, engines, free=None, rand_gen=None, max_iters=1000):
+        """Run the randomized restarts `indices` (each: N(0,1) start in optimizer space, L-BFGS-B with
+        maxfun = maxiter = max_iters) on the given auxiliary engines, one thread per engine; returns a handle
+        whose .result() gives [(f_opt, x_opt, index), ...].  `free` = the parameters that are free DURING the
+        restarts (default: all).  The restarts of the reference recipe do not depend on the run that precedes
+        them (paramz randomizes every free parameter), so they may overlap it; with two or three evaluations
+        in flight the GPU's idle phases (the serial Cholesky chain) of one are filled by the bulk work of another."""
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        free = list(free) if free is not None else self.parameters()
+        indices = list(indices)
+        if not indices or not engines:
+            class _Done:
+                def result(self_inner):
+                    return []
+            return _Done()
+        for e in engines:
+            e.set_data(self.X, self.Y[:, 0])
+            e.set_kernel(self._parts)
+        starts = {}
+        for i in indices:  # draw in index order (deterministic with a seeded rand_gen(i))
+            gen = rand_gen(i) if callable(rand_gen) else None
+            draw = gen(size=len(free)) if gen is not None else np.random.normal(size=len(free))
+            # same round trip through the parameter domain as randomize() + optimize(): bit-identical start
+            starts[i] = _logexp_finv(_logexp_f(draw))
+        pool_q = queue.Queue()
+        for e in engines:
+            pool_q.put(e)
+        lock = threading.Lock()
+
+        def one(i):
+            eng = pool_q.get()
+            try:
+                f_fp = self._stateless_objective(eng, free)
+                x_opt, f_opt, _ = _sciopt.fmin_l_bfgs_b(f_fp, starts[i], maxfun=int(max_iters), maxiter=int(max_iters))
+                with lock:
+                    self.optimization_runs.append(_OptRun(np.array(x_opt), float(f_opt), -1, "background"))
+                return float(f_opt), np.array(x_opt), i
+            finally:
+                pool_q.put(eng)
+
+        ex = ThreadPoolExecutor(max_workers=len(engines))
+        futs = [ex.submit(one, i) for i in indices]
+
+        class _Handle:
+            def result(self_inner):
+                try:
+                    return [f.result() for f in futs]
+                finally:
+                    ex.shutdown(wait=True)
+        return _Handle()
+
     def optimize_restarts(self, num_restarts=10, robust=False, verbose=True, parallel=False, num_processes=None,
                           rand_gen=None, comm=None, **kwargs):
         """Restart 0 continues from the current point; restarts 1.. randomize first; the best f_opt wins

@@ -136,3 +136,21 @@ def test_adaptation_improves_mse():
     assert len(model.hf_X) == 10
     assert mse_after < mse_before
     model.close()
+
+
+def test_concurrent_restarts_give_the_sequential_result():
+    """restart_concurrency > 1 runs the randomized restarts on auxiliary engines beside the first run:
+    same runs, same winner (seeded per-restart draws), so the fitted parameters agree."""
+    import multifidelity_datafusion_gps_amd as mf
+    rng = np.random.default_rng(21)
+    X_hf = rng.uniform(size=(150, 2))
+    out = []
+    for conc in (1, 3):
+        model = mf.NARGP(2, hf2, lf2, seed=5)
+        model.first_run_max_iters, model.restart_max_iters, model.restart_concurrency = 40, 40, conc
+        model.fit(X_hf)
+        out.append(np.array([p.value for p in model.hf_model.parameters()]))
+        if conc > 1:
+            assert any(k.startswith("hf#") for k in model._engines)
+        model.close()
+    np.testing.assert_allclose(out[1], out[0], rtol=1e-6)
