@@ -211,11 +211,19 @@ static int new_event(mfgp_handle* h, int& counter) {
 }
 
 static void plan_potrf_rl(mfgp_handle* h) {
+    // Blocked Cholesky with macro panels of MB leaf blocks and look-ahead over two streams.
+    //   main stream (the serial chain), for every block column c of a macro panel [M0, M1):
+    //       colupdate(c): A[i,c] -= sum_{j in [M0,c)} L[i,j] L[c,j]^T   (left-looking inside the macro, K <= (MB-1)*128)
+    //       leaf(c)     : L_cc, X_cc = L_cc^-1
+    //       panel(c)    : L[i,c] = A[i,c] X_cc^T, i > c
+    //   bulk stream, after the macro's chain: A[i,j] -= L[i,M0:M1] L[j,M0:M1]^T (K = MB*128), first the block
+    //       columns of the NEXT macro panel one by one (each releases the chain step that needs it), then the rest,
+    //       which overlaps the next macro's chain.
     const int64_t ld = h->Np;
     const int nb = h->nblk;
-    int MB = 4;  // macro panel = MB leaf blocks: the bulk trailing update runs with K = MB*128
+    int MB = 4;
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
-    bool lookahead = true;  // bulk updates on a second stream, overlapped with the next macro panel's chain
+    bool lookahead = true;
     if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
     int nev = 0;
     auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
@@ -235,25 +243,33 @@ static void plan_potrf_rl(mfgp_handle* h) {
             }
     };
     auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
-    int ev_next_prev = 0;  // event recorded after the update of THIS macro panel's columns by the previous one
+    std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
     for (int M0 = 0; M0 < nb; M0 += MB) {
         const int M1 = std::min(M0 + MB, nb);
         const int M2 = std::min(M1 + MB, nb);
-        const size_t chain_begin = h->plan.size();
-        for (int k = M0; k < M1; ++k) {
+        for (int c = M0; c < M1; ++c) {
+            bool waited = false;
+            if (c > M0) {   // left-looking update of block column c with the macro's finished columns
+                const int T = 64;  // latency-bound, on the serial chain: many small tiles
+                const int first = (int)h->tasks.size();
+                syrk_tasks(T, c, c + 1, M0, c);
+                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+                if (lookahead && ev_col[c] > 0) { h->plan.back().wait_ev = ev_col[c]; waited = true; }
+            }
             Step s{};
             s.kind = 0;
-            s.blk = k;
+            s.blk = c;
+            if (lookahead && !waited && ev_col[c] > 0) s.wait_ev = ev_col[c];
             h->plan.push_back(s);
-            const int rem = nb - 1 - k;
+            const int rem = nb - 1 - c;
             if (rem == 0) break;
-            const int64_t kc = (int64_t)k * NB;
-            {   // panel: L[i,k] = A[i,k] * X_kk^T
+            const int64_t kc = (int64_t)c * NB;
+            {   // panel: L[i,c] = A[i,c] * X_cc^T
                 const int T = pick_tile(rem);
                 const int sc = NB / T;
                 const int first = (int)h->tasks.size();
-                for (int i = (k + 1) * sc; i < nb * sc; ++i)
-                    for (int j = k * sc; j < (k + 1) * sc; ++j) {
+                for (int i = (c + 1) * sc; i < nb * sc; ++i)
+                    for (int j = c * sc; j < (c + 1) * sc; ++j) {
                         GemmTask t{};
                         t.a_off = (int64_t)i * T * ld + kc;
                         t.b_off = (int64_t)j * T * ld + kc;
@@ -266,45 +282,37 @@ static void plan_potrf_rl(mfgp_handle* h) {
                     }
                 add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
             }
-            if (k + 1 < M1) {   // narrow update: the remaining block columns of this macro panel, K = 128
-                const int T = pick_tile(ntiles_cols(k + 1, M1));
-                const int first = (int)h->tasks.size();
-                syrk_tasks(T, k + 1, M1, k, k + 1);
-                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-            }
         }
-        if (lookahead && ev_next_prev > 0 && chain_begin < h->plan.size()) h->plan[chain_begin].wait_ev = ev_next_prev;
-        ev_next_prev = 0;
-        if (M1 < nb) {   // bulk trailing update with the whole macro panel, K = (M1-M0)*128
-            if (!lookahead) {
-                const int r = nb - M1;
-                const int T = pick_tile(r * (r + 1) / 2);
-                const int first = (int)h->tasks.size();
-                syrk_tasks(T, M1, nb, M0, M1);
-                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-            } else {
-                const int ev_chain = new_event(h, nev);
-                h->plan.back().rec_ev = ev_chain;                 // chain(M) complete (main stream)
-                {   // the next macro panel's columns first ...
-                    const int T = pick_tile(ntiles_cols(M1, M2));
-                    const int first = (int)h->tasks.size();
-                    syrk_tasks(T, M1, M2, M0, M1);
-                    add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-                    Step& st = h->plan.back();
-                    st.strm = 1;
-                    st.wait_ev = ev_chain;
-                    ev_next_prev = new_event(h, nev);
-                    st.rec_ev = ev_next_prev;
-                }
-                if (M2 < nb) {   // ... then the rest, overlapped with the next macro panel's chain
-                    int T = pick_tile(ntiles_cols(M2, nb));
-                    if (const char* e = getenv("MFGP_BULK_TILE")) T = atoi(e) == 64 ? 64 : T;
-                    const int first = (int)h->tasks.size();
-                    syrk_tasks(T, M2, nb, M0, M1);
-                    add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-                    h->plan.back().strm = 1;
-                }
-            }
+        if (M1 >= nb) break;
+        if (!lookahead) {
+            const int r = nb - M1;
+            const int T = pick_tile(r * (r + 1) / 2);
+            const int first = (int)h->tasks.size();
+            syrk_tasks(T, M1, nb, M0, M1);
+            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+            continue;
+        }
+        const int ev_chain = new_event(h, nev);
+        h->plan.back().rec_ev = ev_chain;   // chain(M) complete: every L[:, M0:M1] panel is final
+        bool first_bulk = true;
+        for (int c = M1; c < M2; ++c) {     // the next macro panel's block columns, one launch each
+            const int T = pick_tile(nb - c);
+            const int first = (int)h->tasks.size();
+            syrk_tasks(T, c, c + 1, M0, M1);
+            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+            Step& st = h->plan.back();
+            st.strm = 1;
+            if (first_bulk) st.wait_ev = ev_chain;
+            first_bulk = false;
+            ev_col[c] = new_event(h, nev);
+            st.rec_ev = ev_col[c];
+        }
+        if (M2 < nb) {   // the rest of the trailing matrix: overlaps the next macro panel's chain
+            const int T = pick_tile(ntiles_cols(M2, nb));
+            const int first = (int)h->tasks.size();
+            syrk_tasks(T, M2, nb, M0, M1);
+            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+            h->plan.back().strm = 1;
         }
     }
 }
