@@ -111,6 +111,15 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals):
                                                                  t["hf_predict_s"], measured, n_lf_evals, n_hf_evals)}
 
 
+def pmc_traffic(kernel, n):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc.json), or None"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        return int(d[kernel]["traffic_bytes"]) if int(d.get("n", -1)) == int(n) else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,11 +207,13 @@ def main():
                        "sharding": "restarts + predictive rows over ranks; LF run and first HF run replicated"},
             "roofline": {"kernel": "mfgp_kinv_syrk_f64 (K^-1 = L^-T L^-1, one launch per evaluation)",
                          "bound": "mfma", "achieved": round(ach_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach_tf / FP64_PEAK_TFLOPS, 4),
+                         "traffic": pmc_traffic("mfgp_kinv_syrk_f64", args.n),
                          "launches": int(kinv_launches), "avg_launch_ms": round(kinv_ms / max(kinv_launches, 1), 4)},
             "roofline_kbuild": {"kernel": "mfgp_kbuild_f64<MODE_TRI> (K(X,X)+noise lower triangle)", "bound": "hbm",
                                 "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
+                                "traffic": pmc_traffic("mfgp_kbuild_f64<0>", args.n),
                                 "launches": int(evals), "avg_launch_ms": round(kb_ms / max(evals, 1), 4)},
             "stage_ms_per_evaluation": {k: round((clf[k] + chf[k]) / max(evals, 1), 4)
                                         for k in ("kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms", "grad_ms")},
