@@ -176,6 +176,27 @@ def main():
         dt = float(tt.item())
     ms_per_step = dt * 1e3 / args.steps
 
+    # outside the timed region: the row-block K build + RCCL all-gather layout of north_star,
+    # one evaluation each way on the HF level, reported next to the local build it competes with
+    rowblock = None
+    if world > 1:
+        try:
+            th, nz = np.ones(6), 0.05
+            e = engines["hf"]
+            e.eval(th, nz)
+            barrier()
+            t1 = time.perf_counter()
+            f_loc = e.eval(th, nz, want_grad=False)
+            barrier()
+            t2 = time.perf_counter()
+            f_rb = sharding.eval_rowblock_allgather(e, comm, th, nz, want_grad=False)
+            barrier()
+            t3 = time.perf_counter()
+            rowblock = {"local_build_eval_ms": round((t2 - t1) * 1e3, 3), "rowblock_allgather_eval_ms": round((t3 - t2) * 1e3, 3),
+                        "nlml_equal": bool(f_loc == f_rb)}
+        except Exception as ex:  # noqa: BLE001 - diagnostic only, never fails the bench line
+            rowblock = {"error": repr(ex)[:200]}
+
     if rank == 0:
         clf = engines["lf"].counters()
         chf = engines["hf"].counters()
@@ -219,6 +240,8 @@ def main():
                                         for k in ("kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms", "grad_ms")},
             "result_checksum": {"mean_sum": float(np.sum(mean)), "var_sum": float(np.sum(var))},
         }
+        if rowblock is not None:
+            out["rowblock_allgather"] = rowblock
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args, data, clf["evals"] / args.steps, chf["evals"] / args.steps)
             out["cpu_baseline"] = cb

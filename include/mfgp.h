@@ -103,6 +103,16 @@ int32_t mfgp_set_kernel(mfgp_handle* h, const mfgp_kern_part* parts, int32_t n_p
 int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitter,
                   int32_t want_grad, double* nlml, double* grad);
 
+/* Row-block form of the K build for the multi-GPU layout of SURVEY 8(e3) / north_star: each rank builds rows
+ * [row_begin, row_end) (multiples of 64, within the padded size) of Ky = K + (noise+jitter) I -- all columns --
+ * in place in the device matrix, the ranks all-gather their blocks through the pointer mfgp_dev_matrix returns
+ * (RCCL, e.g. torch.distributed.all_gather_into_tensor on a tensor wrapping that pointer), then
+ * mfgp_eval_prebuilt factorises what is there instead of building K itself.  Same arithmetic as mfgp_eval. */
+int32_t mfgp_kbuild_rows(mfgp_handle* h, const double* theta, double noise, double jitter, int64_t row_begin,
+                         int64_t row_end);
+int32_t mfgp_dev_matrix(mfgp_handle* h, void** dev_ptr, int64_t* padded_n); /* Np x Np fp64, row-major, ld = Np */
+int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, double* grad);
+
 /* the pieces of mfgp_eval, for callers that want them separately (same state machine) */
 int32_t mfgp_factorize(mfgp_handle* h, const double* theta, double noise, double jitter);
 int32_t mfgp_nlml(mfgp_handle* h, double* value);

@@ -18,7 +18,7 @@ MAX_PARTS = 6
 # every symbol include/mfgp.h declares (tests check the .so exports each of them)
 EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
-    "mfgp_set_kernel", "mfgp_eval", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_predict",
+    "mfgp_set_kernel", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_predict",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters",
     "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_probe", "mfgp_dbg_probe_detail",
@@ -88,6 +88,9 @@ def load_library(path=None):
         "mfgp_set_data": (i32, [H, dp, i64, i32, dp]),
         "mfgp_set_kernel": (i32, [H, ctypes.POINTER(KernPart), i32]),
         "mfgp_eval": (i32, [H, dp, f64, f64, i32, dp, dp]),
+        "mfgp_kbuild_rows": (i32, [H, dp, f64, f64, i64, i64]),
+        "mfgp_dev_matrix": (i32, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(i64)]),
+        "mfgp_eval_prebuilt": (i32, [H, i32, dp, dp]),
         "mfgp_factorize": (i32, [H, dp, f64, f64]),
         "mfgp_nlml": (i32, [H, dp]),
         "mfgp_nlml_grad": (i32, [H, dp]),
@@ -188,6 +191,25 @@ class Engine:
         rc = self._lib.mfgp_eval(self._h, _dptr(theta), float(noise), float(jitter), int(bool(want_grad)),
                                  ctypes.byref(nlml), _dptr(grad))
         self._check(rc, "mfgp_eval")
+        return (nlml.value, grad) if want_grad else nlml.value
+
+    # -- row-block K build + all-gather (multi-GPU layout of SURVEY 8(e3)) ---------------------------
+    def kbuild_rows(self, theta, noise, jitter, row_begin, row_end):
+        theta = _c64(theta).reshape(-1)
+        self._check(self._lib.mfgp_kbuild_rows(self._h, _dptr(theta), float(noise), float(jitter), int(row_begin),
+                                               int(row_end)), "mfgp_kbuild_rows")
+
+    def dev_matrix(self):
+        """(device pointer, padded size Np) of the Np x Np fp64 matrix the factorisation consumes"""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._check(self._lib.mfgp_dev_matrix(self._h, ctypes.byref(p), ctypes.byref(n)), "mfgp_dev_matrix")
+        return p.value, n.value
+
+    def eval_prebuilt(self, want_grad=True):
+        nlml = ctypes.c_double()
+        grad = np.zeros(2 * self.n_parts + 1)
+        self._check(self._lib.mfgp_eval_prebuilt(self._h, int(bool(want_grad)), ctypes.byref(nlml), _dptr(grad)),
+                    "mfgp_eval_prebuilt")
         return (nlml.value, grad) if want_grad else nlml.value
 
     def factorize(self, theta, noise, jitter=1e-8):

@@ -147,16 +147,18 @@ __device__ __forceinline__ void cov_values(const KernSpecDev& sp, const double* 
     for (int e = 0; e < 16; ++e) K[e] += prod[e];
 }
 
-enum { MODE_TRI = 0, MODE_PANEL = 1, MODE_FULL = 2 };
+enum { MODE_TRI = 0, MODE_PANEL = 1, MODE_FULL = 2, MODE_ROWS = 3 };
 
 // MODE_TRI   : lower-triangle tiles of Ky = K + (noise+jitter) I on the padded Np grid (identity padding)
 // MODE_PANEL : Kx[r][c] = k(Xs[r], X[c]); rows from Xs (Nrows padded rows), 0 for c >= N
 // MODE_FULL  : full K (no noise) into an N x N buffer, bounds-checked
+// MODE_ROWS  : a block of FULL rows of Ky (all Np columns, noise + identity padding as MODE_TRI): the unit a rank
+//              builds when K(X,X) is sharded by row blocks and all-gathered; bi is offset by `row_tile0`
 template <int MODE>
 __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const double* __restrict__ Xr,
                                                        const double* __restrict__ Xc,
                                                        const double* __restrict__ params, int N, int Np,
-                                                       double* __restrict__ out, int ld) {
+                                                       double* __restrict__ out, int ld, int row_tile0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sxi = smem;
     double* sxj = smem + sp.D * XP;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const dou
         bi = i;
         bj = b - i * (i + 1) / 2;
     } else {
-        bi = blockIdx.y;
+        bi = blockIdx.y + row_tile0;
         bj = blockIdx.x;
     }
     const int tid = threadIdx.x;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const dou
 
     double Kv[16];
     cov_values(sp, params, sxi, sxj, ty, tx, Kv);
-    const double diag_add = (MODE == MODE_TRI) ? (params[2 * sp.nf] + params[2 * sp.nf + 1]) : 0.0;
+    const double diag_add = (MODE == MODE_TRI || MODE == MODE_ROWS) ? (params[2 * sp.nf] + params[2 * sp.nf + 1]) : 0.0;
 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const dou
         for (int c = 0; c < 4; ++c) {
             const int gj = bj * KT + col_of(tx, c);
             double k = Kv[r * 4 + c];
-            if (MODE == MODE_TRI) {
+            if (MODE == MODE_TRI || MODE == MODE_ROWS) {
                 if (gi >= N || gj >= N) k = (gi == gj) ? 1.0 : 0.0;
                 else if (gi == gj) k += diag_add;
             } else if (MODE == MODE_PANEL) {
@@ -218,17 +220,22 @@ void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X, 
                        int N, int Np, double* A, int ld) {
     const int nt = Np / KT;
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_TRI>), dim3(nt * (nt + 1) / 2), dim3(256), kb_lds(spec.D), s,
-                       spec, X, X, params, N, Np, A, ld);
+                       spec, X, X, params, N, Np, A, ld, 0);
 }
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
                          const double* X, const double* params, int N, int Np, double* Kx, int ld) {
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_PANEL>), dim3(Np / KT, Nsp / KT), dim3(256), kb_lds(spec.D), s,
-                       spec, Xs, X, params, N, Np, Kx, ld);
+                       spec, Xs, X, params, N, Np, Kx, ld, 0);
 }
 void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
                         int N, int Np, double* out, int ld) {
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_FULL>), dim3(Np / KT, Np / KT), dim3(256), kb_lds(spec.D), s,
-                       spec, X, X, params, N, Np, out, ld);
+                       spec, X, X, params, N, Np, out, ld, 0);
+}
+void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params, int N, int Np,
+                        double* A, int ld, int row_begin, int row_end) {
+    hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_ROWS>), dim3(Np / KT, (row_end - row_begin) / KT), dim3(256), kb_lds(spec.D), s,
+                       spec, X, X, params, N, Np, A, ld, row_begin / KT);
 }
 
 // ------------------------------------------------------------------------------------------------

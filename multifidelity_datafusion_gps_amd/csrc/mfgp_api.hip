@@ -635,25 +635,36 @@ static int check_ready(mfgp_handle* h, const char* who) {
 }
 
 // enqueue K-build + cholinv + solve (+ K^-1 + gradient); no host sync
-static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, double jitter, bool want_grad) {
+static int set_params(mfgp_handle* h, const double* theta, double noise, double jitter) {
     const int nf = h->spec.nf;
     for (int i = 0; i < 2 * nf; ++i) {
-        if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "mfgp_eval: parameters must be positive and finite");
+        if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "parameters must be positive and finite");
         h->theta[i] = theta[i];
         h->hres[32 + i] = theta[i];
     }
-    if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "mfgp_eval: noise and jitter must be >= 0");
+    if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "noise and jitter must be >= 0");
     h->noise = noise; h->jitter = jitter;
     h->params_set = true;
     h->hres[32 + 2 * nf] = noise;
     h->hres[32 + 2 * nf + 1] = jitter;
+    HIPCHK(h, hipMemcpyAsync(h->dparams, h->hres + 32, (2 * nf + 2) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, double jitter, bool want_grad,
+                        bool prebuilt = false) {
     hipStream_t s = h->stream;
     h->launches = 0;
-    HIPCHK(h, hipMemcpyAsync(h->dparams, h->hres + 32, (2 * nf + 2) * sizeof(double), hipMemcpyHostToDevice, s));
+    if (!prebuilt) {
+        const int rc_ = set_params(h, theta, noise, jitter);
+        if (rc_) return rc_;
+    }
     HIPCHK(h, hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
     HIPCHK(h, hipEventRecord(h->ev[0], s));
-    launch_kbuild_tri(s, h->spec, h->dX, h->dparams, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
-    h->launches++;
+    if (!prebuilt) {
+        launch_kbuild_tri(s, h->spec, h->dX, h->dparams, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
+        h->launches++;
+    }
     HIPCHK(h, hipEventRecord(h->ev[1], s));
     for (const Step& st : h->plan) run_step(h, st);
     HIPCHK(h, hipEventRecord(h->ev[2], s));
@@ -730,6 +741,47 @@ int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitt
     if (!theta) return fail(h, -1, "mfgp_eval: theta is NULL");
     HIPCHK(h, hipSetDevice(h->device));
     rc = enqueue_eval(h, theta, noise, jitter, want_grad != 0);
+    if (rc) return rc;
+    rc = finish_eval(h, want_grad != 0);
+    if (rc) return rc;
+    if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
+    if (want_grad && grad)
+        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) grad[i] = h->grad[i];
+    return 0;
+}
+
+int32_t mfgp_kbuild_rows(mfgp_handle* h, const double* theta, double noise, double jitter, int64_t row_begin,
+                         int64_t row_end) {
+    int rc = check_ready(h, "mfgp_kbuild_rows");
+    if (rc) return rc;
+    if (!theta) return fail(h, -1, "mfgp_kbuild_rows: theta is NULL");
+    if (row_begin < 0 || row_end > h->Np || row_begin >= row_end || row_begin % 64 || row_end % 64)
+        return fail(h, -1, "mfgp_kbuild_rows: rows must be a non-empty range of multiples of 64 within the padded size");
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = set_params(h, theta, noise, jitter);
+    if (rc) return rc;
+    launch_kbuild_rows(h->stream, h->spec, h->dX, h->dparams, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np,
+                       (int)row_begin, (int)row_end);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->factorized = h->kinv_valid = h->grad_valid = false;
+    return 0;
+}
+
+int32_t mfgp_dev_matrix(mfgp_handle* h, void** ptr, int64_t* padded_n) {
+    if (!h || !ptr || !padded_n) return fail(h, -1, "mfgp_dev_matrix: NULL");
+    if (!h->have_data) return fail(h, -1, "mfgp_dev_matrix: mfgp_set_data not called");
+    *ptr = h->buf[BUF_A];
+    *padded_n = h->Np;
+    return 0;
+}
+
+int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, double* grad) {
+    int rc = check_ready(h, "mfgp_eval_prebuilt");
+    if (rc) return rc;
+    if (!h->params_set) return fail(h, -1, "mfgp_eval_prebuilt: mfgp_kbuild_rows not called");
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = enqueue_eval(h, nullptr, 0.0, 0.0, want_grad != 0, true);
     if (rc) return rc;
     rc = finish_eval(h, want_grad != 0);
     if (rc) return rc;

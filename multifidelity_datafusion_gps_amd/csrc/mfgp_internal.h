@@ -78,6 +78,9 @@ void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X, 
 //   panel: Kx[r][c] = k(Xs[r], X[c]) for r < Nsp, c < Np (0 for padded columns c >= N)
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
                          const double* X, const double* params, int N, int Np, double* Kx, int ld);
+//   rows [row_begin, row_end) (multiples of 64) of Ky, all Np columns, written at their place in A
+void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params, int N, int Np,
+                        double* A, int ld, int row_begin, int row_end);
 //   full symmetric K without noise into out (N x N, ld = N) for parity read-back
 void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
                         int N, int Np, double* out, int ld);

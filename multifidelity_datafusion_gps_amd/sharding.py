@@ -72,6 +72,38 @@ class TorchComm:
         return box[0]
 
 
+class _DevArray:
+    """zero-copy view of a device buffer for torch (the CUDA array interface torch.as_tensor understands)"""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def eval_rowblock_allgather(engine, comm, theta, noise, jitter=1e-8, want_grad=True):
+    """One objective(+gradient) evaluation with the K(X,X) build sharded by row blocks:
+    rank r builds its block of full rows of Ky on its GPU, the blocks are all-gathered over RCCL/xGMI IN PLACE in
+    every rank's device matrix, then every rank factorises (the Cholesky itself does not shard at these sizes).
+    Needs the padded size to split into equal 64-row multiples per rank; falls back to the local build otherwise.
+    At N = 8192 on 8 GPUs each rank receives 470 MB to save < 0.15 ms of local K-build: this path is provided
+    because the layout is what a DISTRIBUTED factorisation would start from, not because it is faster here."""
+    ptr, npad = engine.dev_matrix()
+    size, rank = comm.size, comm.rank
+    if size == 1 or npad % (64 * size) != 0:
+        if size == 1:
+            engine.kbuild_rows(theta, noise, jitter, 0, npad)
+            return engine.eval_prebuilt(want_grad)
+        return engine.eval(theta, noise, jitter, want_grad)
+    rows = npad // size
+    engine.kbuild_rows(theta, noise, jitter, rank * rows, (rank + 1) * rows)
+    import torch
+    import torch.distributed as dist
+    full = torch.as_tensor(_DevArray(ptr, (npad, npad)), device="cuda")
+    dist.all_gather_into_tensor(full, full[rank * rows:(rank + 1) * rows].clone())
+    torch.cuda.synchronize()
+    return engine.eval_prebuilt(want_grad)
+
+
 def split_rows(n, rank, size):
     """contiguous, balanced [begin, end) of n rows for `rank`"""
     base, rem = divmod(n, size)

@@ -217,3 +217,28 @@ def test_bench_size_properties(engine):
     m, v = engine.predict(Xa[perm][:256], include_noise=False)
     assert np.all(v >= 1e-15) and np.all(v <= theta[0] * theta[2] + theta[4] + 1e-12)
     assert np.abs(m - Y[perm][:256]).max() < 0.2
+
+
+def test_rowblock_kbuild_plus_prebuilt_eval_equals_fused_eval(engine):
+    """multi-GPU layout of SURVEY 8(e3): K built by blocks of full rows (as ranks would), then factorised in place.
+    Two 'rank' blocks built one after the other on this GPU stand in for the all-gather."""
+    from multifidelity_datafusion_gps_amd.sharding import LocalComm, eval_rowblock_allgather
+    c = cases.make_case("nargp_4d_n64")
+    rng = np.random.default_rng(3)
+    X = rng.uniform(size=(700, 4))
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    Y = cases.hf_4d(X)
+    theta, noise = np.array(c["theta"]), 0.02
+    engine.set_data(Xa, Y)
+    engine.set_kernel(c["parts"])
+    f0, g0 = engine.eval(theta, noise, 1e-8)
+    ptr, npad = engine.dev_matrix()
+    assert npad == 768 and ptr
+    engine.kbuild_rows(theta, noise, 1e-8, 0, 384)
+    engine.kbuild_rows(theta, noise, 1e-8, 384, 768)
+    f1, g1 = engine.eval_prebuilt(True)
+    assert f1 == f0 and np.array_equal(g1, g0)          # same kernels, same order: bitwise
+    f2, g2 = eval_rowblock_allgather(engine, LocalComm(), theta, noise)
+    assert f2 == f0 and np.array_equal(g2, g0)
+    with pytest.raises(RuntimeError):
+        engine.kbuild_rows(theta, noise, 1e-8, 10, 74)   # not multiples of 64
