@@ -125,18 +125,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=8192, help="N_lf = N_hf = N*")
+    ap.add_argument("--points", dest="n", type=int, default=8192, help="N_lf = N_hf = N*")
     ap.add_argument("--evals", type=int, default=20, help="objective evaluations per L-BFGS-B run")
     ap.add_argument("--restarts", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--concurrency", type=int, default=2,
                     help="randomized restarts in flight beside the main run (auxiliary engine handles per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: CPU rehearsal)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (with --backend gloo) on a one-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local_rank = 0
     import torch  # plumbing only: barrier + device sync + the tiny all-gathers of sharding.TorchComm
     torch.cuda.set_device(local_rank)
     from multifidelity_datafusion_gps_amd import sharding
@@ -144,8 +149,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        comm = sharding.TorchComm(device="cuda:%d" % local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            comm = sharding.TorchComm(device="cuda:%d" % local_rank)
+        else:
+            dist.init_process_group(backend=args.backend)
+            comm = sharding.TorchComm(device="cpu")
     else:
         comm = sharding.LocalComm()
 
@@ -171,7 +180,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        tt = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % local_rank) if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt * 1e3 / args.steps
