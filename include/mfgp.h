@@ -118,6 +118,12 @@ int32_t mfgp_factorize(mfgp_handle* h, const double* theta, double noise, double
 int32_t mfgp_nlml(mfgp_handle* h, double* value);
 int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad);
 
+/* Rank-1 append at the CURRENT hyper-parameters: extends L, L^-1, alpha, log-det and the quadratic form by one
+ * training row in O(N^2) instead of refactorising (the adaptation loop adds one row per step:
+ * src/abstractMFGP.py:320,354 -> src/MFDataFusion.py:93-98).  0 = appended; 1 = no padding slot left (N is a
+ * multiple of 128): call mfgp_set_data + mfgp_factorize; >1 = not positive definite with the new row. */
+int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new);
+
 /* replaces hf_model.predict(X*) / lf_model.predict(t) (src/MFDataFusion.py:156, src/abstractMFGP.py:104,114):
  * mean = K(X*,X) alpha ; var = kdiag(X*) - rowsum((K(X*,X) L^-T)^2), floored at 1e-15,
  * + noise when include_noise (GPy's predict() default).  Needs a successful mfgp_factorize/mfgp_eval.

@@ -57,11 +57,21 @@ class MultifidelityDataFusion(AbstractMFGP):
                                         initialize=True, engine=self._engine("hf"))
         self.ARD(self.hf_model, self.num_restarts)
 
+    def append_hf_point(self, x_new):
+        """add one high-fidelity point WITHOUT re-optimising the hyper-parameters (not in the reference, whose
+        adaptation refits from scratch every step): rank-1 Cholesky append on the device."""
+        x_new = np.asarray(x_new, dtype=np.float64).reshape(1, self.input_dim)
+        y_new = self.f_exact(x_new)
+        self.hf_X = np.vstack((self.hf_X, x_new))
+        self.hf_Y = np.vstack((self.hf_Y, y_new))
+        self.hf_model.append(self._augment_data(x_new), y_new)
+
     def adapt(self, adapt_steps: int, plot_mode: str = None, X_test: np.ndarray = None, Y_test: np.ndarray = None,
-              eps: float = 1e-8):
+              eps: float = 1e-8, reoptimize: bool = True):
         """acquire `adapt_steps` new high-fidelity points, each where the predictive variance is largest,
         refitting after every acquisition (src/MFDataFusion.py:102-139)."""
         self.adapt_steps = adapt_steps
+        self.reoptimize = reoptimize   # False: keep the hyper-parameters and append (O(N^2) per step)
         self.X_test = X_test
         self.Y_test = Y_test
         self.eps = eps

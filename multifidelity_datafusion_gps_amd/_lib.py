@@ -18,7 +18,7 @@ MAX_PARTS = 6
 # every symbol include/mfgp.h declares (tests check the .so exports each of them)
 EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
-    "mfgp_set_kernel", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_predict",
+    "mfgp_set_kernel", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters",
     "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_probe", "mfgp_dbg_probe_detail",
@@ -94,6 +94,7 @@ def load_library(path=None):
         "mfgp_factorize": (i32, [H, dp, f64, f64]),
         "mfgp_nlml": (i32, [H, dp]),
         "mfgp_nlml_grad": (i32, [H, dp]),
+        "mfgp_append_row": (i32, [H, dp, f64]),
         "mfgp_predict": (i32, [H, dp, i64, dp, dp, i32, i32]),
         "mfgp_get_K": (i32, [H, dp]),
         "mfgp_get_L": (i32, [H, dp]),
@@ -225,6 +226,19 @@ class Engine:
         g = np.zeros(2 * self.n_parts + 1)
         self._check(self._lib.mfgp_nlml_grad(self._h, _dptr(g)), "mfgp_nlml_grad")
         return g
+
+    def append_row(self, x_new, y_new):
+        """rank-1 append at the current hyper-parameters; True = appended, False = no padding slot left (refit needed)"""
+        x = _c64(x_new).reshape(-1)
+        if x.shape[0] != self.d:
+            raise ValueError("x_new must have %d entries" % self.d)
+        rc = self._lib.mfgp_append_row(self._h, _dptr(x), float(y_new))
+        if rc == 0:
+            self.n += 1
+            return True
+        if rc == 1:
+            return False
+        self._check(rc, "mfgp_append_row")
 
     def predict(self, Xstar, want_var=True, include_noise=True):
         Xs = _c64(Xstar)

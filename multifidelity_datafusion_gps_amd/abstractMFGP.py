@@ -195,7 +195,10 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             self.acquisition_values.append(fopt)
             if (plot_error or plot_uncertainties) and getattr(self, "X_test", None) is not None:
                 self.mse_history.append(self.get_mse(self.X_test, self.Y_test))
-            self.fit(new_hf_X)
+            if getattr(self, "reoptimize", True):
+                self.fit(new_hf_X)                       # the reference: full re-optimisation at N + 1 rows
+            else:
+                self.append_hf_point(acquired_x)         # hyper-parameters kept: O(N^2) rank-1 append on the device
             if np.abs(fopt) < self.eps:
                 self.adapt_steps = i + 1
                 print("Iteration stopped after {} iterations!".format(i + 1)

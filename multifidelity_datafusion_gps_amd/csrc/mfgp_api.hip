@@ -791,6 +791,61 @@ int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, doub
     return 0;
 }
 
+// rank-1 append at fixed hyper-parameters (the adaptation loop of src/abstractMFGP.py:320,354 grows the
+// training set by one row per step).  O(N^2): one covariance row, two triangular mat-vecs with the stored inverse
+// factor, one finishing kernel, one mat-vec for alpha.  Returns 0 = appended; 1 = no padding slot left (N is a multiple
+// of 128: the caller re-uploads and refactorises); >1 = not positive definite with the new row.
+int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
+    int rc = check_ready(h, "mfgp_append_row");
+    if (rc) return rc;
+    if (!x_new) return fail(h, -1, "mfgp_append_row: x_new is NULL");
+    if (!h->factorized) return fail(h, -1, "mfgp_append_row: no valid factorisation");
+    if (h->N >= h->Np) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int n = (int)h->N, D = h->D;
+    const int64_t Np = h->Np;
+    // stage the new row (host -> X[n], and as a 128-row zero-padded panel operand)
+    if (128 > h->xs_cap_rows || D != h->xs_cap_D) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (h->dXs) HIPCHK(h, hipFree(h->dXs));
+        h->xs_cap_rows = std::max(128, h->xs_cap_rows);
+        h->xs_cap_D = D;
+        HIPCHK(h, hipMalloc(&h->dXs, (size_t)h->xs_cap_rows * D * sizeof(double)));
+    }
+    HIPCHK(h, hipMemsetAsync(h->dXs, 0, (size_t)128 * D * sizeof(double), s));
+    HIPCHK(h, hipMemcpyAsync(h->dXs, x_new, (size_t)D * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->dX + (size_t)n * D, x_new, (size_t)D * sizeof(double), hipMemcpyHostToDevice, s));
+    h->hres[56] = y_new;
+    HIPCHK(h, hipMemcpyAsync(h->dY + n, h->hres + 56, sizeof(double), hipMemcpyHostToDevice, s));
+    // k = K(x_new, X[0:n]) -> row 0 of W ; l = X k ; w = X^T l
+    launch_kbuild_panel(s, h->spec, h->dXs, 128, h->dX, h->dparams, n, (int)Np, h->buf[BUF_W], (int)Np);
+    HIPCHK(h, hipMemsetAsync(h->dvec, 0, (size_t)Np * sizeof(double), s));
+    launch_rowdot(s, h->buf[BUF_S], (int)Np, h->buf[BUF_W], h->dvec, n, (int)Np, 0);
+    launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dvec, h->dvec2, n, n, 1);
+    double kdiag = 0.0, prod = 1.0;
+    int cur = h->spec.term[0];
+    for (int f = 0; f < h->spec.nf; ++f) {
+        if (h->spec.term[f] != cur) { kdiag += prod; prod = 1.0; cur = h->spec.term[f]; }
+        prod *= h->theta[2 * f];
+    }
+    kdiag += prod + h->noise + h->jitter;
+    launch_append_finish(s, h->buf[BUF_L], h->buf[BUF_S], (int)Np, n, h->dvec, h->dvec2, h->dz, kdiag, y_new, h->dres + 48);
+    launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dz, h->dalpha, n + 1, n + 1, 1);
+    HIPCHK(h, hipMemcpyAsync(h->hres + 48, h->dres + 48, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    if (h->hres[51] != 0.0) {
+        h->err = "mfgp_append_row: the extended matrix is not positive definite";
+        return n + 2;
+    }
+    h->N = n + 1;
+    h->logdet += 2.0 * log(h->hres[48]);
+    h->quad += h->hres[49] * h->hres[49];
+    h->kinv_valid = h->grad_valid = false;
+    return 0;
+}
+
 int32_t mfgp_factorize(mfgp_handle* h, const double* theta, double noise, double jitter) {
     return mfgp_eval(h, theta, noise, jitter, 0, nullptr, nullptr);
 }

@@ -89,6 +89,8 @@ void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
 //   y[i] = sum_{k in range(i)} M[i][k] x[k];  mode 0: k <= i (lower), 1: k >= i (upper), 2: all k < ncols
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
                    int ncols, int mode);
+void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
+                          double kdiag, double y_new, double* out);
 //   rowsumsq[i] = sum_{k < ncols} M[i][k]^2
 void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols);
 //   scalars[0] = sum z^2 ; scalars[1] = 2*sum logdet_part ; (single small block)

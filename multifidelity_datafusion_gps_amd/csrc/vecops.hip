@@ -69,6 +69,57 @@ __global__ __launch_bounds__(256) void mfgp_finish_solve_f64(const double* __res
     }
 }
 
+// rank-1 append: given l = X k (first n entries) and w = X^T l, finish the new row r = n of L and of
+// the mirrored inverse S, the new z entry and the scalars.  One workgroup.
+//   d = sqrt(kdiag - l.l) ; L[r][0:n] = l, L[r][r] = d ; X[r][0:n] = -w/d, X[r][r] = 1/d (both triangles of S)
+//   z[r] = (y_new - l.z) / d ; out = {d, z_r, l.l, status(0 ok / 1 not PD)}
+__global__ __launch_bounds__(256) void mfgp_append_finish_f64(double* __restrict__ L, double* __restrict__ S, int ld,
+                                                              int n, const double* __restrict__ l,
+                                                              const double* __restrict__ w, double* __restrict__ z,
+                                                              double kdiag, double y_new, double* __restrict__ out) {
+    __shared__ double red[512];
+    const int tid = threadIdx.x;
+    double ss = 0.0, lz = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        ss += l[i] * l[i];
+        lz += l[i] * z[i];
+    }
+    red[tid] = ss;
+    red[256 + tid] = lz;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            red[tid] += red[tid + off];
+            red[256 + tid] += red[256 + tid + off];
+        }
+        __syncthreads();
+    }
+    const double d2 = kdiag - red[0];
+    if (!(d2 > 0.0)) {
+        if (tid == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = red[0]; out[3] = 1.0; }
+        return;
+    }
+    const double d = sqrt(d2), rd = 1.0 / d;
+    for (int i = tid; i < n; i += 256) {
+        const double xv = -w[i] * rd;
+        L[(int64_t)n * ld + i] = l[i];
+        S[(int64_t)n * ld + i] = xv;
+        S[(int64_t)i * ld + n] = xv;
+    }
+    if (tid == 0) {
+        L[(int64_t)n * ld + n] = d;
+        S[(int64_t)n * ld + n] = rd;
+        const double zr = (y_new - red[256]) * rd;
+        z[n] = zr;
+        out[0] = d; out[1] = zr; out[2] = red[0]; out[3] = 0.0;
+    }
+}
+
+void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
+                          double kdiag, double y_new, double* out) {
+    hipLaunchKernelGGL(mfgp_append_finish_f64, dim3(1), dim3(256), 0, s, L, S, ld, n, l, w, z, kdiag, y_new, out);
+}
+
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
                    int ncols, int mode) {
     hipLaunchKernelGGL(mfgp_rowdot_f64, dim3((nrows + 3) / 4), dim3(256), 0, s, M, ld, x, y, nrows, ncols, mode);

@@ -614,6 +614,30 @@ class GPRegression:
         else:
             self.optimizer_array = initial_parameters
 
+    # ---- incremental data ------------------------------------------------------------------------------
+    def append(self, x_new, y_new):
+        """add ONE training row at the current hyper-parameters: O(N^2) rank-1 extension of the
+        factorisation on the device when a padding slot is free, full re-upload + lazy refactorisation otherwise
+        (and whenever the parameters changed since the last factorisation).  The numbers equal a fresh
+        factorisation of the extended data at the same hyper-parameters."""
+        x_new = np.asarray(x_new, dtype=np.float64).reshape(1, -1)
+        y_new = float(np.asarray(y_new).reshape(-1)[0])
+        done = False
+        if not self._dirty:
+            try:
+                done = self._engine.append_row(x_new[0], y_new)
+            except NotPositiveDefinite:
+                done = False
+        self.X = np.vstack([self.X, x_new])
+        self.Y = np.vstack([self.Y, [[y_new]]])
+        if done:
+            self._nlml = self._engine.nlml()
+            self._have_grad = False
+        else:
+            self._engine.set_data(self.X, self.Y[:, 0])
+            self._dirty = True
+        return done
+
     # ---- prediction ------------------------------------------------------------------------------------
     def predict(self, Xnew, full_cov=False, Y_metadata=None, kern=None, likelihood=None, include_likelihood=True):
         """-> (mean (N*,1), variance (N*,1)); the variance includes the noise variance and its latent

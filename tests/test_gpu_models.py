@@ -154,3 +154,31 @@ def test_concurrent_restarts_give_the_sequential_result():
             assert any(k.startswith("hf#") for k in model._engines)
         model.close()
     np.testing.assert_allclose(out[1], out[0], rtol=1e-6)
+
+
+def test_adapt_without_reoptimisation_uses_rank1_append():
+    """adapt(reoptimize=False): the hyper-parameters stay, every acquired point is appended on the device; the
+    model equals one fitted (at those hyper-parameters) on the extended data."""
+    import multifidelity_datafusion_gps_amd as mf
+    rng = np.random.default_rng(8)
+    model = mf.NARGP(2, hf2, lf2, seed=3, adapt_maximizer=mf.DIRECT1Maximizer())
+    model.first_run_max_iters, model.restart_max_iters = 40, 40
+    model.fit(rng.uniform(size=(30, 2)))
+    model.hf_model.likelihood.variance = 1e-4       # keep the comparison well conditioned (the fit drives the noise to ~0)
+    model.predict(rng.uniform(size=(3, 2)))          # factorise at these hyper-parameters
+    theta = [p.value for p in model.hf_model.parameters()]
+    evals0 = model.hf_model.n_evals
+    model.adapt(4, reoptimize=False)
+    assert len(model.hf_X) == 34 and model.hf_model.X.shape == (34, 3)
+    assert [p.value for p in model.hf_model.parameters()] == theta
+    assert model.hf_model.n_evals <= evals0 + 1          # no refits: appends only (at most the one lazy factorisation)
+    Xt = rng.uniform(size=(40, 2))
+    mean, var = model.predict(Xt)
+    parts, plist = model.kernel.engine_parts()
+    th = np.array([p.value for pair in plist for p in pair])
+    nz = model.hf_model.likelihood.variance.value
+    st = orc.inference(parts, th, nz, model.hf_model.X, model.hf_Y)
+    mu, v = orc.predict_stable(parts, th, nz, model.hf_model.X, st, model._augment_data(Xt))
+    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-6)
+    model.close()

@@ -242,3 +242,47 @@ def test_rowblock_kbuild_plus_prebuilt_eval_equals_fused_eval(engine):
     assert f2 == f0 and np.array_equal(g2, g0)
     with pytest.raises(RuntimeError):
         engine.kbuild_rows(theta, noise, 1e-8, 10, 74)   # not multiples of 64
+
+
+def test_rank1_append_equals_fresh_factorisation(engine, engine_cls):
+    """appending rows one at a time at fixed hyper-parameters gives the NLML / alpha / predictions of a
+    fresh factorisation of the extended data; a full 128-block (no padding slot) is reported, not mishandled."""
+    rng = np.random.default_rng(17)
+    X = rng.uniform(size=(140, 3))
+    Y = cases.hf_3d(X) - 5.0
+    parts, theta, noise = cases.single(cases.RBF, 3), np.array([1.1, 0.4]), 0.03
+    Xs = rng.uniform(size=(9, 3))
+    n0 = 120
+    engine.set_data(X[:n0], Y[:n0])
+    engine.set_kernel(parts)
+    engine.factorize(theta, noise, 1e-8)
+    fresh = engine_cls(0)
+    fresh.set_kernel(parts) if False else None
+    for n in range(n0, 132):
+        ok = engine.append_row(X[n], Y[n])
+        if n == 128:                       # N = 128 = Np: no slot left -> refit path
+            assert ok is False
+            engine.set_data(X[:n + 1], Y[:n + 1])
+            engine.factorize(theta, noise, 1e-8)
+            continue
+        assert ok is True
+        fresh.set_data(X[:n + 1], Y[:n + 1])
+        fresh.set_kernel(parts)
+        fresh.factorize(theta, noise, 1e-8)
+        assert engine.nlml() == pytest.approx(fresh.nlml(), rel=1e-11, abs=1e-10)
+        np.testing.assert_allclose(engine.get_alpha(), fresh.get_alpha(), rtol=0, atol=1e-9 * np.abs(fresh.get_alpha()).max())
+        m1, v1 = engine.predict(Xs)
+        m2, v2 = fresh.predict(Xs)
+        np.testing.assert_allclose(m1, m2, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
+    g1 = engine.nlml_grad()                # the appended state also feeds the gradient path
+    g2 = fresh.nlml_grad()
+    np.testing.assert_allclose(g1, g2, rtol=0, atol=1e-8 * np.abs(g2).max())
+    fresh.close()
+    # a duplicate of an existing row with zero noise is not positive definite -> status > 1, state unchanged
+    engine.set_data(X[:50], Y[:50])
+    engine.factorize(theta, 0.0, 0.0)
+    from multifidelity_datafusion_gps_amd._lib import NotPositiveDefinite
+    with pytest.raises(NotPositiveDefinite):
+        engine.append_row(X[7], Y[7])
+    assert engine.n == 50
