@@ -7,10 +7,10 @@ symlink to it.)
 from .abstractMFGP import AbstractMFGP
 from .MFDataFusion import MultifidelityDataFusion
 from .models import GPDF, GPDFC, NARGP
-from . import engine, sharding
+from . import engine, gpc, sharding
 from .adaptation_maximizers import AbstractMaximizer, DIRECT1Maximizer, ScipyDirectMaximizer
 from .augm_iterators import AbstractAugmIterator, BackwardAugmentation, EvenAugmentation
 
-__all__ = ["AbstractMFGP", "MultifidelityDataFusion", "NARGP", "GPDF", "GPDFC", "engine", "sharding",
+__all__ = ["AbstractMFGP", "MultifidelityDataFusion", "NARGP", "GPDF", "GPDFC", "engine", "gpc", "sharding",
            "AbstractMaximizer", "DIRECT1Maximizer", "ScipyDirectMaximizer", "AbstractAugmIterator",
            "BackwardAugmentation", "EvenAugmentation"]

@@ -46,7 +46,7 @@ def _logexp_f(x):
 
 def _logexp_finv(f):
     f = np.asarray(f, dtype=np.float64)
-    return np.where(f > _LIM_VAL, f, np.log(np.expm1(f)))
+    return np.where(f > _LIM_VAL, f, np.log(np.expm1(np.minimum(f, _LIM_VAL))))
 
 
 def _logexp_gradfactor(f, df):

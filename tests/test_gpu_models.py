@@ -182,3 +182,25 @@ def test_adapt_without_reoptimisation_uses_rank1_append():
     np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-6)
     np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-6)
     model.close()
+
+
+def test_mfgp_gpc_driver_with_legendre_pce():
+    """the reference's experiment scripts in miniature (tests/utils.py:75-86): adapt in rounds, refresh the polynomial
+    chaos moments of the fused mean after every round, compare with the analytic moments of hf_2d."""
+    import multifidelity_datafusion_gps_amd as mf
+    from multifidelity_datafusion_gps_amd.gpc import LegendreGPC, MFGP_GPC
+    a = [2.2 * np.pi, np.pi]
+    m_exact = np.prod([(1 - np.cos(ai)) / ai for ai in a])
+    rng = np.random.default_rng(10)
+    model = mf.NARGP(2, hf2, lf2, add_noise=True, seed=4, adapt_maximizer=mf.DIRECT1Maximizer())
+    model.first_run_max_iters, model.restart_max_iters = 40, 40
+    model.fit(rng.uniform(size=(12, 2)))
+    pce = LegendreGPC(lambda x: model.predict(x)[0], np.zeros(2), np.ones(2), polynomial_order=8, quadrature_order=8)
+    X_test = rng.uniform(size=(60, 2))
+    drv = MFGP_GPC(model, pce, num_adapts=2, init_cost=12, X_test=X_test, Y_test=hf2(X_test))
+    drv.adapt()
+    assert len(drv.mean_history) == 3 and drv.cost_history == [12, 17, 22]
+    assert len(model.hf_X) == 22
+    assert abs(drv.mean_history[-1] - m_exact) < 0.05
+    assert drv.mse_history[-1] < drv.mse_history[0] + 1e-12
+    model.close()

@@ -91,3 +91,29 @@ def test_split_rows_covers_everything_once():
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
     c = LocalComm()
     assert c.allgather_object(5) == [5] and c.size == 1
+
+
+def test_legendre_gpc_moments_match_closed_forms():
+    """mean / variance of prod sin(a_i x_i) + c on U[0,1]^d: the closed forms of the reference's tests/utils.py:14-27"""
+    from multifidelity_datafusion_gps_amd.gpc import LegendreGPC
+
+    def analytical_mean(a, constant=0.0):
+        return np.prod([(1 - np.cos(ai)) / ai for ai in a]) + constant
+
+    def analytical_var(a):
+        m = analytical_mean(a)
+        term1 = np.prod([0.5 - np.sin(2 * ai) / (4 * ai) for ai in a])
+        term3 = 2 * m * np.prod([(np.cos(ai) - 1) / ai for ai in a]) * ((-1) ** (len(a) - 1))
+        return term1 + m ** 2 + term3
+
+    for a in ([2.2 * np.pi, np.pi], [3.2 * np.pi, 2.1 * np.pi, 1.2 * np.pi]):
+        d = len(a)
+        f = lambda X: np.prod(np.sin(X * np.array(a)), axis=1)[:, None] + 5.0
+        g = LegendreGPC(f, np.zeros(d), np.ones(d), polynomial_order=14, quadrature_order=16)
+        g.calculate_coefficients()
+        assert g.quad_points.shape == (d, 17 ** d) and g.quad_weights.sum() == pytest.approx(1.0)
+        mean, var = g.get_mean_var()
+        assert mean == pytest.approx(analytical_mean(a, 5.0), rel=1e-9)
+        assert var == pytest.approx(analytical_var(a), rel=2e-3)   # truncated at total order 14
+    g.update_function(lambda X: np.full((len(X), 1), 2.0))
+    assert g.get_mean() == pytest.approx(2.0) and g.get_var() == pytest.approx(0.0, abs=1e-20)
