@@ -305,13 +305,14 @@ class Engine:
         return L, X, ld.value, rc
 
     def dbg_probe_detail(self):
-        out = np.zeros(16)
+        out = np.zeros(20)
         self._check(self._lib.mfgp_dbg_probe_detail(self._h, _dptr(out)), "mfgp_dbg_probe_detail")
         names = ["1w/SIMD x8acc", "2w/SIMD x8acc", "4w/SIMD x8acc", "1w/SIMD x1acc"]
         d = {n: dict(tflops=out[3 * i], cycles_per_mfma=out[3 * i + 1], clock_ghz=out[3 * i + 2])
              for i, n in enumerate(names)}
         d["valu_fma_f64_tflops"] = {"2w/SIMD": out[12], "4w/SIMD": out[13]}
         d["valu_plus_mfma_tflops"] = {"2w/SIMD": out[14], "4w/SIMD": out[15]}
+        d["valu_fma_f64_three_vgpr_operands_tflops"] = {"2w/SIMD": out[16], "4w/SIMD": out[17]}
         return d
 
     def dbg_probe(self):

@@ -206,6 +206,34 @@ __global__ __launch_bounds__(256) void mfgp_probe_valu_f64(double* out, int iter
     if (s == 12345.678) out[0] = s;
 }
 
+// GEMM-like operand pattern: every FMA reads THREE distinct 64-bit VGPR operands (acc += a[i] * b[j]), 8 x 4 tile
+__global__ __launch_bounds__(256) void mfgp_probe_valu3_f64(double* out, int iters) {
+    double acc[8][4], a[8], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = 1.0 + 1e-9 * (threadIdx.x + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = 1.0 - 1e-9 * (threadIdx.x + j);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(a[i], b[j], acc[i][j]);
+        // keep a and b in VGPRs and changing, so nothing folds to constants / SGPRs
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                          "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j];
+    if (s == 12345.678) out[0] = s;
+}
+
 // out4: {VALU-only TFLOP/s (2 waves/SIMD), VALU-only (4 waves/SIMD), mixed total TFLOP/s (2 waves/SIMD: 32 fma + 4 mfma per iter), mixed 4 waves/SIMD}
 void run_probe_valu(hipStream_t s, double* out) {
     hipEvent_t e0, e1;
@@ -229,6 +257,18 @@ void run_probe_valu(hipStream_t s, double* out) {
         double flops = waves * iters * 32.0 * 64.0 * 2.0;
         if (c >= 2) flops += waves * iters * 4.0 * 2048.0;
         out[c] = flops / (ms * 1e-3) / 1e12;
+    }
+    for (int c = 0; c < 2; ++c) {   // out[4], out[5]: the three-VGPR-operand pattern at 2 / 4 waves per SIMD
+        const int blocks = c ? 1024 : 512;
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, s);
+            hipLaunchKernelGGL(mfgp_probe_valu3_f64, dim3(blocks), dim3(256), 0, s, dummy, iters);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        out[4 + c] = blocks * 4.0 * iters * 32.0 * 64.0 * 2.0 / (ms * 1e-3) / 1e12;
     }
     hipFree(dummy);
     hipEventDestroy(e0);
