@@ -1,3 +1,3 @@
-from .gpc_abstract import AbstractGPC
+from .base import AbstractGPC
 from .legendre_gpc import LegendreGPC
 from .mfgp_gpc import MFGP_GPC

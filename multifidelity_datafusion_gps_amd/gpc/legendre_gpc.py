@@ -11,7 +11,7 @@ import itertools
 
 import numpy as np
 
-from .gpc_abstract import AbstractGPC
+from .base import AbstractGPC
 
 
 class LegendreGPC(AbstractGPC):
