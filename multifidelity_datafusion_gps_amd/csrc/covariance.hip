@@ -76,12 +76,15 @@ __device__ __forceinline__ void pair_r2(const double* sxi, const double* sxj, in
     }
 }
 
-// prod[e] *= var * shape(r2[e] / l^2) for the 16 pairs of a thread; one (wave-uniform) shape per call
+// One factor of a product term for the 16 pairs of a thread (wave-uniform shape per call).  RBF factors only add
+// to the term's exponent (expo) and variance product: a term of m RBF factors costs ONE exp per pair, not m
+// (k1*k2 = s1 s2 exp(-r1^2/2l1^2 - r2^2/2l2^2)); Matern factors multiply prod directly.
 __device__ __forceinline__ void apply_factor(int type, double var, double inv_l2, const double (&r2)[16],
-                                             double (&prod)[16]) {
+                                             double (&prod)[16], double (&expo)[16], double& varprod) {
     if (type == MFGP_KERN_RBF) {
+        varprod *= var;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) prod[e] *= var * exp_nonpos(-0.5 * r2[e] * inv_l2);
+        for (int e = 0; e < 16; ++e) expo[e] = __builtin_fma(-0.5 * inv_l2, r2[e], expo[e]);
     } else if (type == MFGP_KERN_MATERN32) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -96,6 +99,17 @@ __device__ __forceinline__ void apply_factor(int type, double var, double inv_l2
             prod[e] *= var * (1.0 + s5r + (5.0 / 3.0) * rs2) * exp_nonpos(-s5r);
         }
     }
+}
+
+// close a product term: fold the accumulated RBF exponent and variance product into prod
+__device__ __forceinline__ void finish_term(double (&prod)[16], double (&expo)[16], double& varprod, bool any_rbf) {
+    if (any_rbf) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) prod[e] *= varprod * exp_nonpos(expo[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) expo[e] = 0.0;
+    varprod = 1.0;
 }
 
 // g = (dk/dl) * l / k of one factor for the 16 pairs
@@ -123,26 +137,32 @@ __device__ __forceinline__ void factor_logderiv(int type, double inv_l2, const d
 // a few FMAs, and it keeps everything in ~100 VGPRs with no private-memory arrays)
 __device__ __forceinline__ void cov_values(const KernSpecDev& sp, const double* params, const double* sxi,
                                            const double* sxj, int ty, int tx, double (&K)[16]) {
-    double prod[16], r2[16];
+    double prod[16], r2[16], expo[16], varprod = 1.0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         K[e] = 0.0;
         prod[e] = 1.0;
+        expo[e] = 0.0;
     }
     int cur = sp.term[0];
+    bool any_rbf = false;
     for (int f = 0; f < sp.nf; ++f) {
         if (sp.term[f] != cur) {
+            finish_term(prod, expo, varprod, any_rbf);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 K[e] += prod[e];
                 prod[e] = 1.0;
             }
             cur = sp.term[f];
+            any_rbf = false;
         }
         const double var = params[2 * f], l = params[2 * f + 1];
         pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
-        apply_factor(sp.type[f], var, 1.0 / (l * l), r2, prod);
+        any_rbf = any_rbf || (sp.type[f] == MFGP_KERN_RBF);
+        apply_factor(sp.type[f], var, 1.0 / (l * l), r2, prod, expo, varprod);
     }
+    finish_term(prod, expo, varprod, any_rbf);
 #pragma unroll
     for (int e = 0; e < 16; ++e) K[e] += prod[e];
 }
@@ -302,14 +322,20 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
     while (f0 < sp.nf) {
         int f1 = f0 + 1;
         while (f1 < sp.nf && sp.term[f1] == sp.term[f0]) ++f1;
-        double prod[16], r2[16];
+        double prod[16], r2[16], expo[16], varprod = 1.0;
+        bool any_rbf = false;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) prod[e] = 1.0;
+        for (int e = 0; e < 16; ++e) {
+            prod[e] = 1.0;
+            expo[e] = 0.0;
+        }
         for (int f = f0; f < f1; ++f) {
             const double l = params[2 * f + 1];
             pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
-            apply_factor(sp.type[f], params[2 * f], 1.0 / (l * l), r2, prod);
+            any_rbf = any_rbf || (sp.type[f] == MFGP_KERN_RBF);
+            apply_factor(sp.type[f], params[2 * f], 1.0 / (l * l), r2, prod, expo, varprod);
         }
+        finish_term(prod, expo, varprod, any_rbf);
         double sv = 0.0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
