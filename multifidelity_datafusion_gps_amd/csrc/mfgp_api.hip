@@ -221,7 +221,7 @@ static void plan_potrf_rl(mfgp_handle* h) {
     //       which overlaps the next macro's chain.
     const int64_t ld = h->Np;
     const int nb = h->nblk;
-    int MB = 4;
+    int MB = 2;   // measured best for Np = 2048 .. 8192 (MFGP_MACRO overrides)
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool lookahead = true;
     if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
@@ -244,6 +244,7 @@ static void plan_potrf_rl(mfgp_handle* h) {
     };
     auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
     std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
+    int ev_rest_prev = 0;            // event after the previous macro's bulk update of the REST (bulk stream)
     for (int M0 = 0; M0 < nb; M0 += MB) {
         const int M1 = std::min(M0 + MB, nb);
         const int M2 = std::min(M1 + MB, nb);
@@ -301,6 +302,15 @@ static void plan_potrf_rl(mfgp_handle* h) {
             syrk_tasks(T, c, c + 1, M0, M1);
             add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
             Step& st = h->plan.back();
+            if (c == M1) {
+                // the column that gates the next leaf stays on the MAIN stream: no event round trip on the chain.
+                // It must still come after the previous macro's rest-update, which covers this column too and
+                // runs on the bulk stream (normally long finished: the wait is on an already signalled event).
+                st.strm = 0;
+                st.wait_ev = ev_rest_prev;
+                ev_col[c] = 0;
+                continue;
+            }
             st.strm = 1;
             if (first_bulk) st.wait_ev = ev_chain;
             first_bulk = false;
@@ -313,6 +323,11 @@ static void plan_potrf_rl(mfgp_handle* h) {
             syrk_tasks(T, M2, nb, M0, M1);
             add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
             h->plan.back().strm = 1;
+            if (first_bulk) h->plan.back().wait_ev = ev_chain;   // MB = 1: nothing else waited on the chain yet
+            ev_rest_prev = new_event(h, nev);
+            h->plan.back().rec_ev = ev_rest_prev;
+        } else {
+            ev_rest_prev = 0;
         }
     }
 }
