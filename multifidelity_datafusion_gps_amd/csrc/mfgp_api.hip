@@ -580,7 +580,7 @@ static int build_plans(mfgp_handle* h) {
 
 int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, const double* Y) {
     if (!h || !X || !Y) return fail(h, -1, "mfgp_set_data: NULL argument");
-    if (N < 1 || D < 1 || D > 64) return fail(h, -1, "mfgp_set_data: need N >= 1 and 1 <= D <= 64");
+    if (N < 1 || D < 1 || D > 32) return fail(h, -1, "mfgp_set_data: need N >= 1 and 1 <= D <= 32 (LDS staging of the covariance kernels)");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t Np = (N + NB - 1) / NB * NB;
     if (Np > h->cap || D != h->D) {
@@ -619,7 +619,7 @@ int32_t mfgp_set_kernel(mfgp_handle* h, const mfgp_kern_part* parts, int32_t n_p
     for (int f = 0; f < n_parts; ++f) {
         const mfgp_kern_part& p = parts[f];
         if (p.type < 0 || p.type > MFGP_KERN_MATERN52) return fail(h, -1, "mfgp_set_kernel: unknown kernel type");
-        if (p.col_begin < 0 || p.col_end <= p.col_begin || p.col_end > 64)
+        if (p.col_begin < 0 || p.col_end <= p.col_begin || p.col_end > 32)
             return fail(h, -1, "mfgp_set_kernel: bad column range");
         if (f > 0 && p.term < parts[f - 1].term) return fail(h, -1, "mfgp_set_kernel: term ids must be ascending");
         sp.type[f] = p.type; sp.c0[f] = p.col_begin; sp.c1[f] = p.col_end; sp.term[f] = p.term;

@@ -286,3 +286,43 @@ def test_rank1_append_equals_fresh_factorisation(engine, engine_cls):
     with pytest.raises(NotPositiveDefinite):
         engine.append_row(X[7], Y[7])
     assert engine.n == 50
+
+
+def test_repeated_evaluations_are_bitwise_identical(engine):
+    """The factorisation overlaps two streams (look-ahead); a missing cross-stream dependency would show up as
+    run-to-run differences.  Same inputs -> bitwise the same NLML and gradient, 25 times, at a size with odd block
+    counts (Np = 3072 = 24 leaf blocks) and with other GPU work interleaved."""
+    rng = np.random.default_rng(99)
+    N = 3000
+    X = rng.uniform(size=(N, 4))
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    Y = cases.hf_4d(X)
+    theta, noise = np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    engine.set_data(Xa, Y)
+    engine.set_kernel(cases.composite(4, 1))
+    f0, g0 = engine.eval(theta, noise)
+    for rep in range(25):
+        if rep % 5 == 4:
+            engine.predict(Xa[:300])            # perturbs the timing between evaluations
+        f, g = engine.eval(theta, noise)
+        assert f == f0 and np.array_equal(g, g0), rep
+
+
+def test_wide_inputs_up_to_the_column_limit(engine):
+    """D = 32 columns (the documented limit of the covariance kernels' LDS staging): composite kernel over 24 + 8."""
+    rng = np.random.default_rng(32)
+    N = 200
+    X = rng.uniform(size=(N, 32))
+    Y = np.sin(X.sum(axis=1))
+    parts = [(cases.RBF, 24, 32, 0), (cases.M52, 0, 24, 0), (cases.RBF, 0, 24, 1)]
+    theta, noise = np.array([1.1, 1.5, 0.9, 3.0, 0.5, 2.5]), 0.02
+    st = orc.inference(parts, theta, noise, X, Y)
+    Xs = rng.uniform(size=(11, 32))
+    mu, var = orc.predict(parts, theta, noise, X, st, Xs)
+    nlml, grad, mean, v = _run(engine, parts, theta, noise, X, Y, Xs)
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v, var, rtol=0, atol=1e-9)
+    with pytest.raises(RuntimeError):
+        engine.set_data(np.zeros((4, 33)), np.zeros(4))
