@@ -115,3 +115,15 @@ def direct_minimize(f_batch, lower, upper, eps=1e-4, maxf=20000, maxT=6000, algm
     ibest = int(np.argmin(fvals))
     x = lower + centers[ibest] * span
     return x, float(fvals[ibest]), dict(nf=nf, iterations=it, nrect=len(fvals))
+
+
+def gablonsky_direct(f_batch, lower, upper, eps=1e-4, maxf=20000, maxT=6000, algmethod=0):
+    """The reference's optimiser itself: Gablonsky's DIRECT / DIRECT-L as shipped in scipy.optimize.direct (the code the
+    `DIRECT` and `scipydirect` packages wrap), with the wrappers' controls (no volume / side-length stop).  Calls
+    f one point at a time, like the reference's callback.  Returns (x, fx, info) like direct_minimize."""
+    from scipy.optimize import Bounds, direct
+    lower = np.asarray(lower, dtype=np.float64).reshape(-1)
+    upper = np.asarray(upper, dtype=np.float64).reshape(-1)
+    res = direct(lambda x: float(np.asarray(f_batch(np.asarray(x)[None, :])).reshape(-1)[0]), Bounds(lower, upper),
+                 eps=eps, maxfun=int(maxf), maxiter=int(maxT), locally_biased=(algmethod == 1), vol_tol=0.0, len_tol=1e-12)
+    return np.asarray(res.x), float(res.fun), dict(nf=int(res.nfev), iterations=int(res.nit), message=str(res.message))

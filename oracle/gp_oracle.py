@@ -10,7 +10,11 @@ installable offline, and the reference's own tests hold no golden vector for K, 
 mean or variance.  This file therefore restates GPy-1.9.9's published
 algorithm **from knowledge of that version** (statements tagged [GPy-recall]) and is pinned only by
 self-consistency checks (finite-difference gradients, closed forms for N = 1, 2, invariances) in
-tests/test_oracle.py plus the golden vectors it generated itself (tests/golden/).
+tests/test_oracle.py plus the golden vectors it generated itself (tests/golden/), and cross-checked against an
+independently written exact-GP implementation available offline (scikit-learn's GaussianProcessRegressor:
+covariance, log marginal likelihood, gradient, predictive moments -- tests/test_oracle_vs_sklearn.py).  That
+check pins the MATH, not GPy's conventions (jitter constant, transforms, optimiser controls), which stay
+[GPy-recall].
 
 Reference call sites this follows (what the reference ASKS of the engine):
   * kernels: src/abstractMFGP.py:59-60 (GPy.kern.RBF(D)), :62-80 (kern1*kern2 + kern3, active_dims)
