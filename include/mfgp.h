@@ -131,6 +131,24 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new);
 int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double* mean, double* var,
                      int32_t want_var, int32_t include_noise);
 
+/* ---- device-resident level chaining ------------------------------------------------------
+ * The reference builds the high-fidelity level's inputs on the host: for every row x it calls f_low at the
+ * stencil points x + i*tau and concatenates (src/MFDataFusion.py:177-208); with a data-driven low-fidelity level
+ * each f_low call is lf_model.predict(t)[0] (src/abstractMFGP.py:104).  These two calls keep that hand-over on
+ * the device.  `lf` is the factorised low-fidelity level (d = its column count); `offsets` is the (c, d)
+ * row-major array of stencil offsets ALREADY multiplied by tau, in iteration order.
+ *
+ * mfgp_augment: out (N, d + c) = [ X | mean_lf(X + offsets[0]) ... mean_lf(X + offsets[c-1]) ]  -- the matrix
+ *   __augment_Data returns, in one call (used for the training inputs of the next level).
+ * mfgp_predict_chained: mfgp_predict of level `h` (D = d + c columns) at the augmented rows of Xstar (Nstar, d),
+ *   the low-fidelity means never leaving the device; aug_out (Nstar, d + c) optionally receives the augmented
+ *   rows.  Same numbers as mfgp_predict(lf) + host concatenation + mfgp_predict(h).
+ * Both handles must live on the same device and must not be used by another thread during the call. */
+int32_t mfgp_augment(mfgp_handle* lf, const double* X, int64_t N, const double* offsets, int32_t c, double* out);
+int32_t mfgp_predict_chained(mfgp_handle* h, mfgp_handle* lf, const double* Xstar, int64_t Nstar,
+                             const double* offsets, int32_t c, double* mean, double* var, int32_t want_var,
+                             int32_t include_noise, double* aug_out);
+
 /* ---- parity / debug read-back (host buffers sized N*N, N) ---------------------------------------- */
 int32_t mfgp_get_K(mfgp_handle* h, double* out);      /* K(X,X) WITHOUT noise, full symmetric (rebuilt)  */
 int32_t mfgp_get_L(mfgp_handle* h, double* out);      /* lower Cholesky factor of Ky, zeros above diag   */

@@ -18,14 +18,17 @@ class MultifidelityDataFusion(AbstractMFGP):
     Parameters are those of the reference class (src/MFDataFusion.py:56-59).  Additions, all optional:
     `seed` (seeded restart draws instead of the global numpy RNG), `comm` (a sharding.Comm: restarts and
     predictive panels are split over the ranks), `engines` (reuse engine handles), `batched_augmentation` (one f_low call on the whole
-    (N*c, d) stencil stack instead of N calls -- identical numbers for row-wise f_low).
+    (N*c, d) stencil stack instead of N calls -- identical numbers for row-wise f_low), `device_chaining` (with a
+    data-driven low-fidelity level the stencil means are handed to the next level on the device).
     """
 
     def __init__(self, name: str, input_dim: int, num_derivatives: int, tau: float, f_exact: callable,
                  lower_bound: np.ndarray = None, upper_bound: np.ndarray = None, f_low: callable = None,
                  lf_X: np.ndarray = None, lf_Y: np.ndarray = None, lf_hf_adapt_ratio: int = 1,
                  use_composite_kernel: bool = True, adapt_maximizer: AbstractMaximizer = None, eps: float = 1e-8,
-                 add_noise: bool = False, seed=None, comm=None, batched_augmentation: bool = True, engines=None):
+                 add_noise: bool = False, seed=None, comm=None, batched_augmentation: bool = True, engines=None,
+                 device_chaining: bool = True):
+        self.device_chaining = device_chaining   # before super().__init__: the LF level is built there
         if adapt_maximizer is None:  # a fresh instance per model (the reference shares one def-time instance)
             adapt_maximizer = ScipyDirectMaximizer()
         super().__init__(name=name, input_dim=input_dim, num_derivatives=num_derivatives,
@@ -100,10 +103,23 @@ class MultifidelityDataFusion(AbstractMFGP):
         if size > 1 and len(X_test) >= 4 * size:
             # predictive panels shard by rows of X*: every rank holds the replicated level state
             b, e = split_rows(len(X_test), self.comm.rank, size)
-            m, v = self.hf_model.predict(self._augment_data(X_test[b:e]))
+            m, v = self._predict_rows(X_test[b:e])
             mv = self.comm.allgather_rows(np.hstack([m, v]))
             return mv[:, :1].copy(), mv[:, 1:].copy()
-        return self.hf_model.predict(self._augment_data(X_test))
+        return self._predict_rows(X_test)
+
+    def _chained(self):
+        """device-resident level chaining applies when the low-fidelity level is a GP of this package on the same
+        device as the high-fidelity level"""
+        return (self.device_chaining and self.data_driven_lf_approach and self.batched_augmentation
+                and getattr(self.lf_model, "_engine", None) is not None and hasattr(self.lf_model._engine, "augment"))
+
+    def _predict_rows(self, X):
+        if self._chained() and hasattr(self.hf_model._engine, "predict_chained") \
+                and self.hf_model._engine.device == self.lf_model._engine.device:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            return self.hf_model.predict_chained(self.lf_model, X, self.augm_iterator.offsets() * self.tau)
+        return self.hf_model.predict(self._augment_data(X))
 
     def get_mse(self, X_test, Y_test):
         assert len(X_test) == len(Y_test), 'unequal number of X and y values'
@@ -118,6 +134,8 @@ class MultifidelityDataFusion(AbstractMFGP):
         assert X.shape == (len(X), self.input_dim)
         offs = self.augm_iterator.offsets()                       # (c, d)
         c = self.augm_iterator.new_entries_count()
+        if self._chained():   # one device call: stencil, low-fidelity means and the concatenation
+            return self.lf_model.augment(np.ascontiguousarray(X, dtype=np.float64), offs * self.tau)
         locs = X[:, None, :] + offs[None, :, :] * self.tau        # (N, c, d)
         if self.batched_augmentation:
             vals = np.asarray(self.f_low(locs.reshape(-1, self.input_dim))).reshape(len(X), c)

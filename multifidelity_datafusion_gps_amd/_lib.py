@@ -19,6 +19,7 @@ MAX_PARTS = 6
 EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
     "mfgp_set_kernel", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
+    "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters",
     "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_probe", "mfgp_dbg_probe_detail",
@@ -96,6 +97,8 @@ def load_library(path=None):
         "mfgp_nlml_grad": (i32, [H, dp]),
         "mfgp_append_row": (i32, [H, dp, f64]),
         "mfgp_predict": (i32, [H, dp, i64, dp, dp, i32, i32]),
+        "mfgp_augment": (i32, [H, dp, i64, dp, i32, dp]),
+        "mfgp_predict_chained": (i32, [H, H, dp, i64, dp, i32, dp, dp, i32, i32, dp]),
         "mfgp_get_K": (i32, [H, dp]),
         "mfgp_get_L": (i32, [H, dp]),
         "mfgp_get_Linv": (i32, [H, dp]),
@@ -250,6 +253,32 @@ class Engine:
                                     _dptr(var) if want_var else None, int(bool(want_var)), int(bool(include_noise)))
         self._check(rc, "mfgp_predict")
         return mean, var
+
+    # -- device-resident level chaining ------------------------------------------
+    def augment(self, X, offsets):
+        """this (low-fidelity) level's posterior mean on the stencil X + offsets[j] -> [X | means] (N, d + c)"""
+        Xc, offs = _c64(X), _c64(offsets)
+        if Xc.ndim != 2 or Xc.shape[1] != self.d or offs.ndim != 2 or offs.shape[1] != self.d:
+            raise ValueError("X must be (N, %d) and offsets (c, %d)" % (self.d, self.d))
+        out = np.empty((Xc.shape[0], self.d + offs.shape[0]))
+        self._check(self._lib.mfgp_augment(self._h, _dptr(Xc), Xc.shape[0], _dptr(offs), offs.shape[0], _dptr(out)),
+                    "mfgp_augment")
+        return out
+
+    def predict_chained(self, lf, Xstar, offsets, want_var=True, include_noise=True, want_aug=False):
+        """predict of this level at [X* | lf means on the stencil]; the means stay on the device"""
+        Xs, offs = _c64(Xstar), _c64(offsets)
+        c = offs.shape[0] if offs.ndim == 2 else -1
+        if Xs.ndim != 2 or offs.ndim != 2 or Xs.shape[1] != lf.d or offs.shape[1] != lf.d or self.d != lf.d + c:
+            raise ValueError("Xstar must be (N*, d_lf), offsets (c, d_lf) and this level must have d_lf + c columns")
+        mean = np.empty(Xs.shape[0])
+        var = np.empty(Xs.shape[0]) if want_var else None
+        aug = np.empty((Xs.shape[0], self.d)) if want_aug else None
+        rc = self._lib.mfgp_predict_chained(self._h, lf._h, _dptr(Xs), Xs.shape[0], _dptr(offs), c, _dptr(mean),
+                                            _dptr(var) if want_var else None, int(bool(want_var)),
+                                            int(bool(include_noise)), _dptr(aug) if want_aug else None)
+        self._check(rc, "mfgp_predict_chained")
+        return (mean, var, aug) if want_aug else (mean, var)
 
     # -- read-back ------------------------------------------------------------------------------
     def _get_mat(self, fn, who):

@@ -52,6 +52,9 @@ struct mfgp_handle {
     GemmTask* dtasks = nullptr;
     size_t tasks_cap = 0;
     int xs_cap_rows = 0, xs_cap_D = 0;
+    double *dXc = nullptr, *dm = nullptr, *doffs = nullptr, *dAug = nullptr;  // level chaining scratch
+    int64_t ch_rows = 0;
+    int ch_c = 0;
     double* hres = nullptr;  // pinned
     int* hinfo = nullptr;    // pinned
     std::vector<GemmTask> tasks;
@@ -552,6 +555,10 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     hipStreamSynchronize(h->stream);
     free_mats(h);
     if (h->dXs) hipFree(h->dXs);
+    if (h->dXc) hipFree(h->dXc);
+    if (h->dm) hipFree(h->dm);
+    if (h->doffs) hipFree(h->doffs);
+    if (h->dAug) hipFree(h->dAug);
     if (h->dtasks) hipFree(h->dtasks);
     hipFree(h->dparams); hipFree(h->dres); hipFree(h->dinfo);
     hipHostFree(h->hres); hipHostFree(h->hinfo);
@@ -901,6 +908,70 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
     return 0;
 }
 
+// make room for a predictive panel of rows_p rows in h->dXs
+static int ensure_xs(mfgp_handle* h, int rows_p) {
+    const int D = h->D;
+    if (rows_p > h->xs_cap_rows || D != h->xs_cap_D) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->dXs) HIPCHK(h, hipFree(h->dXs));
+        h->dXs = nullptr;
+        h->xs_cap_rows = std::max(rows_p, h->xs_cap_rows);
+        h->xs_cap_D = D;
+        HIPCHK(h, hipMalloc(&h->dXs, (size_t)h->xs_cap_rows * D * sizeof(double)));
+    }
+    return 0;
+}
+
+// mean (and variance) of the `rows` test rows already resident (zero padded to rows_p) in h->dXs, in stream order
+static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean, double* var, int want_var,
+                         int include_noise, double* pan_ms, double* var_ms) {
+    hipStream_t s = h->stream;
+    const int64_t Np = h->Np;
+    int rc;
+    // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound skinny product instead of a padded tile GEMM
+    static const bool skinny_on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
+    const bool skinny = want_var && skinny_on && rows <= 64;
+    const int rows16 = rows <= 16 ? 1 : (rows <= 32 ? 2 : 4);
+    if (want_var && !skinny && h->predv_rows != rows_p) {
+        // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
+        h->tasks.resize((size_t)h->kinv_step.first + h->kinv_step.count);
+        plan_predv(h, rows_p);
+        rc = upload_tasks(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[6], s));
+    launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, h->dparams, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
+    launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, h->dvec, rows_p, (int)Np, 2);
+    h->launches += 2;
+    HIPCHK(h, hipEventRecord(h->ev[7], s));
+    HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (want_var) {
+        h->kinv_valid = false;  // V overwrites the K^-1 storage
+        const int vrows = skinny ? 16 * rows16 : rows_p;
+        if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
+        else run_step(h, h->predv_step);
+        launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
+        launch_finish_var(s, h->spec, h->dparams, h->dvec2, h->dvec2, vrows, include_noise ? h->noise : 0.0);
+        h->launches += 2;
+        HIPCHK(h, hipEventRecord(h->ev[8], s));
+        HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    *pan_ms += ev_ms(h->ev[6], h->ev[7]);
+    if (want_var) *var_ms += ev_ms(h->ev[7], h->ev[8]);
+    return 0;
+}
+
+static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double var_ms) {
+    h->tm.predict_panel_ms = pan_ms;
+    h->tm.predict_var_ms = var_ms;
+    h->cum.predicts += 1;
+    h->cum.predict_rows += (double)Nstar;
+    h->cum.predict_ms += pan_ms + var_ms;
+    h->tm.n_launches = h->launches;
+}
+
 int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double* mean, double* var,
                      int32_t want_var, int32_t include_noise) {
     int rc = check_ready(h, "mfgp_predict");
@@ -917,48 +988,135 @@ int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double*
     for (int64_t r0 = 0; r0 < Nstar; r0 += Np) {
         const int64_t rows = std::min(Np, Nstar - r0);
         const int rows_p = (int)((rows + NB - 1) / NB * NB);
-        if (rows_p > h->xs_cap_rows || D != h->xs_cap_D) {
-            HIPCHK(h, hipStreamSynchronize(s));
-            if (h->dXs) HIPCHK(h, hipFree(h->dXs));
-            h->xs_cap_rows = std::max(rows_p, h->xs_cap_rows);
-            h->xs_cap_D = D;
-            HIPCHK(h, hipMalloc(&h->dXs, (size_t)h->xs_cap_rows * D * sizeof(double)));
-        }
+        rc = ensure_xs(h, rows_p);
+        if (rc) return rc;
         HIPCHK(h, hipMemsetAsync(h->dXs, 0, (size_t)rows_p * D * sizeof(double), s));
         HIPCHK(h, hipMemcpyAsync(h->dXs, Xstar + r0 * D, (size_t)rows * D * sizeof(double), hipMemcpyHostToDevice, s));
-        if (want_var && h->predv_rows != rows_p) {
-            // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
-            h->tasks.resize((size_t)h->kinv_step.first + h->kinv_step.count);
-            plan_predv(h, rows_p);
-            rc = upload_tasks(h);
-            if (rc) return rc;
-        }
-        HIPCHK(h, hipEventRecord(h->ev[6], s));
-        launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, h->dparams, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
-        launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, h->dvec, rows_p, (int)Np, 2);
-        h->launches += 2;
-        HIPCHK(h, hipEventRecord(h->ev[7], s));
-        HIPCHK(h, hipMemcpyAsync(mean + r0, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (want_var) {
-            h->kinv_valid = false;  // V overwrites the K^-1 storage
-            run_step(h, h->predv_step);
-            launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, rows_p, (int)Np);
-            launch_finish_var(s, h->spec, h->dparams, h->dvec2, h->dvec2, rows_p, include_noise ? h->noise : 0.0);
-            h->launches += 2;
-            HIPCHK(h, hipEventRecord(h->ev[8], s));
-            HIPCHK(h, hipMemcpyAsync(var + r0, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
-        }
-        HIPCHK(h, hipStreamSynchronize(s));
-        HIPCHK(h, hipGetLastError());
-        pan_ms += ev_ms(h->ev[6], h->ev[7]);
-        if (want_var) var_ms += ev_ms(h->ev[7], h->ev[8]);
+        rc = predict_chunk(h, rows, rows_p, mean + r0, want_var ? var + r0 : nullptr, want_var, include_noise, &pan_ms,
+                           &var_ms);
+        if (rc) return rc;
     }
-    h->tm.predict_panel_ms = pan_ms;
-    h->tm.predict_var_ms = var_ms;
-    h->cum.predicts += 1;
-    h->cum.predict_rows += (double)Nstar;
-    h->cum.predict_ms += pan_ms + var_ms;
-    h->tm.n_launches = h->launches;
+    predict_account(h, Nstar, pan_ms, var_ms);
+    return 0;
+}
+
+// ---- device-resident level chaining ------------------------------------------------------
+static int ensure_chain(mfgp_handle* lf, int64_t rows, int c) {
+    const int d = lf->D;
+    if (rows > lf->ch_rows || c > lf->ch_c) {
+        HIPCHK(lf, hipStreamSynchronize(lf->stream));
+        if (lf->dXc) HIPCHK(lf, hipFree(lf->dXc));
+        if (lf->dm) HIPCHK(lf, hipFree(lf->dm));
+        if (lf->doffs) HIPCHK(lf, hipFree(lf->doffs));
+        if (lf->dAug) HIPCHK(lf, hipFree(lf->dAug));
+        lf->dXc = lf->dm = lf->doffs = lf->dAug = nullptr;
+        lf->ch_rows = std::max(rows, lf->ch_rows);
+        lf->ch_c = std::max(c, lf->ch_c);
+        HIPCHK(lf, hipMalloc(&lf->dXc, (size_t)lf->ch_rows * d * sizeof(double)));
+        HIPCHK(lf, hipMalloc(&lf->dm, (size_t)lf->ch_rows * lf->ch_c * sizeof(double)));
+        HIPCHK(lf, hipMalloc(&lf->doffs, (size_t)lf->ch_c * d * sizeof(double)));
+        HIPCHK(lf, hipMalloc(&lf->dAug, (size_t)lf->ch_rows * (d + lf->ch_c) * sizeof(double)));
+    }
+    return 0;
+}
+
+// On lf->stream: upload `rows` base points, push the (rows*c, d) stencil stack through the low-fidelity posterior
+// mean.  Leaves the base points in lf->dXc and the means, (rows, c) row-major, in lf->dm.  No host synchronisation.
+static int chain_lf_means(mfgp_handle* lf, const double* Xhost, int64_t rows, const double* offs_host, int c) {
+    hipStream_t s = lf->stream;
+    const int d = lf->D;
+    const int64_t Np = lf->Np;
+    int rc = ensure_chain(lf, rows, c);
+    if (rc) return rc;
+    const int64_t T = rows * c;
+    rc = ensure_xs(lf, (int)std::min<int64_t>(Np, (T + NB - 1) / NB * NB));
+    if (rc) return rc;
+    HIPCHK(lf, hipMemcpyAsync(lf->doffs, offs_host, (size_t)c * d * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(lf, hipMemcpyAsync(lf->dXc, Xhost, (size_t)rows * d * sizeof(double), hipMemcpyHostToDevice, s));
+    for (int64_t t0 = 0; t0 < T; t0 += Np) {
+        const int n = (int)std::min(Np, T - t0);
+        const int n_p = (n + NB - 1) / NB * NB;
+        launch_stencil_rows(s, lf->dXc, lf->doffs, d, c, t0, n, n_p, lf->dXs);
+        launch_kbuild_panel(s, lf->spec, lf->dXs, n_p, lf->dX, lf->dparams, (int)lf->N, (int)Np, lf->buf[BUF_W], (int)Np);
+        // the padded rows n..n_p of the mean land in dvec's tail, never in dm: write through dvec, then copy
+        launch_rowdot(s, lf->buf[BUF_W], (int)Np, lf->dalpha, lf->dvec, n_p, (int)Np, 2);
+        HIPCHK(lf, hipMemcpyAsync(lf->dm + t0, lf->dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        lf->launches += 3;
+    }
+    return 0;
+}
+
+static int chain_check(mfgp_handle* lf, const double* X, int64_t N, const double* offs, int c, const char* who) {
+    int rc = check_ready(lf, who);
+    if (rc) return rc;
+    if (!X || !offs) return fail(lf, -1, std::string(who) + ": NULL argument");
+    if (N < 1 || c < 1) return fail(lf, -1, std::string(who) + ": need N >= 1 and c >= 1");
+    if (!lf->factorized) return fail(lf, -1, std::string(who) + ": the low-fidelity level has no valid factorisation");
+    return 0;
+}
+
+int32_t mfgp_augment(mfgp_handle* lf, const double* X, int64_t N, const double* offsets, int32_t c, double* out) {
+    int rc = chain_check(lf, X, N, offsets, c, "mfgp_augment");
+    if (rc) return rc;
+    if (!out) return fail(lf, -1, "mfgp_augment: NULL argument");
+    HIPCHK(lf, hipSetDevice(lf->device));
+    const int d = lf->D, w = d + c;
+    const int64_t chunk = lf->Np;
+    lf->launches = 0;
+    for (int64_t r0 = 0; r0 < N; r0 += chunk) {
+        const int64_t rows = std::min(chunk, N - r0);
+        rc = chain_lf_means(lf, X + r0 * d, rows, offsets, c);
+        if (rc) return rc;
+        launch_assemble_aug(lf->stream, lf->dXc, lf->dm, (int)rows, (int)rows, d, c, lf->dAug, w);
+        HIPCHK(lf, hipMemcpyAsync(out + r0 * w, lf->dAug, (size_t)rows * w * sizeof(double), hipMemcpyDeviceToHost,
+                                  lf->stream));
+        HIPCHK(lf, hipStreamSynchronize(lf->stream));
+        HIPCHK(lf, hipGetLastError());
+    }
+    return 0;
+}
+
+int32_t mfgp_predict_chained(mfgp_handle* h, mfgp_handle* lf, const double* Xstar, int64_t Nstar, const double* offsets,
+                             int32_t c, double* mean, double* var, int32_t want_var, int32_t include_noise,
+                             double* aug_out) {
+    int rc = check_ready(h, "mfgp_predict_chained");
+    if (rc) return rc;
+    if (!lf) return fail(h, -1, "mfgp_predict_chained: NULL low-fidelity handle");
+    if (lf == h) return fail(h, -1, "mfgp_predict_chained: the two levels must be distinct handles");
+    rc = chain_check(lf, Xstar, Nstar, offsets, c, "mfgp_predict_chained");
+    if (rc) return fail(h, rc, std::string("mfgp_predict_chained: low-fidelity level: ") + lf->err);
+    if (!mean || (want_var && !var)) return fail(h, -1, "mfgp_predict_chained: NULL argument");
+    if (!h->factorized) return fail(h, -1, "mfgp_predict_chained: no valid factorisation (call mfgp_factorize / mfgp_eval)");
+    if (h->device != lf->device) return fail(h, -1, "mfgp_predict_chained: the two levels live on different devices");
+    if (h->D != lf->D + c) return fail(h, -1, "mfgp_predict_chained: this level has D != d_lf + c columns");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int d = lf->D, D = h->D;
+    const int64_t Np = h->Np;
+    double pan_ms = 0, var_ms = 0;
+    h->launches = 0;
+    lf->launches = 0;
+    for (int64_t r0 = 0; r0 < Nstar; r0 += Np) {
+        const int64_t rows = std::min(Np, Nstar - r0);
+        const int rows_p = (int)((rows + NB - 1) / NB * NB);
+        rc = ensure_xs(h, rows_p);
+        if (rc) return rc;
+        rc = chain_lf_means(lf, Xstar + r0 * d, rows, offsets, c);
+        if (rc) return fail(h, rc, std::string("mfgp_predict_chained: low-fidelity level: ") + lf->err);
+        // the augmented rows go straight into this level's panel input; this level's stream waits for them
+        launch_assemble_aug(lf->stream, lf->dXc, lf->dm, (int)rows, rows_p, d, c, h->dXs, D);
+        if (aug_out)
+            HIPCHK(h, hipMemcpyAsync(aug_out + r0 * D, h->dXs, (size_t)rows * D * sizeof(double), hipMemcpyDeviceToHost,
+                                     lf->stream));
+        HIPCHK(h, hipEventRecord(lf->ev[9], lf->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, lf->ev[9], 0));
+        h->launches += lf->launches + 1;
+        lf->launches = 0;
+        rc = predict_chunk(h, rows, rows_p, mean + r0, want_var ? var + r0 : nullptr, want_var, include_noise, &pan_ms,
+                           &var_ms);
+        if (rc) return rc;
+        if (aug_out) HIPCHK(h, hipStreamSynchronize(lf->stream));
+    }
+    predict_account(h, Nstar, pan_ms, var_ms);
     return 0;
 }
 

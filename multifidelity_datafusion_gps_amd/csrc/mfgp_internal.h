@@ -64,6 +64,8 @@ constexpr int MFGP_MAX_GROUPS = 3;
 void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
                  const double* B, double* C, double* C2, int ld, int role = 0);
 size_t gemm_lds_bytes(int tile);
+// skinny variance product for <= 64 test rows: V[0 .. 16*rows16) = W X^T (X = L^-1 from the mirrored S); rows16 in {1, 2, 4}
+void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const double* S, double* V, int ld, int Np);
 
 // leaf: Cholesky + inverse of the 128x128 diagonal block `blk` of A (ld), in LDS.
 //   L block (zeros above diag) -> Lout[blk,blk];  X = L^-1 -> S[blk,blk] stored mirrored (X + X^T - diag)
@@ -104,6 +106,12 @@ int grad_num_partials(int Np);
 //   var[i] = max(kss - ss[i], 1e-15) + add ; kss from params
 void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* params, const double* ss,
                        double* var, int n, double add);
+
+// level chaining: stencil stack rows and the augmented-row assembly (vecops.hip)
+void launch_stencil_rows(hipStream_t s, const double* Xc, const double* offs, int d, int c, int64_t t0, int n, int n_p,
+                         double* T);
+void launch_assemble_aug(hipStream_t s, const double* Xc, const double* m, int rows, int rows_p, int d, int c,
+                         double* out, int ld);
 
 // probes
 void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs);

@@ -132,6 +132,47 @@ void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* l
     hipLaunchKernelGGL(mfgp_finish_solve_f64, dim3(1), dim3(256), 0, s, z, Np, logdet_part, nblk, scalars);
 }
 
+// ---- device-resident level chaining -------------------------------------------------
+// stencil rows t0 .. t0+n of the (rows*c, d) stack  T[i*c + j] = Xc[i] + offs[j]  (src/MFDataFusion.py:190-197:
+// the low-fidelity level is evaluated at x + i*tau for every stencil offset i); rows n .. n_p are zero padding.
+__global__ __launch_bounds__(256) void mfgp_stencil_rows_f64(const double* __restrict__ Xc, const double* __restrict__ offs,
+                                                             int d, int c, int64_t t0, int n, int n_p,
+                                                             double* __restrict__ T) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n_p * d) return;
+    const int r = (int)(e / d), k = (int)(e % d);
+    double v = 0.0;
+    if (r < n) {
+        const int64_t t = t0 + r;
+        v = Xc[(t / c) * d + k] + offs[(t % c) * d + k];
+    }
+    T[e] = v;
+}
+// out[i] = [ Xc[i, 0:d] | m[i*c .. i*c + c) ] for i < rows, zeros for rows <= i < rows_p   (ld >= d + c)
+__global__ __launch_bounds__(256) void mfgp_assemble_aug_f64(const double* __restrict__ Xc, const double* __restrict__ m,
+                                                             int rows, int rows_p, int d, int c,
+                                                             double* __restrict__ out, int ld) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int w = d + c;
+    if (e >= (int64_t)rows_p * w) return;
+    const int i = (int)(e / w), k = (int)(e % w);
+    double v = 0.0;
+    if (i < rows) v = (k < d) ? Xc[(int64_t)i * d + k] : m[(int64_t)i * c + (k - d)];
+    out[(int64_t)i * ld + k] = v;
+}
+void launch_stencil_rows(hipStream_t s, const double* Xc, const double* offs, int d, int c, int64_t t0, int n, int n_p,
+                         double* T) {
+    const int64_t tot = (int64_t)n_p * d;
+    hipLaunchKernelGGL(mfgp_stencil_rows_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, offs, d, c, t0, n,
+                       n_p, T);
+}
+void launch_assemble_aug(hipStream_t s, const double* Xc, const double* m, int rows, int rows_p, int d, int c,
+                         double* out, int ld) {
+    const int64_t tot = (int64_t)rows_p * (d + c);
+    hipLaunchKernelGGL(mfgp_assemble_aug_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, m, rows, rows_p, d,
+                       c, out, ld);
+}
+
 // ---- probes ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfgp_probe_mfma_f64(double* out, int iters) {
     d4_t acc[8];

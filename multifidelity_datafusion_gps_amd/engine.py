@@ -656,6 +656,21 @@ class GPRegression:
         mean, _ = self._engine.predict(Xnew, want_var=False)
         return mean[:, None]
 
+    def augment(self, X, offsets):
+        """[X | posterior mean of THIS level at X + offsets[j]]: the next level's inputs in one device call
+        (src/MFDataFusion.py:177-208 with f_low = lambda t: lf_model.predict(t)[0], src/abstractMFGP.py:104)."""
+        self._ensure(False)
+        return self._engine.augment(X, offsets)
+
+    def predict_chained(self, lf_model, Xnew, offsets, include_likelihood=True):
+        """predict() of this level at the rows augmented by lf_model's posterior mean, the hand-over kept on the device
+         -> (mean (N*,1), variance (N*,1)); same numbers as predict(lf_model.augment(Xnew, offsets))."""
+        lf_model._ensure(False)
+        self._ensure(False)
+        mean, var = self._engine.predict_chained(lf_model._engine, Xnew, offsets, want_var=True,
+                                                 include_noise=include_likelihood)
+        return mean[:, None], var[:, None]
+
     def timings(self):
         return self._engine.timings()
 

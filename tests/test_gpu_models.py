@@ -204,3 +204,24 @@ def test_mfgp_gpc_driver_with_legendre_pce():
     assert abs(drv.mean_history[-1] - m_exact) < 0.05
     assert drv.mse_history[-1] < drv.mse_history[0] + 1e-12
     model.close()
+
+
+def test_device_chaining_gives_the_host_route_numbers():
+    """device_chaining (default) hands the low-fidelity stencil means to the high-fidelity level on the device;
+    the fitted model and its predictions equal the host route's (device_chaining=False) bit for bit."""
+    import multifidelity_datafusion_gps_amd as mf
+    rng = np.random.default_rng(14)
+    X_lf = rng.uniform(size=(90, 2))
+    X_hf = rng.uniform(size=(24, 2))
+    Xt = rng.uniform(size=(150, 2))
+    out = []
+    for chained in (True, False):
+        model = mf.GPDFC(2, 0.001, 2, hf2, None, lf_X=X_lf, lf_Y=lf2(X_lf), seed=6, device_chaining=chained)
+        model.first_run_max_iters, model.restart_max_iters = 30, 30
+        model.fit(X_hf)
+        assert model._chained() == chained
+        mean, var = model.predict(Xt)
+        out.append((model.hf_model.X.copy(), mean, var))
+        model.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)

@@ -326,3 +326,90 @@ def test_wide_inputs_up_to_the_column_limit(engine):
     np.testing.assert_allclose(v, var, rtol=0, atol=1e-9)
     with pytest.raises(RuntimeError):
         engine.set_data(np.zeros((4, 33)), np.zeros(4))
+
+
+@pytest.mark.parametrize("n_lf,n_hf,n_star,nder", [(100, 40, 300, 2), (260, 150, 37, 1), (50, 10, 1, 0)])
+def test_device_resident_level_chaining_equals_host_hand_over(engine, engine_cls, n_lf, n_hf, n_star, nder):
+    """mfgp_augment / mfgp_predict_chained keep the low-fidelity stencil means on the device.
+    Bitwise the numbers of the host route (lf predict -> concatenate -> hf predict, src/MFDataFusion.py:177-208),
+    and the oracle's within the stated tolerances.  Sizes exercise ragged panels on both levels and stencil stacks
+    longer than the low-fidelity panel height."""
+    d, tau = 2, 1e-3
+    rng = np.random.default_rng(n_lf + n_hf)
+    offs = [np.zeros(d)]
+    for step in range(1, nder + 1):
+        for j in range(d):
+            v = np.zeros(d); v[j] = -step
+            offs.append(v)
+    offs = np.array(offs) * tau
+    c = len(offs)
+    X_lf = rng.uniform(size=(n_lf, d)); Y_lf = cases.lf_2d(X_lf)
+    lf = engine
+    lf.set_data(X_lf, Y_lf)
+    lf.set_kernel(cases.single(cases.RBF, d))
+    th_lf, nz_lf = np.array([1.1, 0.4]), 1e-3
+    lf.factorize(th_lf, nz_lf)
+    X_hf = rng.uniform(size=(n_hf, d))
+    # host route: stacked stencil -> lf mean -> concatenate
+    stack = (X_hf[:, None, :] + offs[None, :, :]).reshape(-1, d)
+    host_aug = np.hstack([X_hf, lf.predict(stack, want_var=False)[0].reshape(n_hf, c)])
+    dev_aug = lf.augment(X_hf, offs)
+    assert np.array_equal(dev_aug, host_aug)
+    st_lf = orc.inference(cases.single(cases.RBF, d), th_lf, nz_lf, X_lf, Y_lf)
+    mu_o, _ = orc.predict(cases.single(cases.RBF, d), th_lf, nz_lf, X_lf, st_lf, stack)
+    np.testing.assert_allclose(dev_aug[:, d:].reshape(-1), mu_o, rtol=0, atol=1e-9)
+
+    hf = engine_cls()
+    parts = cases.composite(d, c)
+    th_hf, nz_hf = np.array([1.0, 2.0, 1.0, 0.7, 0.5, 0.9]), 1e-3
+    hf.set_data(dev_aug, cases.hf_2d(X_hf))
+    hf.set_kernel(parts)
+    hf.factorize(th_hf, nz_hf)
+    Xs = rng.uniform(size=(n_star, d))
+    stack_s = (Xs[:, None, :] + offs[None, :, :]).reshape(-1, d)
+    aug_s = np.hstack([Xs, lf.predict(stack_s, want_var=False)[0].reshape(n_star, c)])
+    m_host, v_host = hf.predict(aug_s)
+    m_dev, v_dev, aug_dev = hf.predict_chained(lf, Xs, offs, want_aug=True)
+    assert np.array_equal(aug_dev, aug_s)
+    assert np.array_equal(m_dev, m_host) and np.array_equal(v_dev, v_host)
+    m2, none = hf.predict_chained(lf, Xs, offs, want_var=False)
+    assert none is None and np.array_equal(m2, m_host)
+    # argument errors are reported, not executed
+    with pytest.raises((RuntimeError, ValueError)):
+        hf.predict_chained(hf, Xs, offs)
+    with pytest.raises((RuntimeError, ValueError)):
+        hf.predict_chained(lf, Xs, offs[:-1] if c > 1 else np.vstack([offs, offs]))
+    fresh = engine_cls()
+    fresh.set_data(X_lf, Y_lf); fresh.set_kernel(cases.single(cases.RBF, d))
+    with pytest.raises(RuntimeError):
+        fresh.augment(X_hf, offs)          # no factorisation yet
+    fresh.close()
+    hf.close()
+
+
+@pytest.mark.parametrize("N", [97, 700, 2100])
+def test_skinny_variance_path_for_small_batches(engine, N):
+    """N* <= 64 (the DIRECT callback / acquisition case) takes the bandwidth-bound skinny product
+    instead of the padded tile GEMM: oracle tolerance, and agreement with the tile-GEMM path on the same rows."""
+    rng = np.random.default_rng(N)
+    X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01
+    engine.set_data(Xa, Y); engine.set_kernel(parts)
+    engine.factorize(theta, noise)
+    st = orc.inference(parts, theta, noise, Xa, Y, want_grad=False)
+    Xs_all = rng.uniform(size=(80, 5))
+    m_big, v_big = engine.predict(Xs_all)                 # 80 rows: tile-GEMM path
+    for ns in (1, 2, 16, 17, 32, 33, 64):
+        m, v = engine.predict(Xs_all[:ns])
+        mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xs_all[:ns])
+        np.testing.assert_allclose(m, mu, rtol=0, atol=1e-9 * max(1.0, np.abs(Y).max()))
+        np.testing.assert_allclose(v, var, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(v, v_big[:ns], rtol=0, atol=1e-12)
+        assert np.array_equal(m, m_big[:ns])
+        m2, v2 = engine.predict(Xs_all[:ns])
+        assert np.array_equal(v, v2)                          # deterministic
+    # the gradient after a skinny predict is still right (V overwrote the K^-1 storage -> recomputed lazily)
+    nlml, grad = engine.eval(theta, noise, 1e-8, want_grad=True)
+    fo, go = st["nlml"], None
+    assert nlml == pytest.approx(fo, rel=1e-10)

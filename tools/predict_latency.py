@@ -1,3 +1,5 @@
+"""Latency of one predict call (mean + variance) against the number of test rows; MFGP_SKINNY=0 disables the skinny
+variance product for N* <= 64 (then every batch is padded to a 128-row tile GEMM)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +12,7 @@ for N in (512, 2048, 8192):
     Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
     e.set_data(Xa, Y); e.set_kernel(cases.composite(4, 1))
     e.factorize(np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01)
-    for ns in (1, 16, 128, 1000):
+    for ns in (1, 16, 32, 64, 65, 128, 1000):
         Xs = Xa[:ns] + 0.01
         e.predict(Xs)
         t0 = time.perf_counter()
@@ -18,4 +20,4 @@ for N in (512, 2048, 8192):
             e.predict(Xs)
         dt = (time.perf_counter() - t0) / 20
         t = e.timings()
-        print("N=%5d N*=%5d  %.3f ms per predict call (panel %.3f var %.3f)" % (N, ns, dt * 1e3, t["predict_panel_ms"], t["predict_var_ms"]))
+        print("N=%5d N*=%5d  %.3f ms per predict call (panel %.3f var %.3f)" % (N, ns, dt * 1e3, t["predict_panel_ms"], t["predict_var_ms"]), flush=True)
