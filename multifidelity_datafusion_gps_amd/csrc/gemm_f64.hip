@@ -17,19 +17,21 @@
 
 namespace mfgp {
 
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks, const double* A, const double* B,
-                                             double* C, double* C2, int ld) {
+template <int BM, int BN, int WM, int WN, int NBUF = 2, int KT = BK>
+__device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, const double* B, double* C, double* C2,
+                                             int ld) {
     constexpr int NT = 64 * WM * WN;      // threads per workgroup (wave grid WM x WN)
     constexpr int TM = BM / (16 * WM);    // 16-row MFMA blocks per wave along M
     constexpr int TN = BN / (16 * WN);
-    constexpr int NA = BM * 16 / NT;      // 16-byte chunks per thread per K-step
-    constexpr int NBC = BN * 16 / NT;
+    constexpr int CPR = KT / 2;           // 16-byte chunks per tile row and K-step (KT = K-step depth: 32, or 16 for the slim variant)
+    constexpr int NA = BM * CPR / NT;     // chunks per thread per K-step
+    constexpr int NBC = BN * CPR / NT;
+    constexpr int SWM = CPR - 1;          // XOR swizzle mask over the chunks of a row
+    static_assert(NA >= 1 && NBC >= 1 && (CPR == 16 || CPR == 8), "tile / K-step combination not supported");
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* As = smem;                  // [2][BM*BK]
-    double* Bs = smem + 2 * BM * BK;    // [2][BN*BK]
+    double* As = smem;                     // [NBUF][BM*KT]
+    double* Bs = smem + NBUF * BM * KT;    // [NBUF][BN*KT]
 
-    const GemmTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -39,7 +41,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
 
     const double* Ap = A + t.a_off;
     const double* Bp = B + t.b_off;
-    const int nk = t.klen / BK;
+    const int nk = t.klen / KT;
     const bool a_lo = t.flags & TF_A_LOWER, a_up = t.flags & TF_A_UPPER;
     const bool b_lo = t.flags & TF_B_LOWER, b_up = t.flags & TF_B_UPPER;
     const int a_lo_shift = t.klen - BM, b_lo_shift = t.klen - BN;
@@ -55,8 +57,8 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int g = tid + NT * u;
-            const int row = g >> 4, c = g & 15;
-            const int k = kt * BK + 2 * c;
+            const int row = g / CPR, c = g % CPR;
+            const int k = kt * KT + 2 * c;
             d2_t v = *reinterpret_cast<const d2_t*>(Ap + (int64_t)row * ld + k);
             if (a_lo) {
                 if (k > row + a_lo_shift) v.x = 0.0;
@@ -71,8 +73,8 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
 #pragma unroll
         for (int u = 0; u < NBC; ++u) {
             const int g = tid + NT * u;
-            const int row = g >> 4, c = g & 15;
-            const int k = kt * BK + 2 * c;
+            const int row = g / CPR, c = g % CPR;
+            const int k = kt * KT + 2 * c;
             d2_t v = *reinterpret_cast<const d2_t*>(Bp + (int64_t)row * ld + k);
             if (b_lo) {
                 if (k > row + b_lo_shift) v.x = 0.0;
@@ -86,33 +88,33 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
         }
     };
     auto store_tiles = [&](int buf) {
-        double* as = As + buf * (BM * BK);
-        double* bs = Bs + buf * (BN * BK);
+        double* as = As + buf * (BM * KT);
+        double* bs = Bs + buf * (BN * KT);
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int g = tid + NT * u;
-            const int row = g >> 4, c = g & 15;
-            *reinterpret_cast<d2_t*>(as + row * BK + ((c ^ (row & 15)) << 1)) = ra[u];
+            const int row = g / CPR, c = g % CPR;
+            *reinterpret_cast<d2_t*>(as + row * KT + ((c ^ (row & SWM)) << 1)) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < NBC; ++u) {
             const int g = tid + NT * u;
-            const int row = g >> 4, c = g & 15;
-            *reinterpret_cast<d2_t*>(bs + row * BK + ((c ^ (row & 15)) << 1)) = rb[u];
+            const int row = g / CPR, c = g % CPR;
+            *reinterpret_cast<d2_t*>(bs + row * KT + ((c ^ (row & SWM)) << 1)) = rb[u];
         }
     };
     auto compute = [&](int buf) {
-        const double* as = As + buf * (BM * BK) + (wm * (BM / WM) + fr) * BK + (q & 1);
-        const double* bs = Bs + buf * (BN * BK) + (wn * (BN / WN) + fr) * BK + (q & 1);
+        const double* as = As + buf * (BM * KT) + (wm * (BM / WM) + fr) * KT + (q & 1);
+        const double* bs = Bs + buf * (BN * KT) + (wn * (BN / WN) + fr) * KT + (q & 1);
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
+        for (int kk = 0; kk < KT / 4; ++kk) {
             // lane (fr, q) supplies element [row fr][k = 4*kk + q]: 16-byte chunk 2*kk + (q>>1), half q&1
-            const int sw = ((2 * kk + (q >> 1)) ^ fr) << 1;
+            const int sw = ((2 * kk + (q >> 1)) ^ (fr & SWM)) << 1;
             double a[TM], b[TN];
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) a[mi] = as[mi * 16 * BK + sw];
+            for (int mi = 0; mi < TM; ++mi) a[mi] = as[mi * 16 * KT + sw];
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) b[ni] = bs[ni * 16 * BK + sw];
+            for (int ni = 0; ni < TN; ++ni) b[ni] = bs[ni * 16 * KT + sw];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -124,12 +126,25 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask* __restrict__ tasks,
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) load_tiles(kt + 1);
-        compute(kt & 1);
-        if (more) store_tiles((kt + 1) & 1);
-        __syncthreads();
+    if constexpr (NBUF == 2) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1 < nk);
+            if (more) load_tiles(kt + 1);
+            compute(kt & 1);
+            if (more) store_tiles((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // slim variant: the next K-step waits in registers while this one is on the matrix cores, and is written to
+        // the single LDS buffer between two barriers
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1 < nk);
+            if (more) load_tiles(kt + 1);
+            compute(0);
+            __syncthreads();
+            if (more) store_tiles(0);
+            __syncthreads();
+        }
     }
 
     // epilogue: v_mfma_f64_16x16x4 C/D layout: D[row = q + 4*reg][col = fr]
@@ -165,27 +180,36 @@ constexpr int GEMM_THREADS = 64 * GW_M * GW_N;    // the fp64 MFMA pipe busy (pr
 //   mfgp_predvar_f64             : the predictive-variance product V = K(X*,X) L^-T
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_t128(const GemmTask* __restrict__ tasks, const double* A,
                                                                 const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
                                                                const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks[blockIdx.x], A, B, C, C2, ld);
+}
+// chain variant: the GEMM steps on the serial Cholesky chain (panel, column update).  16 KB of LDS (one buffer, K-steps of
+// 16) instead of 64, so a workgroup fits on a CU BESIDE a 128 KB workgroup of the bulk trailing update running on the
+// other stream (160 KB per CU, allocated in 1280-byte granules: 32 KB would miss by 768 bytes) instead of waiting
+// ~60 us for one to retire; raised wave priority so its MFMAs issue first.
+__global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_chain(const GemmTask* __restrict__ tasks, const double* A,
+                                                                 const double* B, double* C, double* C2, int ld) {
+    __builtin_amdgcn_s_setprio(3);
+    gemm_nt_tile<64, 64, GW_M, GW_N, 1, 16>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_kinv_syrk_f64(const GemmTask* __restrict__ tasks, const double* A,
                                                              const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_kinv_syrk_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
                                                                  const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_predvar_f64(const GemmTask* __restrict__ tasks, const double* A,
                                                            const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<128, 128, GW_M, GW_N>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_predvar_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
                                                                const double* B, double* C, double* C2, int ld) {
-    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks, A, B, C, C2, ld);
+    gemm_nt_tile<64, 64, GW_M, GW_N>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 
 size_t gemm_lds_bytes(int tile) { return (size_t)2 * (tile + tile) * BK * sizeof(double); }
@@ -207,7 +231,12 @@ void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, con
                                           (int)gemm_lds_bytes(t == 0 ? 128 : 64));
         attr_set = true;
     }
-    const gemm_kernel_t k = table[role][tile == 128 ? 0 : 1];
+    if (role == 3 && tile == 64) {   // serial-chain step: slim workgroups that co-reside with the bulk update
+        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain, dim3(ntasks), dim3(GEMM_THREADS), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
+                           C, C2, ld);
+        return;
+    }
+    const gemm_kernel_t k = table[role == 3 ? 0 : role][tile == 128 ? 0 : 1];
     hipLaunchKernelGGL(k, dim3(ntasks), dim3(GEMM_THREADS), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld);
 }
 

@@ -28,7 +28,7 @@ enum Buf { BUF_A = 0, BUF_L = 1, BUF_S = 2, BUF_W = 3 };
 
 struct Step {
     int kind;  // 0 = leaf, 1 = gemm
-    int role;  // gemm kernel symbol: 0 recursion, 1 K^-1, 2 predictive variance
+    int role;  // gemm kernel symbol: 0 recursion, 1 K^-1, 2 predictive variance, 3 serial-chain step (slim workgroups)
     int strm;  // 0 = main stream (the serial chain), 1 = bulk-update stream (look-ahead)
     int wait_ev, rec_ev;  // 1-based indices into the event pool (0 = none): wait before / record after the launch
     int blk;   // leaf block
@@ -92,6 +92,7 @@ static int fail(mfgp_handle* h, int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 // planner
 // ------------------------------------------------------------------------------------------------
+static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group);
 static int pick_tile(int ntiles128) { return ntiles128 >= 160 ? 128 : 64; }
 
 static void add_gemm(mfgp_handle* h, std::vector<Step>& plan, int tile, int first, int a, int b, int c, int c2) {
@@ -228,6 +229,12 @@ static void plan_potrf_rl(mfgp_handle* h) {
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool lookahead = true;
     if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
+    bool merge_cols = true;
+    if (const char* e = getenv("MFGP_MERGE_COLS")) merge_cols = atoi(e) != 0;
+    // slim chain workgroups (role 3) co-reside with the bulk update's workgroups; alone they are ~30 % slower than the
+    // double-buffered 64-tile kernel, so they only pay where bulk updates are long enough to overlap the chain
+    int chain_role = (lookahead && nb >= 48) ? 3 : 0;
+    if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
     int nev = 0;
     auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
         // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
@@ -258,6 +265,7 @@ static void plan_potrf_rl(mfgp_handle* h) {
                 const int first = (int)h->tasks.size();
                 syrk_tasks(T, c, c + 1, M0, c);
                 add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+                h->plan.back().role = chain_role;
                 if (lookahead && ev_col[c] > 0) { h->plan.back().wait_ev = ev_col[c]; waited = true; }
             }
             Step s{};
@@ -285,6 +293,7 @@ static void plan_potrf_rl(mfgp_handle* h) {
                         h->tasks.push_back(t);
                     }
                 add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
+                if (T == 64) h->plan.back().role = chain_role;
             }
         }
         if (M1 >= nb) break;
@@ -299,26 +308,37 @@ static void plan_potrf_rl(mfgp_handle* h) {
         const int ev_chain = new_event(h, nev);
         h->plan.back().rec_ev = ev_chain;   // chain(M) complete: every L[:, M0:M1] panel is final
         bool first_bulk = true;
-        for (int c = M1; c < M2; ++c) {     // the next macro panel's block columns, one launch each
-            const int T = pick_tile(nb - c);
+        {
+            // the column that gates the next leaf stays on the MAIN stream: no event round trip on the chain.
+            // It must still come after the previous macro's rest-update, which covers this column too and
+            // runs on the bulk stream (normally long finished: the wait is on an already signalled event).
+            const int T = pick_tile(nb - M1);
             const int first = (int)h->tasks.size();
-            syrk_tasks(T, c, c + 1, M0, M1);
+            syrk_tasks(T, M1, M1 + 1, M0, M1);
             add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
             Step& st = h->plan.back();
-            if (c == M1) {
-                // the column that gates the next leaf stays on the MAIN stream: no event round trip on the chain.
-                // It must still come after the previous macro's rest-update, which covers this column too and
-                // runs on the bulk stream (normally long finished: the wait is on an already signalled event).
-                st.strm = 0;
-                st.wait_ev = ev_rest_prev;
-                ev_col[c] = 0;
-                continue;
+            st.strm = 0;
+            if (T == 64) st.role = chain_role;
+            st.wait_ev = ev_rest_prev;
+            ev_col[M1] = 0;
+        }
+        if (M1 + 1 < M2) {
+            // the other block columns of the next macro panel: ONE launch on the bulk stream (each is needed one chain
+            // step later than the previous; a launch per column left the GPU at ~140 workgroups three times in a row)
+            const int cols = M2 - (M1 + 1);
+            const int T = merge_cols ? pick_tile(cols * (nb - M1 - 1)) : 64;
+            for (int c = M1 + 1; c < M2; c += merge_cols ? cols : 1) {
+                const int first = (int)h->tasks.size();
+                syrk_tasks(merge_cols ? T : pick_tile(nb - c), c, merge_cols ? M2 : c + 1, M0, M1);
+                add_gemm(h, h->plan, merge_cols ? T : pick_tile(nb - c), first, BUF_L, BUF_L, BUF_A, -1);
+                Step& st = h->plan.back();
+                st.strm = 1;
+                if (first_bulk) st.wait_ev = ev_chain;
+                first_bulk = false;
+                const int ev = new_event(h, nev);
+                st.rec_ev = ev;
+                for (int cc = c; cc < (merge_cols ? M2 : c + 1); ++cc) ev_col[cc] = ev;
             }
-            st.strm = 1;
-            if (first_bulk) st.wait_ev = ev_chain;
-            first_bulk = false;
-            ev_col[c] = new_event(h, nev);
-            st.rec_ev = ev_col[c];
         }
         if (M2 < nb) {   // the rest of the trailing matrix: overlaps the next macro panel's chain
             const int T = pick_tile(ntiles_cols(M2, nb));
@@ -334,6 +354,7 @@ static void plan_potrf_rl(mfgp_handle* h) {
         }
     }
 }
+
 
 struct TriNode { int b0, bm, b1, level; };
 static int collect_nodes(int b0, int b1, std::vector<TriNode>& out) {

@@ -60,7 +60,8 @@ constexpr int MFGP_MAX_GROUPS = 3;
 
 // ---- launchers (implemented in the .hip files) -------------------------------------------------
 // tile: 128 or 64.  tasks = device pointer to ntasks GemmTask.
-// role: 0 = recursion GEMMs, 1 = the K^-1 SYRK launch, 2 = predictive-variance product (distinct kernel symbols)
+// role: 0 = recursion GEMMs, 1 = the K^-1 SYRK launch, 2 = predictive-variance product (distinct kernel symbols),
+//       3 = a step on the serial Cholesky chain (64-tile only: mfgp_gemm_nt_f64_chain)
 void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
                  const double* B, double* C, double* C2, int ld, int role = 0);
 size_t gemm_lds_bytes(int tile);
