@@ -150,33 +150,55 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         model[".*Gaussian_noise"].fix()
         conc = int(self.restart_concurrency)
         rank, size = self.comm.rank, self.comm.size
-        mine_bg = [i for i in range(1, num_restarts) if i % size == rank]
-        if conc <= 1 or not mine_bg:
+        if conc <= 1:
             model.optimize(max_iters=self.first_run_max_iters)
             model[".*Gaussian_noise"].unfix()
             model[".*Gaussian_noise"].constrain_positive()
             model.optimize_restarts(num_restarts, optimizer="bfgs", max_iters=self.restart_max_iters, verbose=False,
                                     rand_gen=self._restart_rng(), comm=self.comm)
             return
-        level = [k for k, e in self._engines.items() if e is model._engine]
-        tag = level[0] if level else "aux"
-        aux = [self._engine("%s#%d" % (tag, j)) for j in range(1, min(conc, len(mine_bg)) + 1)]
-        handle = model.start_background_restarts(mine_bg, aux, free=model.parameters(), rand_gen=self._restart_rng(),
-                                                 max_iters=self.restart_max_iters)
-        model.optimize(max_iters=self.first_run_max_iters)
-        model[".*Gaussian_noise"].unfix()
-        model[".*Gaussian_noise"].constrain_positive()
+        # Rank 0 owns the only sequential piece (first run -> restart 0, which continues from it); the randomized
+        # restarts go to the least-loaded rank.  No other rank needs the first run: the winner overwrites every
+        # free parameter on every rank.
+        mine_bg = self.assign_restarts(num_restarts, size)[rank]
+        handle = None
+        if mine_bg:
+            level = [k for k, e in self._engines.items() if e is model._engine]
+            tag = level[0] if level else "aux"
+            aux = [self._engine("%s#%d" % (tag, j)) for j in range(1, min(conc, len(mine_bg)) + 1)]
+            free = [p for p in model.parameters()]       # every parameter is free during the restarts
+            handle = model.start_background_restarts(mine_bg, aux, free=free, rand_gen=self._restart_rng(),
+                                                     max_iters=self.restart_max_iters)
         runs = []
         if rank == 0:
+            model.optimize(max_iters=self.first_run_max_iters)
+        model[".*Gaussian_noise"].unfix()
+        model[".*Gaussian_noise"].constrain_positive()
+        if rank == 0 and num_restarts > 0:
             r0 = model.optimize(max_iters=self.restart_max_iters)   # restart 0 continues from the current point
             if r0 is not None:
                 runs.append((r0.f_opt, r0.x_opt, 0))
-        runs += handle.result()
+        if handle is not None:
+            runs += handle.result()
         if size > 1:
             runs = [r for part in self.comm.allgather_object(runs) for r in part]
         if runs:
             best = min(runs, key=lambda r: (r[0], r[2]))
             model.optimizer_array = best[1]
+
+    @staticmethod
+    def assign_restarts(num_restarts, size):
+        """-> per rank, the randomized restarts (indices 1..num_restarts-1) it runs beside its other work.
+        Rank 0 starts with a load of two runs (first run + restart 0, sequential); every restart goes to the rank with
+        the smallest load, the highest such rank on ties (rank 0's extra runs can only slow its chain down)."""
+        load = [0] * size
+        load[0] = 2
+        out = [[] for _ in range(size)]
+        for i in range(1, num_restarts):
+            r = min(range(size), key=lambda k: (load[k], -k))
+            out[r].append(i)
+            load[r] += 1
+        return out
 
     # ---- adaptation loop ---------------------------------------------------------------------------------
     def adapt_and_plot(self, plot_means: bool = False, plot_uncertainties: bool = False, plot_error: bool = False,

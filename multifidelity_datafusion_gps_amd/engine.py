@@ -589,8 +589,7 @@ class GPRegression:
             if i % size != rank:
                 continue
             try:
-                self.optimizer_array = initial_parameters
-                if i > 0:
+                if i > 0:   # restart 0 IS the current point (no reset: a round trip through the transform costs the last bits)
                     if callable(rand_gen):
                         self.randomize(rand_gen(i))
                     else:

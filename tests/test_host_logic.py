@@ -138,3 +138,14 @@ def test_batched_direct_agrees_with_gablonsky_code():
     x1, f1 = DIRECT1Maximizer(faithful=True).maximize(model_predict, np.zeros(2), np.ones(2))
     x2, f2 = DIRECT1Maximizer().maximize(model_predict, np.zeros(2), np.ones(2))
     assert np.abs(x1 - x2).max() < 1e-2 and f1 == pytest.approx(f2, abs=1e-3)
+
+
+def test_restart_assignment_keeps_the_sequential_chain_on_rank_zero():
+    from multifidelity_datafusion_gps_amd.abstractMFGP import AbstractMFGP
+    for size in (1, 2, 3, 4, 6, 8):
+        parts = AbstractMFGP.assign_restarts(6, size)
+        assert sorted(i for p in parts for i in p) == [1, 2, 3, 4, 5]          # every randomized restart exactly once
+        loads = [len(p) + (2 if r == 0 else 0) for r, p in enumerate(parts)]
+        assert max(loads) - min(l for l in loads if l > 0 or size <= 7) <= 2
+        assert max(loads) == -(-7 // size) or size == 1 or max(loads) == 2      # ceil(7 runs / size), never below the chain
+    assert AbstractMFGP.assign_restarts(6, 4)[0] == [] and AbstractMFGP.assign_restarts(6, 8)[0] == []
