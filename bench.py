@@ -12,8 +12,8 @@ objective+gradient evaluation budget (--evals, default 20; SURVEY.md 8(d) "fixed
 
   python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-N > 1 is STRONG scaling of the same job: the 6 independent restarts and the N* predictive rows are
-sharded over the ranks (sharding.py); the sequential parts (LF run, first HF run) are replicated.
+N > 1 is STRONG scaling of the same job: the randomized restarts and the N* predictive rows are sharded over the
+ranks (sharding.py); the LF run is replicated; rank 0 alone runs the sequential first HF run -> restart 0.
 Prints ONE JSON line on rank 0.  `value` = milliseconds per fit+predict (lower is better).
 The CPU comparator (`cpu_baseline`) is the numpy/LAPACK oracle timed on the host cores of the same box
 on a bounded sample (one objective+gradient evaluation per level + the predict products), scaled by the
@@ -237,7 +237,7 @@ def main():
                        "evals_issued_rank0_per_step": evals / args.steps,
                        "gpu_ms_per_evaluation": round(gpu_eval_ms, 3),
                        "restart_concurrency": args.concurrency,
-                       "sharding": "restarts + predictive rows over ranks; LF run and first HF run replicated"},
+                       "sharding": "randomized restarts + predictive rows over ranks; LF run replicated; first HF run -> restart 0 on rank 0 only"},
             "roofline": {"kernel": "mfgp_kinv_syrk_f64 (K^-1 = L^-T L^-1, one launch per evaluation)",
                          "bound": "mfma", "achieved": round(ach_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / FP64_PEAK_TFLOPS, 4),
