@@ -258,6 +258,7 @@ static void plan_potrf_rl(mfgp_handle* h) {
     for (int M0 = 0; M0 < nb; M0 += MB) {
         const int M1 = std::min(M0 + MB, nb);
         const int M2 = std::min(M1 + MB, nb);
+        int main_waited_ev = 0;   // the merged column launch signals ONE event for several columns: wait for it once
         for (int c = M0; c < M1; ++c) {
             bool waited = false;
             if (c > M0) {   // left-looking update of block column c with the macro's finished columns
@@ -266,12 +267,15 @@ static void plan_potrf_rl(mfgp_handle* h) {
                 syrk_tasks(T, c, c + 1, M0, c);
                 add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
                 h->plan.back().role = chain_role;
-                if (lookahead && ev_col[c] > 0) { h->plan.back().wait_ev = ev_col[c]; waited = true; }
+                if (lookahead && ev_col[c] > 0) {
+                    if (ev_col[c] != main_waited_ev) h->plan.back().wait_ev = main_waited_ev = ev_col[c];
+                    waited = true;   // (an event wait costs ~6 us on the chain even when already signalled)
+                }
             }
             Step s{};
             s.kind = 0;
             s.blk = c;
-            if (lookahead && !waited && ev_col[c] > 0) s.wait_ev = ev_col[c];
+            if (lookahead && !waited && ev_col[c] > 0 && ev_col[c] != main_waited_ev) s.wait_ev = main_waited_ev = ev_col[c];
             h->plan.push_back(s);
             const int rem = nb - 1 - c;
             if (rem == 0) break;
