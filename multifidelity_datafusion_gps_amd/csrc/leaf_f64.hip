@@ -9,22 +9,22 @@
 // Phase 1 factorises in place by 16-column panels with look-ahead:
 //   * the 16x16 diagonal micro-Cholesky runs in the REGISTERS of wave 0 (lane = row, 16 columns per
 //     lane, pivots and column entries broadcast with v_readlane: no LDS round trip, no barrier inside),
-//   * rows below the diagonal block: one thread per row, forward substitution against L_jj (LDS broadcast),
+//   * the inverse of the 16x16 diagonal factor comes out of the same pivot loop (one extra FMA per broadcast), and the
+//     rows below the diagonal block are solved as MFMA products with it,
 //   * the rank-16 trailing update runs on MFMA; the next panel's block column is updated first, then
 //     wave 0 factorises the next diagonal block WHILE waves 1-7 finish the rest of the update.
-// Phase 2 inverts in place (right-to-left block columns, LAPACK dtrti2 order): the eight 16x16
-// diagonal inverses are solved concurrently, then X[ib][jb] = -sum_kb X[ib][kb] (L[kb][jb] X[jb][jb])
-// on MFMA.
+// Phase 2 inverts in place: the eight 16x16 diagonal inverses are already there, the rest is assembled recursively
+// (X21 = -X22 (L21 X11) over 16 -> 32 -> 64 -> 128) on MFMA.
 #include "mfgp_internal.h"
 
 namespace mfgp {
 
 constexpr int LP = 130;       // LDS pitch (doubles)
 constexpr int LEAF_THREADS = 512;
-constexpr int SC_RINV = 0;    // scratch: 1/l_kk for the 128 pivots
-constexpr int SC_RED = 128;   // 8 partial sums
-constexpr int SC_LT = 144;    // 16x16 transposed copy of the current diagonal factor: LT[m*16 + k] = L_jj[k][m]
-constexpr int SC_SIZE = SC_LT + 256;
+constexpr int SC_RED = 0;      // scratch: 8 partial sums
+constexpr int SC_Y = 16;      // the eight inverted diagonal factors Y_jj = L_jj^-1, 16x16 row-major each
+constexpr int YP = 18;        // pitch of a Y block (16 would put the 16 rows of a fragment read on one bank pair)
+constexpr int SC_SIZE = SC_Y + 8 * 16 * YP;
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -47,51 +47,69 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
     return y;
 }
 
-// 16x16 Cholesky in the registers of one wave.  blk -> element (0,0) of the diagonal block in LDS.
+// 16x16 Cholesky AND the inverse of the factor in the registers of one wave.  blk -> element (0,0) of the diagonal
+// block in LDS.  Lanes 0-15: lane i holds row i of the block, v[k] = A[i][k] -> L[i][k].  Lanes 16-31: lane 16+c holds
+// column c of the inverse Y = L^-1, v[k] = -(sum_{m<k} l_km Y[m][c]) until pivot k, then Y[k][c].
+// The inverse rides on the factorisation's own broadcasts: row j of Y is Y[j][:] = (e_j - sum_{m<j} l_jm Y[m][:]) / l_jj,
+// and l_kj -- broadcast at pivot j to eliminate column j from row k -- is exactly the coefficient with which the
+// finished row j of Y enters row k's sum.  With the sums kept negated both lane groups execute the SAME instruction
+// v[k] -= v[j] * l_kj, so the inverse costs one add per pivot and no extra communication.
 // Branch-free inside the pivot loop: a failed pivot (d <= 0 or NaN) is replaced by 1 and its index kept.
-__device__ __forceinline__ void micro_chol16(double* blk, double* rinv_out, double* lt_out, int lane, int* info,
-                                             int pivot0) {
+__device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lane, int* info, int pivot0) {
     const int i = lane & 15;
-    double a[16];
+    const bool inv_lane = (lane & 16) != 0;
+    double v[16];
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
-        const d2_t v = *reinterpret_cast<const d2_t*>(blk + i * LP + k);
-        a[k] = v.x;
-        a[k + 1] = v.y;
+        const d2_t t = *reinterpret_cast<const d2_t*>(blk + i * LP + k);
+        v[k] = inv_lane ? 0.0 : t.x;
+        v[k + 1] = inv_lane ? 0.0 : t.y;
     }
-    double my_rinv = 0.0;
     int fail = 0;  // 1-based index of the first non-positive pivot inside this block (wave-uniform)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        double d = readlane_f64(a[j], j);
+        double d = readlane_f64(v[j], j);
         const bool ok = d > 0.0;
         fail = (!ok && fail == 0) ? j + 1 : fail;
         d = ok ? d : 1.0;
         const double y = fast_rsqrt(d);
-        a[j] *= y;                      // l_ij for rows i > j; row j itself: a_jj * y = sqrt(d) when ok
-        a[j] = (i == j && !ok) ? 1.0 : a[j];
-        my_rinv = (i == j) ? y : my_rinv;
+        const double e = (inv_lane && i == j) ? 1.0 : 0.0;
+        v[j] = (v[j] + e) * y;          // factor lanes: l_ij (row j itself: sqrt(d)); inverse lanes: Y[j][c]
+        v[j] = (!inv_lane && i == j && !ok) ? 1.0 : v[j];
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) {
-            const double lkj = readlane_f64(a[j], k);
-            a[k] = __builtin_fma(-a[j], lkj, a[k]);  // meaningful for rows i >= k
+            const double lkj = readlane_f64(v[j], k);   // from factor lane k
+            v[k] = __builtin_fma(-v[j], lkj, v[k]);     // factor lanes: meaningful for rows i >= k
             if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 broadcasts in flight (SGPR pressure)
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     if (lane < 16) {
-        rinv_out[i] = my_rinv;
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
-            d2_t v;
-            v.x = (k <= i) ? a[k] : 0.0;
-            v.y = (k + 1 <= i) ? a[k + 1] : 0.0;
-            *reinterpret_cast<d2_t*>(blk + i * LP + k) = v;
+            d2_t t;
+            t.x = (k <= i) ? v[k] : 0.0;
+            t.y = (k + 1 <= i) ? v[k + 1] : 0.0;
+            *reinterpret_cast<d2_t*>(blk + i * LP + k) = t;
         }
+    } else if (lane < 32) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lt_out[k * 16 + i] = (k <= i) ? a[k] : 0.0;  // column k of L_jj, contiguous
+        for (int k = 0; k < 16; ++k) y_out[k * YP + i] = v[k];   // column i of Y_jj (zero above the diagonal)
     }
     if (fail != 0 && lane == 0 && *info == 0) *info = pivot0 + fail;
+}
+
+// rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
+__device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
+    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double av = sL[(ib * 16 + fr) * LP + jb * 16 + 4 * s + q];
+        const double bv = Y[fr * YP + 4 * s + q];   // B[k][n] = Y[n][k]
+        acc = mfma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + jb * 16 + fr] = acc[r];
 }
 
 // C[ib][kb] -= L[ib][jb] L[kb][jb]^T on 16x16 blocks of the LDS matrix
@@ -147,41 +165,13 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
 
     STAMP(1);
     // ---- phase 1: blocked Cholesky with look-ahead ---------------------------------------------------
-    if (wave == 0) micro_chol16(sL, sc + SC_RINV, sc + SC_LT, lane, info, blk * NB);
+    if (wave == 0) micro_chol16(sL, sc + SC_Y, lane, info, blk * NB);
     __syncthreads();
     STAMP(2);
     for (int jb = 0; jb < 8; ++jb) {
         const int base = jb * 16;
-        // rows below the diagonal block: x L_jj^T = a by forward substitution, one thread per row
-        {
-            const int nrows = NB - base - 16;
-            if (tid < nrows) {
-                double* rowp = sL + (base + 16 + tid) * LP + base;
-                // an opaque per-lane zero keeps the (wave-uniform) L_jj reads in VGPRs: hipcc otherwise moves every
-                // broadcast value to an SGPR with v_readfirstlane and spills ~130 SGPRs in this loop nest
-                int vz;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-                const double* LT = sc + SC_LT + vz;
-                const double* rinv = sc + SC_RINV + base + vz;
-                double x[16];
-#pragma unroll
-                for (int k = 0; k < 16; k += 2) {
-                    const d2_t v = *reinterpret_cast<const d2_t*>(rowp + k);
-                    x[k] = v.x;
-                    x[k + 1] = v.y;
-                }
-                // right-looking: after x[m] is final, eliminate it from every later unknown (independent FMAs)
-#pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    x[m] *= rinv[m];
-#pragma unroll
-                    for (int k = m + 1; k < 16; ++k) x[k] = __builtin_fma(-x[m], LT[m * 16 + k], x[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k += 2)
-                    *reinterpret_cast<d2_t*>(rowp + k) = (d2_t){x[k], x[k + 1]};
-            }
-        }
+        // rows below the diagonal block: x L_jj^T = a, as the product with the inverted diagonal factor (one block per wave)
+        for (int ib = jb + 1 + wave; ib < 8; ib += 8) solve_block(sL, sc + SC_Y + jb * 16 * YP, ib, jb, fr, q);
         __syncthreads();
         if (jb == 0) STAMP(3);
         if (jb == 7) break;
@@ -194,7 +184,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
         if (jb == 0) STAMP(4);
         // wave 0 factorises the next diagonal block while waves 1-7 finish the trailing update
         if (wave == 0) {
-            micro_chol16(sL + (base + 16) * LP + base + 16, sc + SC_RINV + base + 16, sc + SC_LT, lane, info,
+            micro_chol16(sL + (base + 16) * LP + base + 16, sc + SC_Y + (jb + 1) * 16 * YP, lane, info,
                          blk * NB + base + 16);
         } else {
             const int m = 6 - jb;  // block columns jb+2 .. 7
@@ -229,27 +219,10 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
 
     STAMP(7);
     // ---- phase 2: in-place inverse ---------------------------------------------------------------------
-    // (a) the eight 16x16 diagonal inverses, one thread per column, all at once
-    {
-        double x[16];
-        const int b = tid >> 4, k = tid & 15;
-        if (tid < 128) {
-            const double* Lb = sL + (b * 16) * LP + b * 16;
-            const double* rinv = sc + SC_RINV + b * 16;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double s = (i == k) ? 1.0 : 0.0;
-#pragma unroll
-                for (int m = 0; m < i; ++m) s = __builtin_fma(-Lb[i * LP + m], x[m], s);
-                x[i] = s * rinv[i];
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            double* Lb = sL + (b * 16) * LP + b * 16;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Lb[i * LP + k] = x[i];  // zeros above the diagonal come out of the solve
-        }
+    // (a) the eight 16x16 diagonal inverses were produced with the factors: copy them over the diagonal blocks
+    for (int e = tid; e < 8 * 256; e += LEAF_THREADS) {
+        const int b = e >> 8, i = (e >> 4) & 15, k = e & 15;
+        sL[(b * 16 + i) * LP + b * 16 + k] = sc[SC_Y + (b * 16 + i) * YP + k];
     }
     __syncthreads();
     STAMP(8);

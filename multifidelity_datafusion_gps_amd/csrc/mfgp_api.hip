@@ -1254,6 +1254,8 @@ int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out) {
 int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, double* C, int32_t M, int32_t N,
                          int32_t K, double alpha, double beta, int32_t tile) {
     if (!h || !A || !B || !C) return fail(h, -1, "mfgp_dbg_gemm_nt: NULL");
+    const bool chain = (tile == -64);   // -64: the serial-chain variant of the 64-tile kernel (mfgp_gemm_nt_f64_chain)
+    if (chain) tile = 64;
     if ((tile != 128 && tile != 64) || M % tile || N % tile || K % BK || K < BK)
         return fail(h, -1, "mfgp_dbg_gemm_nt: M, N must be multiples of the tile and K of 32");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1281,7 +1283,7 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
         }
     HIPCHK(h, hipMalloc(&dt, ts.size() * sizeof(GemmTask)));
     HIPCHK(h, hipMemcpy(dt, ts.data(), ts.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
-    launch_gemm(h->stream, tile, dt, (int)ts.size(), dA, dB, dC, nullptr, ld);
+    launch_gemm(h->stream, tile, dt, (int)ts.size(), dA, dB, dC, nullptr, ld, chain ? 3 : 0);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy2D(C, (size_t)N * 8, dC, (size_t)ld * 8, (size_t)N * 8, M, hipMemcpyDeviceToHost));

@@ -9,7 +9,7 @@ def test_device_is_gfx950(engine):
     assert "gfx950" in engine.device_info, engine.device_info
 
 
-@pytest.mark.parametrize("tile", [128, 64])
+@pytest.mark.parametrize("tile", [128, 64, -64])
 def test_mfma_layout_identity_times_asymmetric(engine, tile):
     """A = I with an ASYMMETRIC B catches a swapped C/D lane map (guide: cdna_hip_programming.md section 3)."""
     n = 128
@@ -19,7 +19,8 @@ def test_mfma_layout_identity_times_asymmetric(engine, tile):
     np.testing.assert_array_equal(C, B.T)  # C[i][j] = sum_k I[i][k] B[j][k] = B[j][i]
 
 
-@pytest.mark.parametrize("tile,M,N,K", [(128, 128, 128, 32), (128, 256, 384, 160), (64, 64, 192, 96), (64, 320, 128, 512)])
+@pytest.mark.parametrize("tile,M,N,K", [(128, 128, 128, 32), (128, 256, 384, 160), (64, 64, 192, 96), (64, 320, 128, 512),
+                                        (-64, 64, 64, 32), (-64, 192, 128, 128), (-64, 320, 64, 416)])   # -64: serial-chain kernel
 def test_gemm_nt_against_numpy(engine, tile, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K))
