@@ -1,0 +1,46 @@
+"""The C-ABI from a plain C program (gcc, no Python / torch in that process): include/mfgp.h is the drop-in boundary
+for ANY host language.  The client's numbers are checked against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as orc
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "multifidelity_datafusion_gps_amd")
+
+
+def test_plain_c_client_matches_oracle(tmp_path):
+    exe = tmp_path / "abi_client"
+    cmd = ["gcc", "-O1", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "abi_client.c"),
+           "-o", str(exe), "-L", PKG, "-lmfgp_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    c = cases.make_case("nargp_4d_n64")
+    X, Y, Xs, parts, theta, noise = c["X"], c["Y"], c["Xs"], c["parts"], c["theta"], c["noise"]
+    case = tmp_path / "case.txt"
+    with open(case, "w") as f:
+        f.write("%d %d %d %d\n" % (X.shape[0], X.shape[1], len(parts), Xs.shape[0]))
+        for p in parts:
+            f.write("%d %d %d %d\n" % tuple(p))
+        f.write(" ".join(repr(float(t)) for t in theta) + "\n" + repr(float(noise)) + "\n")
+        for arr in (X, Y, Xs):
+            f.write(" ".join(repr(float(v)) for v in np.asarray(arr).reshape(-1)) + "\n")
+    out = subprocess.run([str(exe), str(case)], check=True, capture_output=True, text=True, timeout=120).stdout
+    lines = out.strip().splitlines()
+    assert "gfx950" in lines[0]
+    nlml = float([l for l in lines if l.startswith("nlml")][0].split()[1])
+    grad = np.array([float(l.split()[1]) for l in lines if l.startswith("grad")])
+    pred = np.array([[float(v) for v in l.split()[1:]] for l in lines if l.startswith("pred")])
+    st = orc.inference(parts, theta, noise, X, Y)
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    mu, var = orc.predict_stable(parts, theta, noise, X, st, Xs)
+    np.testing.assert_allclose(pred[:, 0], mu, rtol=0, atol=1e-9 * max(1.0, np.abs(Y).max()))
+    np.testing.assert_allclose(pred[:, 1], var, rtol=0, atol=1e-9)
+    rc_line = [l for l in lines if l.startswith("null_predict_rc")][0]
+    assert int(rc_line.split()[1]) < 0 and "NULL" in rc_line
