@@ -8,7 +8,9 @@ One STEP = one complete pass of the hot path over one batch of synthetic input:
   predict:                 X*_aug = [X* | mean_1(X*)]                  -> mean, variance at N* points
 following src/MFDataFusion.py:75-100,141-156 and src/abstractMFGP.py:82-106,131-137 of the reference.
 Optimiser trajectories are not comparable across back-ends, so every L-BFGS-B run gets the same FIXED
-objective+gradient evaluation budget (--evals, default 20; SURVEY.md 8(d) "fixed-budget fit").
+objective+gradient evaluation budget (--evals, default 20; SURVEY.md 8(d) "fixed-budget fit"), enforced EXACTLY
+(`eval_cap`): with scipy's `maxfun` alone a run overshoots by up to a line search, and the total then moves by
++-8 % with the last bits of the arithmetic (173 vs 188 evaluations between two versions of one kernel).
 
   python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
@@ -62,6 +64,7 @@ def one_step(args, comm, engines, data):
         restart_max_iters = args.evals
         num_restarts = args.restarts
         restart_concurrency = args.concurrency
+        eval_cap = args.evals          # exact: scipy's maxfun alone lets a run overshoot by a line search
 
     model = BudgetNARGP(4, f_exact=hf_4d, f_low=None, lf_X=X_lf, lf_Y=Y_lf, seed=args.seed, comm=comm,
                         engines=engines)

@@ -25,6 +25,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     restart_max_iters = 1000    # :137
     num_restarts = 6            # src/MFDataFusion.py:100
     lf_max_iters = 1000         # lf_model.optimize() default budget (src/abstractMFGP.py:103)
+    eval_cap = None             # hard cap on objective evaluations per L-BFGS-B run (benchmarks: exact budgets)
     restart_concurrency = 1     # >1: that many randomized restarts run concurrently with the first run / restart 0
 
     @abc.abstractmethod
@@ -109,6 +110,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             self.lf_X = lf_X
             self.lf_Y = lf_Y
             self.lf_model = gp.GPRegression(X=lf_X, Y=lf_Y, initialize=True, engine=self._engine("lf"))
+            self.lf_model.eval_cap = self.eval_cap
             self.lf_model.optimize(max_iters=self.lf_max_iters)
             self.f_low = lambda t: self.lf_model.predict_mean(t)
         else:
@@ -148,6 +150,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         threads WHILE the main thread does the first run and restart 0; same runs, same winner rule."""
         model[".*Gaussian_noise"] = model.Y.var() * self.noise_ratio
         model[".*Gaussian_noise"].fix()
+        model.eval_cap = self.eval_cap
         conc = int(self.restart_concurrency)
         rank, size = self.comm.rank, self.comm.size
         if conc <= 1:

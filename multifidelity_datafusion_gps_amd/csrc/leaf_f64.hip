@@ -22,9 +22,12 @@ namespace mfgp {
 constexpr int LP = 130;       // LDS pitch (doubles)
 constexpr int LEAF_THREADS = 512;
 constexpr int SC_RED = 0;      // scratch: 8 partial sums
-constexpr int SC_Y = 16;      // the eight inverted diagonal factors Y_jj = L_jj^-1, 16x16 row-major each
-constexpr int YP = 18;        // pitch of a Y block (16 would put the 16 rows of a fragment read on one bank pair)
-constexpr int SC_SIZE = SC_Y + 8 * 16 * YP;
+constexpr int SC_SIZE = 16;
+
+// where the inverted diagonal factor Y_jj = L_jj^-1 (16x16, pitch LP) waits for phase 2: in a block ABOVE the diagonal
+// of the LDS matrix -- that half only holds the symmetric copy of the input and is never read -- so that the leaf
+// stays at 133 KB of LDS (a slim chain workgroup of another evaluation still fits on the CU beside it)
+__device__ __forceinline__ int y_offset(int jb) { return jb < 7 ? (jb * 16) * LP + (jb + 1) * 16 : 7 * 16; }
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -94,7 +97,7 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
         }
     } else if (lane < 32) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y_out[k * YP + i] = v[k];   // column i of Y_jj (zero above the diagonal)
+        for (int k = 0; k < 16; ++k) y_out[k * LP + i] = v[k];   // column i of Y_jj (zero above the diagonal)
     }
     if (fail != 0 && lane == 0 && *info == 0) *info = pivot0 + fail;
 }
@@ -105,7 +108,7 @@ __device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib,
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const double av = sL[(ib * 16 + fr) * LP + jb * 16 + 4 * s + q];
-        const double bv = Y[fr * YP + 4 * s + q];   // B[k][n] = Y[n][k]
+        const double bv = Y[fr * LP + 4 * s + q];   // B[k][n] = Y[n][k]
         acc = mfma(av, bv, acc);
     }
 #pragma unroll
@@ -165,13 +168,13 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
 
     STAMP(1);
     // ---- phase 1: blocked Cholesky with look-ahead ---------------------------------------------------
-    if (wave == 0) micro_chol16(sL, sc + SC_Y, lane, info, blk * NB);
+    if (wave == 0) micro_chol16(sL, sL + y_offset(0), lane, info, blk * NB);
     __syncthreads();
     STAMP(2);
     for (int jb = 0; jb < 8; ++jb) {
         const int base = jb * 16;
         // rows below the diagonal block: x L_jj^T = a, as the product with the inverted diagonal factor (one block per wave)
-        for (int ib = jb + 1 + wave; ib < 8; ib += 8) solve_block(sL, sc + SC_Y + jb * 16 * YP, ib, jb, fr, q);
+        for (int ib = jb + 1 + wave; ib < 8; ib += 8) solve_block(sL, sL + y_offset(jb), ib, jb, fr, q);
         __syncthreads();
         if (jb == 0) STAMP(3);
         if (jb == 7) break;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
         if (jb == 0) STAMP(4);
         // wave 0 factorises the next diagonal block while waves 1-7 finish the trailing update
         if (wave == 0) {
-            micro_chol16(sL + (base + 16) * LP + base + 16, sc + SC_Y + (jb + 1) * 16 * YP, lane, info,
+            micro_chol16(sL + (base + 16) * LP + base + 16, sL + y_offset(jb + 1), lane, info,
                          blk * NB + base + 16);
         } else {
             const int m = 6 - jb;  // block columns jb+2 .. 7
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     // (a) the eight 16x16 diagonal inverses were produced with the factors: copy them over the diagonal blocks
     for (int e = tid; e < 8 * 256; e += LEAF_THREADS) {
         const int b = e >> 8, i = (e >> 4) & 15, k = e & 15;
-        sL[(b * 16 + i) * LP + b * 16 + k] = sc[SC_Y + (b * 16 + i) * YP + k];
+        sL[(b * 16 + i) * LP + b * 16 + k] = sL[y_offset(b) + i * LP + k];
     }
     __syncthreads();
     STAMP(8);

@@ -278,6 +278,29 @@ class _ParamSelection:
 # ------------------------------------------------------------------------------------------------
 # the model
 # ------------------------------------------------------------------------------------------------
+class _BudgetExhausted(Exception):
+    pass
+
+
+def _capped(f_fp, cap, x0):
+    """-> (f, state): f evaluates f_fp at most `cap` times and then raises _BudgetExhausted; state holds the best point
+    seen.  scipy's maxfun is only checked between iterations, so a run may overshoot it by a line search; a benchmark
+    that compares code versions at a FIXED evaluation budget needs the count exact (cap = None: no cap)."""
+    state = {"n": 0, "f": np.inf, "x": np.array(x0, dtype=np.float64)}
+    if not cap:
+        return f_fp, state
+
+    def f(x):
+        if state["n"] >= cap:
+            raise _BudgetExhausted()
+        state["n"] += 1
+        val, g = f_fp(x)
+        if val < state["f"]:
+            state["f"], state["x"] = float(val), np.array(x, dtype=np.float64)
+        return val, g
+    return f, state
+
+
 class _OptRun:
     def __init__(self, x_opt, f_opt, n_evals, status):
         self.x_opt, self.f_opt, self.n_evals, self.status = x_opt, f_opt, n_evals, status
@@ -287,6 +310,8 @@ class GPRegression:
     """Exact GP regression with a Gaussian likelihood on the HIP engine (GPy.models.GPRegression stand-in)."""
 
     _allowed_failures = 10  # paramz tolerates this many failed objective evaluations per model [GPy-recall]
+
+    eval_cap = None   # hard cap on objective evaluations per optimize() / restart (None: scipy's maxfun semantics only)
 
     def __init__(self, X, Y, kernel=None, noise_var=1.0, initialize=True, engine=None, name="GP regression"):
         X = np.ascontiguousarray(X, dtype=np.float64)
@@ -465,8 +490,12 @@ class GPRegression:
         if x0.size == 0:
             return None
         n0 = self.n_evals
-        x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(self._objective_grads, x0, maxfun=int(max_iters), maxiter=int(max_iters),
-                                                iprint=1 if messages else -1)
+        fun, budget = _capped(self._objective_grads, self.eval_cap, x0)
+        try:
+            x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(fun, x0, maxfun=int(max_iters), maxiter=int(max_iters),
+                                                    iprint=1 if messages else -1)
+        except _BudgetExhausted:
+            x_opt, f_opt, d = budget["x"], budget["f"], {"task": "STOP: evaluation cap reached"}
         self.optimizer_array = x_opt
         run = _OptRun(np.array(x_opt), float(f_opt), self.n_evals - n0, d.get("task", d.get("warnflag")))
         self.optimization_runs.append(run)
@@ -555,8 +584,11 @@ class GPRegression:
         def one(i):
             eng = pool_q.get()
             try:
-                f_fp = self._stateless_objective(eng, free)
-                x_opt, f_opt, _ = _sciopt.fmin_l_bfgs_b(f_fp, starts[i], maxfun=int(max_iters), maxiter=int(max_iters))
+                f_fp, budget = _capped(self._stateless_objective(eng, free), self.eval_cap, starts[i])
+                try:
+                    x_opt, f_opt, _ = _sciopt.fmin_l_bfgs_b(f_fp, starts[i], maxfun=int(max_iters), maxiter=int(max_iters))
+                except _BudgetExhausted:
+                    x_opt, f_opt = budget["x"], budget["f"]
                 with lock:
                     self.optimization_runs.append(_OptRun(np.array(x_opt), float(f_opt), -1, "background"))
                 return float(f_opt), np.array(x_opt), i

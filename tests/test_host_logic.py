@@ -149,3 +149,22 @@ def test_restart_assignment_keeps_the_sequential_chain_on_rank_zero():
         assert max(loads) - min(l for l in loads if l > 0 or size <= 7) <= 2
         assert max(loads) == -(-7 // size) or size == 1 or max(loads) == 2      # ceil(7 runs / size), never below the chain
     assert AbstractMFGP.assign_restarts(6, 4)[0] == [] and AbstractMFGP.assign_restarts(6, 8)[0] == []
+
+
+def test_eval_cap_is_exact():
+    """GPRegression.eval_cap stops an L-BFGS-B run after exactly that many objective evaluations and keeps the best point."""
+    from tests.oracle_engine import OracleEngine
+    from multifidelity_datafusion_gps_amd import engine as gp
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(30, 2)); Y = np.sin(4 * X[:, :1]) + X[:, 1:]
+    eng = OracleEngine()
+    m = gp.GPRegression(X, Y, engine=eng)
+    f0 = m.objective_function()
+    n0 = eng.n_evals
+    m.eval_cap = 7
+    run = m.optimize(max_iters=1000)
+    assert eng.n_evals - n0 == 7 and run.n_evals == 7
+    assert run.f_opt < f0 and m.objective_function() == pytest.approx(run.f_opt, rel=1e-12)
+    m.eval_cap = None
+    run2 = m.optimize(max_iters=5)          # scipy's own semantics: may overshoot maxfun
+    assert run2.n_evals >= 5
