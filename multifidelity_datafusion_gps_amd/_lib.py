@@ -342,6 +342,8 @@ class Engine:
         d["valu_fma_f64_tflops"] = {"2w/SIMD": out[12], "4w/SIMD": out[13]}
         d["valu_plus_mfma_tflops"] = {"2w/SIMD": out[14], "4w/SIMD": out[15]}
         d["valu_fma_f64_three_vgpr_operands_tflops"] = {"2w/SIMD": out[16], "4w/SIMD": out[17]}
+        d["mfma_i8_tops"] = out[18]        # v_mfma_i32_16x16x64_i8, bare loop
+        d["mfma_bf16_tflops"] = out[19]    # v_mfma_f32_16x16x32_bf16, bare loop
         return d
 
     def dbg_probe(self):

@@ -318,6 +318,66 @@ void run_probe_valu(hipStream_t s, double* out) {
 
 // out[3*c + 0..2] = {TFLOP/s, shader cycles per MFMA per wave (median), shader clock GHz} for the configs
 //   c=0: 1 wave/SIMD x 8 acc, c=1: 2 waves/SIMD x 8 acc, c=2: 4 waves/SIMD x 8 acc, c=3: 1 wave/SIMD x 1 acc (dependent)
+// low-precision matrix pipes, for sizing an fp64 emulation (Ozaki splitting) against the fp64 MFMA ceiling:
+// v_mfma_i32_16x16x64_i8 (32768 int8 ops each) and v_mfma_f32_16x16x32_bf16 (16384 flops each), 8 accumulators per wave
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void mfgp_probe_mfma_i8(int* out, int iters) {
+    v4i_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4i_t){0, 0, 0, 0};
+    const v4i_t a = {(int)threadIdx.x, 1, 2, 3}, b = {3, 2, 1, (int)threadIdx.x};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
+    }
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (sum == 123456789) out[0] = sum;
+}
+__global__ __launch_bounds__(256) void mfgp_probe_mfma_bf16(float* out, int iters) {
+    v4f_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+    v8bf_t a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(1.0f + 0.001f * (threadIdx.x & 7)); b[i] = (__bf16)(1.0f - 0.001f * i); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (sum == 12345.678f) out[0] = sum;
+}
+void run_probe_lowp(hipStream_t s, double* out2) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    int* dummy = nullptr;
+    hipMalloc(&dummy, 64);
+    const int iters = 20000, blocks = 2048;   // 2 workgroups of 4 waves per SIMD pair: 8 waves per CU x 8
+    for (int which = 0; which < 2; ++which) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, s);
+            if (which == 0) hipLaunchKernelGGL(mfgp_probe_mfma_i8, dim3(blocks), dim3(256), 0, s, dummy, iters);
+            else hipLaunchKernelGGL(mfgp_probe_mfma_bf16, dim3(blocks), dim3(256), 0, s, reinterpret_cast<float*>(dummy), iters);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+        }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double ops = (double)blocks * 4.0 * iters * 8.0 * (which == 0 ? 32768.0 : 16384.0);
+        out2[which] = ops / (ms * 1e-3) / 1e12;   // Tera-ops (int8) / TFLOP (bf16) per second
+    }
+    hipFree(dummy);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+}
+
 void run_probe_detail(hipStream_t s, double* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
