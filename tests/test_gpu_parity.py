@@ -413,3 +413,59 @@ def test_skinny_variance_path_for_small_batches(engine, N):
     nlml, grad = engine.eval(theta, noise, 1e-8, want_grad=True)
     fo, go = st["nlml"], None
     assert nlml == pytest.approx(fo, rel=1e-10)
+
+
+def test_cfg2_single_rbf_n4096_against_oracle(engine):
+    """BASELINE.json config 2 exactly: N = 4096, d = 3, y = hf_3d, single RBF, theta = (1, 0.3),
+    noise = 1e-2 Var(y): K build + Cholesky (+ the rest of the evaluation) against the oracle at full size."""
+    rng = np.random.default_rng(1)
+    N = 4096
+    X = rng.uniform(size=(N, 3)); Y = cases.hf_3d(X)
+    parts, theta, noise = cases.single(cases.RBF, 3), np.array([1.0, 0.3]), 1e-2 * Y.var()
+    st = orc.inference(parts, theta, noise, X, Y)
+    engine.set_data(X, Y); engine.set_kernel(parts)
+    nlml, grad = engine.eval(theta, noise)
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    L = engine.get_L()
+    Ky = orc.cov(parts, theta, X) + (noise + 1e-8) * np.eye(N)
+    assert np.linalg.norm(L @ L.T - Ky) / np.linalg.norm(Ky) <= 1e-14 * N
+    assert 2.0 * np.log(np.diag(L)).sum() == pytest.approx(st["logdet"], rel=1e-10)
+
+
+def test_slim_chain_regime_n6200_against_oracle(engine):
+    """N = 6200 (Np = 6272 = 49 leaf blocks: odd count, and past the size from which the serial chain's GEMM steps run
+    as slim co-resident workgroups): the full evaluation and a prediction against the oracle."""
+    rng = np.random.default_rng(62)
+    N = 6200
+    X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    st = orc.inference(parts, theta, noise, Xa, Y)
+    Xs = rng.uniform(size=(70, 4))
+    Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
+    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
+    nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
+
+
+def test_north_star_size_n8192_against_oracle(engine):
+    """The north-star size itself, once, against the oracle (about 20 s of host LAPACK): NLML, every gradient
+    component, and predictions of the composite-kernel level at N = 8192."""
+    rng = np.random.default_rng(2)
+    N = 8192
+    X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    st = orc.inference(parts, theta, noise, Xa, Y)
+    Xs = rng.uniform(size=(65, 4))
+    Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
+    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
+    nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
