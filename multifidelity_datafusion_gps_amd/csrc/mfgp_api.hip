@@ -217,9 +217,10 @@ static int new_event(mfgp_handle* h, int& counter) {
 static void plan_potrf_rl(mfgp_handle* h) {
     // Blocked Cholesky with macro panels of MB leaf blocks and look-ahead over two streams.
     //   main stream (the serial chain), for every block column c of a macro panel [M0, M1):
-    //       colupdate(c): A[i,c] -= sum_{j in [M0,c)} L[i,j] L[c,j]^T   (left-looking inside the macro, K <= (MB-1)*128)
     //       leaf(c)     : L_cc, X_cc = L_cc^-1
     //       panel(c)    : L[i,c] = A[i,c] X_cc^T, i > c
+    //       inner(c)    : A[i,j] -= L[i,c] L[j,c]^T for the macro's later columns j in (c, M1), K = 128 (right-looking
+    //                     inside the macro; MFGP_INNER_RIGHT=0: left-looking colupdate(c) before leaf(c) instead)
     //   bulk stream, after the macro's chain: A[i,j] -= L[i,M0:M1] L[j,M0:M1]^T (K = MB*128), first the block
     //       columns of the NEXT macro panel one by one (each releases the chain step that needs it), then the rest,
     //       which overlaps the next macro's chain.
@@ -229,6 +230,12 @@ static void plan_potrf_rl(mfgp_handle* h) {
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool lookahead = true;
     if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
+    // inside a macro panel: right-looking (after panel(c), column c's K = 128 contribution to the macro's later columns)
+    // instead of left-looking (before leaf(c), the K <= (MB-1)*128 contribution of the macro's earlier columns to
+    // column c): a step on the chain costs launch + K-depth, and K = 128 three times beats 128 + 256 + 384
+    // (N = 8192: 11.28 -> 11.04 ms, 4096: 3.57 -> 3.43, 2048: 1.46 -> 1.36)
+    bool inner_right = true;
+    if (const char* e = getenv("MFGP_INNER_RIGHT")) inner_right = atoi(e) != 0;
     bool merge_cols = true;
     if (const char* e = getenv("MFGP_MERGE_COLS")) merge_cols = atoi(e) != 0;
     // slim chain workgroups (role 3) co-reside with the bulk update's workgroups; alone they are ~30 % slower than the
@@ -261,7 +268,7 @@ static void plan_potrf_rl(mfgp_handle* h) {
         int main_waited_ev = 0;   // the merged column launch signals ONE event for several columns: wait for it once
         for (int c = M0; c < M1; ++c) {
             bool waited = false;
-            if (c > M0) {   // left-looking update of block column c with the macro's finished columns
+            if (c > M0 && !inner_right) {   // left-looking update of block column c with the macro's finished columns
                 const int T = 64;  // latency-bound, on the serial chain: many small tiles
                 const int first = (int)h->tasks.size();
                 syrk_tasks(T, c, c + 1, M0, c);
@@ -298,6 +305,14 @@ static void plan_potrf_rl(mfgp_handle* h) {
                     }
                 add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
                 if (T == 64) h->plan.back().role = chain_role;
+            }
+            if (inner_right && c + 1 < M1) {   // right-looking inside the macro: column c -> the macro's later columns, K = 128
+                const int first = (int)h->tasks.size();
+                syrk_tasks(64, c + 1, M1, c, c + 1);
+                add_gemm(h, h->plan, 64, first, BUF_L, BUF_L, BUF_A, -1);
+                h->plan.back().role = chain_role;
+                const int e = ev_col[c + 1];
+                if (lookahead && e > 0 && e != main_waited_ev) h->plan.back().wait_ev = main_waited_ev = e;
             }
         }
         if (M1 >= nb) break;
