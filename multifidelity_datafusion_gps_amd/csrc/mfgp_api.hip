@@ -236,6 +236,13 @@ static void plan_potrf_rl(mfgp_handle* h) {
     // (N = 8192: 11.28 -> 11.04 ms, 4096: 3.57 -> 3.43, 2048: 1.46 -> 1.36)
     bool inner_right = true;
     if (const char* e = getenv("MFGP_INNER_RIGHT")) inner_right = atoi(e) != 0;
+    // `shift`: the chain's K = 128 inner updates also cover the NEXT macro panel's first column, so that no K = MB*128
+    // step (and no wait for the previous macro's bulk update) gates its first leaf.  Pays where the factorisation is
+    // chain-bound throughout (N = 4096: 3.42 -> 3.28 ms, 2048: 1.37 -> 1.28); neutral at N = 8192, where the first half
+    // is bound by the bulk updates and the gating step's slack is worth as much as its latency.
+    bool shift = nb < 48;
+    if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
+    shift = shift && lookahead && inner_right;
     bool merge_cols = true;
     if (const char* e = getenv("MFGP_MERGE_COLS")) merge_cols = atoi(e) != 0;
     // slim chain workgroups (role 3) co-reside with the bulk update's workgroups; alone they are ~30 % slower than the
@@ -306,9 +313,12 @@ static void plan_potrf_rl(mfgp_handle* h) {
                 add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
                 if (T == 64) h->plan.back().role = chain_role;
             }
-            if (inner_right && c + 1 < M1) {   // right-looking inside the macro: column c -> the macro's later columns, K = 128
+            // right-looking inside the macro: column c -> the macro's later columns, K = 128.  `shift`: also -> the first
+            // column of the NEXT macro panel, so that no K = MB*128 step gates its first leaf
+            const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
+            if (inner_right && c + 1 < inner_hi) {
                 const int first = (int)h->tasks.size();
-                syrk_tasks(64, c + 1, M1, c, c + 1);
+                syrk_tasks(64, c + 1, inner_hi, c, c + 1);
                 add_gemm(h, h->plan, 64, first, BUF_L, BUF_L, BUF_A, -1);
                 h->plan.back().role = chain_role;
                 const int e = ev_col[c + 1];
@@ -327,6 +337,33 @@ static void plan_potrf_rl(mfgp_handle* h) {
         const int ev_chain = new_event(h, nev);
         h->plan.back().rec_ev = ev_chain;   // chain(M) complete: every L[:, M0:M1] panel is final
         bool first_bulk = true;
+        if (shift) {
+            // the chain has already brought the next macro panel's first column up to date; the bulk stream takes the
+            // columns (M1, M1+MB] in one launch (the next chain waits for its event once) and everything beyond in another
+            const int lo = M1 + 1, hi = std::min(M1 + MB, nb - 1);
+            if (lo <= hi) {
+                const int T = pick_tile(ntiles_cols(lo, hi + 1));
+                const int first = (int)h->tasks.size();
+                syrk_tasks(T, lo, hi + 1, M0, M1);
+                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+                Step& st = h->plan.back();
+                st.strm = 1;
+                st.wait_ev = ev_chain;
+                first_bulk = false;
+                const int ev = new_event(h, nev);
+                st.rec_ev = ev;
+                for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
+            }
+            if (hi + 1 < nb) {
+                const int T = pick_tile(ntiles_cols(hi + 1, nb));
+                const int first = (int)h->tasks.size();
+                syrk_tasks(T, hi + 1, nb, M0, M1);
+                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
+                h->plan.back().strm = 1;
+                if (first_bulk) h->plan.back().wait_ev = ev_chain;
+            }
+            continue;
+        }
         {
             // the column that gates the next leaf stays on the MAIN stream: no event round trip on the chain.
             // It must still come after the previous macro's rest-update, which covers this column too and
