@@ -93,7 +93,12 @@ static int fail(mfgp_handle* h, int code, const std::string& msg) {
 // planner
 // ------------------------------------------------------------------------------------------------
 static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group);
-static int pick_tile(int ntiles128) { return ntiles128 >= 160 ? 128 : 64; }
+static int pick_tile(int ntiles128) {
+    // 128-tiles run the MFMA pipe better, but a launch of few tiles is bound by its LONGEST tile (one tile per CU, 256
+    // CUs): below ~300 tiles four times as many 64-tiles balance better (top inverse level at N = 4096: 2 x 330 -> 2 x 220 us)
+    static const int t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : 300;
+    return ntiles128 >= t128_min ? 128 : 64;
+}
 
 static void add_gemm(mfgp_handle* h, std::vector<Step>& plan, int tile, int first, int a, int b, int c, int c2) {
     Step s{};
@@ -502,7 +507,8 @@ static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group) {
 static void plan_kinv(mfgp_handle* h) {
     const int64_t ld = h->Np;
     const int nb = h->nblk;
-    const int T = pick_tile(nb * (nb + 1) / 2);
+    static const int kinv_t128_min = getenv("MFGP_KINV_T128_MIN") ? atoi(getenv("MFGP_KINV_T128_MIN")) : 600;   // N = 4096: 0.65 -> 0.54 ms, N = 3072: 0.48 -> 0.25 ms
+    const int T = nb * (nb + 1) / 2 >= kinv_t128_min ? 128 : 64;
     const int sc = NB / T;
     const int first = (int)h->tasks.size();
     // locality order: super-blocks of BI x BJ output tiles (BI row panels + BJ column panels feed BI*BJ tiles);
