@@ -15,7 +15,7 @@
  *     the library copies what it needs and owns every device allocation behind the opaque handle.
  *   - hyper-parameters cross the boundary in natural units (variance, lengthscale, noise variance);
  *     the positivity transforms stay in Python (reference: paramz Logexp, [GPy-recall]).
- *   - a handle is bound to one device and one HIP stream and is not thread-safe; distinct handles may
+ *   - a handle is bound to one device (and its own HIP streams) and is not thread-safe; distinct handles may
  *     be driven from distinct threads / processes (one process per GPU is the multi-GPU model).
  */
 #ifndef MFGP_H
@@ -52,14 +52,14 @@ typedef struct mfgp_kern_part {
  * algorithmic work of the two single-launch kernels the bench reports rooflines for. */
 typedef struct mfgp_timings {
     double kbuild_ms;    /* K(X,X)+noise lower-triangle build: ONE launch of mfgp_kbuild_tri_f64      */
-    double cholinv_ms;   /* recursive Cholesky + triangular inverse (leaf kernels + MFMA tile GEMMs)  */
+    double cholinv_ms;   /* blocked Cholesky + triangular inverse (leaf kernels + MFMA tile GEMMs)    */
     double solve_ms;     /* z = L^-1 y, alpha = L^-T z, log-det, quadratic form                        */
     double kinv_ms;      /* K^-1 = L^-T L^-1 lower triangle: ONE launch of the MFMA tile-GEMM kernel   */
     double grad_ms;      /* fused dNLML/dtheta reduction over the lower triangle                       */
     double predict_panel_ms; /* K(X*,X) panel + mean GEMV                                              */
     double predict_var_ms;   /* V = K(X*,X) L^-T (MFMA) + row sum of squares                           */
     double total_ms;     /* first event -> last event of the call                                       */
-    double kbuild_bytes; /* algorithmic bytes of the K-build launch (4*Np*(Np+128) B)      */
+    double kbuild_bytes; /* algorithmic bytes of the K-build launch (4*Np*(Np+64) B)       */
     double kinv_flops;   /* algorithmic flops of the K^-1 launch (Np^3/3)                               */
     double cholinv_flops;/* 2*Np^3/3                                                                    */
     int64_t n_launches;  /* kernel launches issued by the call                                          */
@@ -75,7 +75,7 @@ typedef struct mfgp_counters {
 
 /* ---- lifecycle --------------------------------------------------------------------------------- */
 
-/* create an engine on HIP device `device_id` (one stream). Fails loudly (<0) when no HIP device. */
+/* create an engine on HIP device `device_id`. Fails loudly (<0) when no HIP device. */
 int32_t mfgp_create(int32_t device_id, mfgp_handle** out);
 int32_t mfgp_destroy(mfgp_handle* h);
 /* text of the last error on this handle (or a global one when h == NULL); owned by the library */
