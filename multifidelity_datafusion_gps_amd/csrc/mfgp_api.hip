@@ -57,6 +57,7 @@ struct mfgp_handle {
     int ch_c = 0;
     double* hres = nullptr;  // pinned
     int* hinfo = nullptr;    // pinned
+    bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 1024 unless MFGP_STAGE_TIMING=1)
     std::vector<GemmTask> tasks;
     std::vector<Step> plan;         // cholinv
     Step kinv_step{}, predv_step{};
@@ -644,10 +645,14 @@ int32_t mfgp_create(int32_t device_id, mfgp_handle** out) {
     }
     for (auto& ev : h->ev) HIPCHK(h, hipEventCreate(&ev));
     HIPCHK(h, hipMalloc(&h->dparams, 32 * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->dres, 64 * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->dinfo, sizeof(int)));
-    HIPCHK(h, hipHostMalloc(&h->hres, 64 * sizeof(double)));
-    HIPCHK(h, hipHostMalloc(&h->hinfo, sizeof(int)));
+    // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
+    // pinned, device-mapped host memory: no copy kernel at the end of a call and no fill kernel for the status at its
+    // start (each costs ~5 us plus a gap; an evaluation at N <= 128 is ~75 us of GPU time in all)
+    HIPCHK(h, hipHostMalloc(&h->hres, 64 * sizeof(double), hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dres), h->hres, 0));
+    memset(h->hres, 0, 64 * sizeof(double));
+    h->dinfo = reinterpret_cast<int*>(h->dres + 30);   // the pivot status lives beside the results
+    h->hinfo = reinterpret_cast<int*>(h->hres + 30);
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device_id));
     char tmp[256];
@@ -679,8 +684,8 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->doffs) hipFree(h->doffs);
     if (h->dAug) hipFree(h->dAug);
     if (h->dtasks) hipFree(h->dtasks);
-    hipFree(h->dparams); hipFree(h->dres); hipFree(h->dinfo);
-    hipHostFree(h->hres); hipHostFree(h->hinfo);
+    hipFree(h->dparams);
+    hipHostFree(h->hres);
     for (auto& ev : h->ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
     if (h->stream2) hipStreamDestroy(h->stream2);
@@ -723,6 +728,8 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
     }
     const bool replan = (Np != h->Np);
     h->N = N; h->Np = Np; h->D = D; h->nblk = (int)(Np / NB);
+    h->stage_timing = Np >= 1024;
+    if (const char* e = getenv("MFGP_STAGE_TIMING")) h->stage_timing = atoi(e) != 0;
     HIPCHK(h, hipMemsetAsync(h->dX, 0, (size_t)Np * D * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->dY, 0, (size_t)Np * sizeof(double), h->stream));
     HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -800,30 +807,29 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
         const int rc_ = set_params(h, theta, noise, jitter);
         if (rc_) return rc_;
     }
-    HIPCHK(h, hipMemsetAsync(h->dinfo, 0, sizeof(int), s));
+    *h->hinfo = 0;   // (the previous call synchronised the stream)
     HIPCHK(h, hipEventRecord(h->ev[0], s));
     if (!prebuilt) {
         launch_kbuild_tri(s, h->spec, h->dX, h->dparams, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
         h->launches++;
     }
-    HIPCHK(h, hipEventRecord(h->ev[1], s));
+    const bool stages = h->stage_timing;   // an event record costs 6-8 us of stream time: per-stage stamps only where that is noise
+    if (stages) HIPCHK(h, hipEventRecord(h->ev[1], s));
     for (const Step& st : h->plan) run_step(h, st);
-    HIPCHK(h, hipEventRecord(h->ev[2], s));
+    if (stages) HIPCHK(h, hipEventRecord(h->ev[2], s));
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dY, h->dz, (int)h->Np, (int)h->Np, 0);       // z = X y
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dz, h->dalpha, (int)h->Np, (int)h->Np, 1);   // alpha = X^T z
     launch_finish_solve(s, h->dz, (int)h->Np, h->dlogdet, h->nblk, h->dres);
     h->launches += 3;
-    HIPCHK(h, hipEventRecord(h->ev[3], s));
+    if (stages || !want_grad) HIPCHK(h, hipEventRecord(h->ev[3], s));
     if (want_grad) {
         run_step(h, h->kinv_step);
-        HIPCHK(h, hipEventRecord(h->ev[4], s));
+        if (stages) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->dparams, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
         h->launches += 2;
         HIPCHK(h, hipEventRecord(h->ev[5], s));
     }
-    HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, 32 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->hinfo, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -833,15 +839,16 @@ static int finish_eval(mfgp_handle* h, bool want_grad) {
     HIPCHK(h, hipGetLastError());
     mfgp_timings& t = h->tm;
     memset(&t, 0, sizeof t);
-    t.kbuild_ms = ev_ms(h->ev[0], h->ev[1]);
-    t.cholinv_ms = ev_ms(h->ev[1], h->ev[2]);
-    t.solve_ms = ev_ms(h->ev[2], h->ev[3]);
-    t.total_ms = ev_ms(h->ev[0], h->ev[3]);
-    if (want_grad) {
-        t.kinv_ms = ev_ms(h->ev[3], h->ev[4]);
-        t.grad_ms = ev_ms(h->ev[4], h->ev[5]);
-        t.total_ms = ev_ms(h->ev[0], h->ev[5]);
+    if (h->stage_timing) {
+        t.kbuild_ms = ev_ms(h->ev[0], h->ev[1]);
+        t.cholinv_ms = ev_ms(h->ev[1], h->ev[2]);
+        t.solve_ms = ev_ms(h->ev[2], h->ev[3]);
+        if (want_grad) {
+            t.kinv_ms = ev_ms(h->ev[3], h->ev[4]);
+            t.grad_ms = ev_ms(h->ev[4], h->ev[5]);
+        }
     }
+    t.total_ms = ev_ms(h->ev[0], h->ev[want_grad ? 5 : 3]);
     const double np = (double)h->Np;
     t.kbuild_bytes = 4.0 * np * (np + 64.0);
     t.kinv_flops = np * np * np / 3.0;
@@ -973,7 +980,6 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     kdiag += prod + h->noise + h->jitter;
     launch_append_finish(s, h->buf[BUF_L], h->buf[BUF_S], (int)Np, n, h->dvec, h->dvec2, h->dz, kdiag, y_new, h->dres + 48);
     launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dz, h->dalpha, n + 1, n + 1, 1);
-    HIPCHK(h, hipMemcpyAsync(h->hres + 48, h->dres + 48, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     if (h->hres[51] != 0.0) {
@@ -1010,7 +1016,6 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
         launch_grad(s, h->spec, h->dX, h->dparams, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
         HIPCHK(h, hipEventRecord(h->ev[5], s));
-        HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, 32 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
         HIPCHK(h, hipGetLastError());
         h->tm.kinv_ms = ev_ms(h->ev[3], h->ev[4]);
