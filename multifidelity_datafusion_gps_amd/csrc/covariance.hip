@@ -135,7 +135,7 @@ __device__ __forceinline__ void factor_logderiv(int type, double inv_l2, const d
 
 // K of the 16 pairs: factor-major (runtime loop over factors, each re-accumulating its own r^2 from LDS:
 // a few FMAs, and it keeps everything in ~100 VGPRs with no private-memory arrays)
-__device__ __forceinline__ void cov_values(const KernSpecDev& sp, const double* params, const double* sxi,
+__device__ __forceinline__ void cov_values(const KernSpecDev& sp, const double* sxi,
                                            const double* sxj, int ty, int tx, double (&K)[16]) {
     double prod[16], r2[16], expo[16], varprod = 1.0;
 #pragma unroll
@@ -157,7 +157,7 @@ __device__ __forceinline__ void cov_values(const KernSpecDev& sp, const double* 
             cur = sp.term[f];
             any_rbf = false;
         }
-        const double var = params[2 * f], l = params[2 * f + 1];
+        const double var = sp.theta[2 * f], l = sp.theta[2 * f + 1];
         pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
         any_rbf = any_rbf || (sp.type[f] == MFGP_KERN_RBF);
         apply_factor(sp.type[f], var, 1.0 / (l * l), r2, prod, expo, varprod);
@@ -176,8 +176,7 @@ enum { MODE_TRI = 0, MODE_PANEL = 1, MODE_FULL = 2, MODE_ROWS = 3 };
 //              builds when K(X,X) is sharded by row blocks and all-gathered; bi is offset by `row_tile0`
 template <int MODE>
 __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const double* __restrict__ Xr,
-                                                       const double* __restrict__ Xc,
-                                                       const double* __restrict__ params, int N, int Np,
+                                                       const double* __restrict__ Xc, int N, int Np,
                                                        double* __restrict__ out, int ld, int row_tile0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sxi = smem;
@@ -201,8 +200,8 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const dou
     __syncthreads();
 
     double Kv[16];
-    cov_values(sp, params, sxi, sxj, ty, tx, Kv);
-    const double diag_add = (MODE == MODE_TRI || MODE == MODE_ROWS) ? (params[2 * sp.nf] + params[2 * sp.nf + 1]) : 0.0;
+    cov_values(sp, sxi, sxj, ty, tx, Kv);
+    const double diag_add = (MODE == MODE_TRI || MODE == MODE_ROWS) ? (sp.theta[2 * sp.nf] + sp.theta[2 * sp.nf + 1]) : 0.0;
 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -236,26 +235,26 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const dou
 
 static size_t kb_lds(int D) { return (size_t)2 * D * XP * sizeof(double); }
 
-void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X,
                        int N, int Np, double* A, int ld) {
     const int nt = Np / KT;
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_TRI>), dim3(nt * (nt + 1) / 2), dim3(256), kb_lds(spec.D), s,
-                       spec, X, X, params, N, Np, A, ld, 0);
+                       spec, X, X, N, Np, A, ld, 0);
 }
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
-                         const double* X, const double* params, int N, int Np, double* Kx, int ld) {
+                         const double* X, int N, int Np, double* Kx, int ld) {
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_PANEL>), dim3(Np / KT, Nsp / KT), dim3(256), kb_lds(spec.D), s,
-                       spec, Xs, X, params, N, Np, Kx, ld, 0);
+                       spec, Xs, X, N, Np, Kx, ld, 0);
 }
-void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
                         int N, int Np, double* out, int ld) {
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_FULL>), dim3(Np / KT, Np / KT), dim3(256), kb_lds(spec.D), s,
-                       spec, X, X, params, N, Np, out, ld, 0);
+                       spec, X, X, N, Np, out, ld, 0);
 }
-void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params, int N, int Np,
+void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, int N, int Np,
                         double* A, int ld, int row_begin, int row_end) {
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_ROWS>), dim3(Np / KT, (row_end - row_begin) / KT), dim3(256), kb_lds(spec.D), s,
-                       spec, X, X, params, N, Np, A, ld, row_begin / KT);
+                       spec, X, X, N, Np, A, ld, row_begin / KT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -269,7 +268,6 @@ void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X,
 constexpr int NSUM = 2 * MFGP_MAX_PARTS + 1;
 
 __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const double* __restrict__ X,
-                                                           const double* __restrict__ params,
                                                            const double* __restrict__ Kinv, int ld,
                                                            const double* __restrict__ alpha, int N,
                                                            double* __restrict__ partials) {
@@ -330,10 +328,10 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
             expo[e] = 0.0;
         }
         for (int f = f0; f < f1; ++f) {
-            const double l = params[2 * f + 1];
+            const double l = sp.theta[2 * f + 1];
             pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
             any_rbf = any_rbf || (sp.type[f] == MFGP_KERN_RBF);
-            apply_factor(sp.type[f], params[2 * f], 1.0 / (l * l), r2, prod, expo, varprod);
+            apply_factor(sp.type[f], sp.theta[2 * f], 1.0 / (l * l), r2, prod, expo, varprod);
         }
         finish_term(prod, expo, varprod, any_rbf);
         double sv = 0.0;
@@ -343,7 +341,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
             sv += prod[e];
         }
         for (int f = f0; f < f1; ++f) {
-            const double l = params[2 * f + 1];
+            const double l = sp.theta[2 * f + 1];
             double g[16];
             pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
             factor_logderiv(sp.type[f], 1.0 / (l * l), r2, g);
@@ -366,7 +364,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
     }
 }
 
-__global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp, const double* __restrict__ params,
+__global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp,
                                                             const double* __restrict__ partials, int nblocks,
                                                             double* __restrict__ out) {
     __shared__ double red[256];
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp, cons
     if (tid == 0) {
         const double S = red[0];
         if (i == NSUM - 1) out[2 * sp.nf] = -0.5 * S;
-        else if (i / 2 < sp.nf) out[i] = -0.5 * S / params[i];  // params[2f]=var_f, params[2f+1]=l_f
+        else if (i / 2 < sp.nf) out[i] = -0.5 * S / sp.theta[i];  // theta[2f]=var_f, theta[2f+1]=l_f
     }
 }
 
@@ -392,18 +390,18 @@ int grad_num_partials(int Np) {
     return nt * (nt + 1) / 2;
 }
 
-void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
                  const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
                  double* out) {
     const int nb = grad_num_partials(Np);
     const size_t lds = kb_lds(spec.D) + (size_t)256 * NSUM * sizeof(double);
-    hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, params, Kinv, ld, alpha, N,
+    hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, Kinv, ld, alpha, N,
                        partials);
-    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(NSUM), dim3(256), 0, s, spec, params, partials, nb, out);
+    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(NSUM), dim3(256), 0, s, spec, partials, nb, out);
 }
 
 // var[i] = max(kss - ss[i], 1e-15) + add,  kss = sum_terms prod var_f  (GPy Kdiag of a stationary kernel)
-__global__ void mfgp_finish_var_f64(KernSpecDev sp, const double* __restrict__ params,
+__global__ void mfgp_finish_var_f64(KernSpecDev sp,
                                     const double* __restrict__ ss, double* __restrict__ var, int n, double add) {
     double kss = 0.0, prod = 1.0;
     int cur = sp.term[0];
@@ -413,7 +411,7 @@ __global__ void mfgp_finish_var_f64(KernSpecDev sp, const double* __restrict__ p
             prod = 1.0;
             cur = sp.term[f];
         }
-        prod *= params[2 * f];
+        prod *= sp.theta[2 * f];
     }
     kss += prod;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -424,9 +422,9 @@ __global__ void mfgp_finish_var_f64(KernSpecDev sp, const double* __restrict__ p
     }
 }
 
-void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* params, const double* ss,
+void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* ss,
                        double* var, int n, double add) {
-    hipLaunchKernelGGL(mfgp_finish_var_f64, dim3((n + 255) / 256), dim3(256), 0, s, spec, params, ss, var, n, add);
+    hipLaunchKernelGGL(mfgp_finish_var_f64, dim3((n + 255) / 256), dim3(256), 0, s, spec, ss, var, n, add);
 }
 
 }  // namespace mfgp

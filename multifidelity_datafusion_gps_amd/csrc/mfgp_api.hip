@@ -46,7 +46,7 @@ struct mfgp_handle {
     int D = 0, nblk = 0;
     double* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     double *dX = nullptr, *dXs = nullptr, *dY = nullptr, *dz = nullptr, *dalpha = nullptr;
-    double *dparams = nullptr, *dlogdet = nullptr, *dres = nullptr, *dpart = nullptr, *dvec = nullptr,
+    double *dlogdet = nullptr, *dres = nullptr, *dpart = nullptr, *dvec = nullptr,
            *dvec2 = nullptr;
     int* dinfo = nullptr;
     GemmTask* dtasks = nullptr;
@@ -644,7 +644,6 @@ int32_t mfgp_create(int32_t device_id, mfgp_handle** out) {
         }
     }
     for (auto& ev : h->ev) HIPCHK(h, hipEventCreate(&ev));
-    HIPCHK(h, hipMalloc(&h->dparams, 32 * sizeof(double)));
     // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
     // pinned, device-mapped host memory: no copy kernel at the end of a call and no fill kernel for the status at its
     // start (each costs ~5 us plus a gap; an evaluation at N <= 128 is ~75 us of GPU time in all)
@@ -684,7 +683,6 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->doffs) hipFree(h->doffs);
     if (h->dAug) hipFree(h->dAug);
     if (h->dtasks) hipFree(h->dtasks);
-    hipFree(h->dparams);
     hipHostFree(h->hres);
     for (auto& ev : h->ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
@@ -784,18 +782,18 @@ static int check_ready(mfgp_handle* h, const char* who) {
 
 // enqueue K-build + cholinv + solve (+ K^-1 + gradient); no host sync
 static int set_params(mfgp_handle* h, const double* theta, double noise, double jitter) {
+    // the hyper-parameters ride in the kernel arguments (KernSpecDev::theta): nothing to upload
     const int nf = h->spec.nf;
     for (int i = 0; i < 2 * nf; ++i) {
         if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "parameters must be positive and finite");
         h->theta[i] = theta[i];
-        h->hres[32 + i] = theta[i];
+        h->spec.theta[i] = theta[i];
     }
     if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "noise and jitter must be >= 0");
     h->noise = noise; h->jitter = jitter;
     h->params_set = true;
-    h->hres[32 + 2 * nf] = noise;
-    h->hres[32 + 2 * nf + 1] = jitter;
-    HIPCHK(h, hipMemcpyAsync(h->dparams, h->hres + 32, (2 * nf + 2) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->spec.theta[2 * nf] = noise;
+    h->spec.theta[2 * nf + 1] = jitter;
     return 0;
 }
 
@@ -810,7 +808,7 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     *h->hinfo = 0;   // (the previous call synchronised the stream)
     HIPCHK(h, hipEventRecord(h->ev[0], s));
     if (!prebuilt) {
-        launch_kbuild_tri(s, h->spec, h->dX, h->dparams, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
+        launch_kbuild_tri(s, h->spec, h->dX, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
         h->launches++;
     }
     const bool stages = h->stage_timing;   // an event record costs 6-8 us of stream time: per-stage stamps only where that is noise
@@ -825,7 +823,7 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     if (want_grad) {
         run_step(h, h->kinv_step);
         if (stages) HIPCHK(h, hipEventRecord(h->ev[4], s));
-        launch_grad(s, h->spec, h->dX, h->dparams, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
+        launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
         h->launches += 2;
         HIPCHK(h, hipEventRecord(h->ev[5], s));
@@ -908,7 +906,7 @@ int32_t mfgp_kbuild_rows(mfgp_handle* h, const double* theta, double noise, doub
     HIPCHK(h, hipSetDevice(h->device));
     rc = set_params(h, theta, noise, jitter);
     if (rc) return rc;
-    launch_kbuild_rows(h->stream, h->spec, h->dX, h->dparams, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np,
+    launch_kbuild_rows(h->stream, h->spec, h->dX, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np,
                        (int)row_begin, (int)row_end);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
@@ -967,7 +965,7 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     h->hres[56] = y_new;
     HIPCHK(h, hipMemcpyAsync(h->dY + n, h->hres + 56, sizeof(double), hipMemcpyHostToDevice, s));
     // k = K(x_new, X[0:n]) -> row 0 of W ; l = X k ; w = X^T l
-    launch_kbuild_panel(s, h->spec, h->dXs, 128, h->dX, h->dparams, n, (int)Np, h->buf[BUF_W], (int)Np);
+    launch_kbuild_panel(s, h->spec, h->dXs, 128, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np);
     HIPCHK(h, hipMemsetAsync(h->dvec, 0, (size_t)Np * sizeof(double), s));
     launch_rowdot(s, h->buf[BUF_S], (int)Np, h->buf[BUF_W], h->dvec, n, (int)Np, 0);
     launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dvec, h->dvec2, n, n, 1);
@@ -1013,7 +1011,7 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
         HIPCHK(h, hipEventRecord(h->ev[3], s));
         run_step(h, h->kinv_step);
         HIPCHK(h, hipEventRecord(h->ev[4], s));
-        launch_grad(s, h->spec, h->dX, h->dparams, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
+        launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
         HIPCHK(h, hipEventRecord(h->ev[5], s));
         HIPCHK(h, hipStreamSynchronize(s));
@@ -1064,7 +1062,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         if (rc) return rc;
     }
     HIPCHK(h, hipEventRecord(h->ev[6], s));
-    launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, h->dparams, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
+    launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
     launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, h->dvec, rows_p, (int)Np, 2);
     h->launches += 2;
     HIPCHK(h, hipEventRecord(h->ev[7], s));
@@ -1075,7 +1073,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
         else run_step(h, h->predv_step);
         launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
-        launch_finish_var(s, h->spec, h->dparams, h->dvec2, h->dvec2, vrows, include_noise ? h->noise : 0.0);
+        launch_finish_var(s, h->spec, h->dvec2, h->dvec2, vrows, include_noise ? h->noise : 0.0);
         h->launches += 2;
         HIPCHK(h, hipEventRecord(h->ev[8], s));
         HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1161,7 +1159,7 @@ static int chain_lf_means(mfgp_handle* lf, const double* Xhost, int64_t rows, co
         const int n = (int)std::min(Np, T - t0);
         const int n_p = (n + NB - 1) / NB * NB;
         launch_stencil_rows(s, lf->dXc, lf->doffs, d, c, t0, n, n_p, lf->dXs);
-        launch_kbuild_panel(s, lf->spec, lf->dXs, n_p, lf->dX, lf->dparams, (int)lf->N, (int)Np, lf->buf[BUF_W], (int)Np);
+        launch_kbuild_panel(s, lf->spec, lf->dXs, n_p, lf->dX, (int)lf->N, (int)Np, lf->buf[BUF_W], (int)Np);
         // the padded rows n..n_p of the mean land in dvec's tail, never in dm: write through dvec, then copy
         launch_rowdot(s, lf->buf[BUF_W], (int)Np, lf->dalpha, lf->dvec, n_p, (int)Np, 2);
         HIPCHK(lf, hipMemcpyAsync(lf->dm + t0, lf->dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1270,7 +1268,7 @@ int32_t mfgp_get_K(mfgp_handle* h, double* out) {
     const int64_t N = h->N;
     double* d = nullptr;
     HIPCHK(h, hipMalloc(&d, (size_t)N * N * sizeof(double)));
-    launch_kbuild_full(h->stream, h->spec, h->dX, h->dparams, (int)N, (int)h->Np, d, (int)N);
+    launch_kbuild_full(h->stream, h->spec, h->dX, (int)N, (int)h->Np, d, (int)N);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, d, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(h, hipFree(d));

@@ -45,6 +45,8 @@ static_assert(sizeof(GemmTask) == 64, "GemmTask layout");
 
 // kernel-structure descriptor passed by value to the covariance kernels
 struct KernSpecDev {
+    double theta[2 * MFGP_MAX_PARTS + 2];   // [var_f, len_f]*, then noise, jitter: travels with the kernel arguments
+                                            // (no parameter upload per evaluation)
     int32_t nf;                       // number of factors
     int32_t D;                        // columns of X
     int32_t type[MFGP_MAX_PARTS];
@@ -76,16 +78,16 @@ void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld
 
 // covariance builders
 //   tri: lower-triangle 64x64 tiles of Ky = K + (noise+jitter) I over padded Np (identity padding)
-void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X,
                        int N, int Np, double* A, int ld);
 //   panel: Kx[r][c] = k(Xs[r], X[c]) for r < Nsp, c < Np (0 for padded columns c >= N)
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
-                         const double* X, const double* params, int N, int Np, double* Kx, int ld);
+                         const double* X, int N, int Np, double* Kx, int ld);
 //   rows [row_begin, row_end) (multiples of 64) of Ky, all Np columns, written at their place in A
-void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params, int N, int Np,
+void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, int N, int Np,
                         double* A, int ld, int row_begin, int row_end);
 //   full symmetric K without noise into out (N x N, ld = N) for parity read-back
-void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
                         int N, int Np, double* out, int ld);
 
 // vector ops
@@ -100,12 +102,12 @@ void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nr
 void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* logdet_part, int nblk,
                          double* scalars);
 //   gradient: partial sums over lower-triangle 64x64 tiles; out[2*nf+1] (natural-parameter gradient of NLML)
-void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X, const double* params,
+void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
                  const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
                  double* out);
 int grad_num_partials(int Np);
-//   var[i] = max(kss - ss[i], 1e-15) + add ; kss from params
-void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* params, const double* ss,
+//   var[i] = max(kss - ss[i], 1e-15) + add ; kss from spec.theta
+void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* ss,
                        double* var, int n, double add);
 
 // level chaining: stencil stack rows and the augmented-row assembly (vecops.hip)
