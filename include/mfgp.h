@@ -172,7 +172,8 @@ int32_t mfgp_dbg_probe(mfgp_handle* h, double* mfma_f64_tflops, double* copy_gbs
  * c = 0: 1 wave/SIMD x 8 accumulators, 1: 2 waves/SIMD, 2: 4 waves/SIMD, 3: 1 wave/SIMD x 1 (dependent chain);
  * out[12..15] = v_fma_f64 VALU TFLOP/s at 2 / 4 waves per SIMD, and VALU+MFMA mixed-issue totals (2 / 4 waves);
  * out[16..17] = v_fma_f64 with three distinct VGPR operands per FMA (the register-tiled GEMM pattern). out[18] = bare int8 MFMA Tops/s,
- * out[19] = bare bf16 MFMA TFLOP/s (sizing an fp64 emulation on the low-precision pipes). out has 20 entries. */
+ * out[19] = bare bf16 MFMA TFLOP/s (sizing an fp64 emulation on the low-precision pipes); out[20], out[21] = write-only / read-only
+ * HBM stream GB/s. out has 24 entries. */
 int32_t mfgp_dbg_probe_detail(mfgp_handle* h, double* out16);
 
 #ifdef __cplusplus

@@ -334,7 +334,7 @@ class Engine:
         return L, X, ld.value, rc
 
     def dbg_probe_detail(self):
-        out = np.zeros(20)
+        out = np.zeros(24)
         self._check(self._lib.mfgp_dbg_probe_detail(self._h, _dptr(out)), "mfgp_dbg_probe_detail")
         names = ["1w/SIMD x8acc", "2w/SIMD x8acc", "4w/SIMD x8acc", "1w/SIMD x1acc"]
         d = {n: dict(tflops=out[3 * i], cycles_per_mfma=out[3 * i + 1], clock_ghz=out[3 * i + 2])
@@ -344,6 +344,8 @@ class Engine:
         d["valu_fma_f64_three_vgpr_operands_tflops"] = {"2w/SIMD": out[16], "4w/SIMD": out[17]}
         d["mfma_i8_tops"] = out[18]        # v_mfma_i32_16x16x64_i8, bare loop
         d["mfma_bf16_tflops"] = out[19]    # v_mfma_f32_16x16x32_bf16, bare loop
+        d["hbm_write_only_gbs"] = out[20]
+        d["hbm_read_only_gbs"] = out[21]
         return d
 
     def dbg_probe(self):

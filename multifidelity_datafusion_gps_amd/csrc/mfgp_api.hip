@@ -1402,6 +1402,7 @@ int32_t mfgp_dbg_probe_detail(mfgp_handle* h, double* out12) {
     run_probe_detail(h->stream, out12);
     run_probe_valu(h->stream, out12 + 12);
     run_probe_lowp(h->stream, out12 + 18);
+    run_probe_bw(h->stream, out12 + 20);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

@@ -120,6 +120,7 @@ void launch_assemble_aug(hipStream_t s, const double* Xc, const double* m, int r
 void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs);
 void run_probe_detail(hipStream_t s, double* out12);
 void run_probe_valu(hipStream_t s, double* out4);
-void run_probe_lowp(hipStream_t s, double* out2);   // [0] int8 MFMA Tops/s, [1] bf16 MFMA TFLOP/s (bare loops)
+void run_probe_lowp(hipStream_t s, double* out2);
+void run_probe_bw(hipStream_t s, double* out2);     // [0] write-only, [1] read-only HBM stream GB/s (1 GiB, 16 B per lane)   // [0] int8 MFMA Tops/s, [1] bf16 MFMA TFLOP/s (bare loops)
 
 }  // namespace mfgp

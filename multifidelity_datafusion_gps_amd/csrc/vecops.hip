@@ -196,6 +196,46 @@ __global__ __launch_bounds__(256) void mfgp_probe_copy(const d2_t* __restrict__ 
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// write-only and read-only HBM streams (the K build is a pure write stream, the skinny variance product a pure read)
+__global__ __launch_bounds__(256) void mfgp_probe_write(d2_t* __restrict__ dst, int64_t n, double v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (d2_t){v, v + (double)i};
+}
+__global__ __launch_bounds__(256) void mfgp_probe_read(const d2_t* __restrict__ src, int64_t n, double* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (; i < n; i += stride) { const d2_t v = src[i]; s += v.x + v.y; }
+    if (s == 1.2345e300) out[0] = s;
+}
+void run_probe_bw(hipStream_t s, double* out2) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int64_t bytes = (int64_t)1 << 30;
+    d2_t* buf = nullptr;
+    double* dummy = nullptr;
+    hipMalloc(&buf, bytes);
+    hipMalloc(&dummy, 64);
+    float ms = 0.f;
+    for (int which = 0; which < 2; ++which) {
+        for (int rep = 0; rep < 6; ++rep) {
+            if (rep == 1) hipEventRecord(e0, s);
+            if (which == 0) hipLaunchKernelGGL(mfgp_probe_write, dim3(4096), dim3(256), 0, s, buf, bytes / 16, 1.0);
+            else hipLaunchKernelGGL(mfgp_probe_read, dim3(4096), dim3(256), 0, s, buf, bytes / 16, dummy);
+        }
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        out2[which] = 5.0 * (double)bytes / (ms * 1e-3) / 1e9;
+    }
+    hipFree(buf);
+    hipFree(dummy);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+}
+
 // detailed MFMA probe: per-wave shader cycles (s_memtime) and 100 MHz real time around the loop
 template <int NACC>
 __global__ __launch_bounds__(256) void mfgp_probe_mfma_detail(unsigned long long* out, int iters) {
