@@ -165,17 +165,6 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
                          int32_t N, int32_t K, double alpha, double beta, int32_t tile);
 /* Cholesky + inverse of one SPD 128x128 block through the leaf kernel: Lout, Xout are 128x128. */
 int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xout, double* logdet_half);
-/* peak probes: returns achieved TFLOP/s of a bare v_mfma_f64_16x16x4_f64 loop and GB/s of a
- * 1 GiB device copy (used by bench.py to sanity-check the roofline denominators). */
-int32_t mfgp_dbg_probe(mfgp_handle* h, double* mfma_f64_tflops, double* copy_gbs);
-/* out12[3*c + {0,1,2}] = {TFLOP/s, shader cycles per v_mfma_f64_16x16x4_f64 per wave, shader clock GHz} for
- * c = 0: 1 wave/SIMD x 8 accumulators, 1: 2 waves/SIMD, 2: 4 waves/SIMD, 3: 1 wave/SIMD x 1 (dependent chain);
- * out[12..15] = v_fma_f64 VALU TFLOP/s at 2 / 4 waves per SIMD, and VALU+MFMA mixed-issue totals (2 / 4 waves);
- * out[16..17] = v_fma_f64 with three distinct VGPR operands per FMA (the register-tiled GEMM pattern). out[18] = bare int8 MFMA Tops/s,
- * out[19] = bare bf16 MFMA TFLOP/s (sizing an fp64 emulation on the low-precision pipes); out[20], out[21] = write-only / read-only
- * HBM stream GB/s. out has 24 entries. */
-int32_t mfgp_dbg_probe_detail(mfgp_handle* h, double* out16);
-
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters",
-    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_probe", "mfgp_dbg_probe_detail",
+    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf",
 ]
 
 
@@ -108,8 +108,6 @@ def load_library(path=None):
         "mfgp_get_counters": (i32, [H, ctypes.POINTER(Counters), i32]),
         "mfgp_dbg_gemm_nt": (i32, [H, dp, dp, dp, i32, i32, i32, f64, f64, i32]),
         "mfgp_dbg_leaf": (i32, [H, dp, dp, dp, dp]),
-        "mfgp_dbg_probe": (i32, [H, dp, dp]),
-        "mfgp_dbg_probe_detail": (i32, [H, dp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -332,23 +330,3 @@ class Engine:
         if rc < 0:
             self._check(rc, "mfgp_dbg_leaf")
         return L, X, ld.value, rc
-
-    def dbg_probe_detail(self):
-        out = np.zeros(24)
-        self._check(self._lib.mfgp_dbg_probe_detail(self._h, _dptr(out)), "mfgp_dbg_probe_detail")
-        names = ["1w/SIMD x8acc", "2w/SIMD x8acc", "4w/SIMD x8acc", "1w/SIMD x1acc"]
-        d = {n: dict(tflops=out[3 * i], cycles_per_mfma=out[3 * i + 1], clock_ghz=out[3 * i + 2])
-             for i, n in enumerate(names)}
-        d["valu_fma_f64_tflops"] = {"2w/SIMD": out[12], "4w/SIMD": out[13]}
-        d["valu_plus_mfma_tflops"] = {"2w/SIMD": out[14], "4w/SIMD": out[15]}
-        d["valu_fma_f64_three_vgpr_operands_tflops"] = {"2w/SIMD": out[16], "4w/SIMD": out[17]}
-        d["mfma_i8_tops"] = out[18]        # v_mfma_i32_16x16x64_i8, bare loop
-        d["mfma_bf16_tflops"] = out[19]    # v_mfma_f32_16x16x32_bf16, bare loop
-        d["hbm_write_only_gbs"] = out[20]
-        d["hbm_read_only_gbs"] = out[21]
-        return d
-
-    def dbg_probe(self):
-        a, b = ctypes.c_double(), ctypes.c_double()
-        self._check(self._lib.mfgp_dbg_probe(self._h, ctypes.byref(a), ctypes.byref(b)), "mfgp_dbg_probe")
-        return a.value, b.value

@@ -30,6 +30,26 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+PROBE_SRC = os.path.join(os.path.dirname(HERE), "tools", "probes", "probes.hip")
+PROBE_LIB = os.path.join(os.path.dirname(HERE), "tools", "probes", "libmfgp_probes.so")
+
+
+def build_probes(force=False, verbose=False):
+    """tools/probes/libmfgp_probes.so: hardware probes for tests / tools (NOT part of the product library)"""
+    if not os.path.exists(PROBE_SRC):
+        return None
+    if not force and os.path.exists(PROBE_LIB) and os.path.getmtime(PROBE_LIB) >= os.path.getmtime(PROBE_SRC):
+        return PROBE_LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", PROBE_LIB, PROBE_SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libmfgp_probes.so")
+    return PROBE_LIB
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

@@ -13,6 +13,7 @@
 // 16-byte-chunk XOR swizzle (chunk ^= row & 15) so that the MFMA fragment reads (16 rows x 2 k per
 // 32-lane group, ds_read_b64) are bank-conflict free without padding -> MFMA.  LDS is double
 // buffered: the global loads of K-step t+1 are in flight while step t is on the matrix cores.
+#include <mutex>
 #include "mfgp_internal.h"
 
 namespace mfgp {
@@ -222,15 +223,18 @@ void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, con
     static const gemm_kernel_t table[3][2] = {{mfgp_gemm_nt_f64_t128, mfgp_gemm_nt_f64_t64},
                                               {mfgp_kinv_syrk_f64, mfgp_kinv_syrk_f64_t64},
                                               {mfgp_predvar_f64, mfgp_predvar_f64_t64}};
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function; restart threads launch
+    // concurrently (engine.py start_background_restarts), so the first launch on each device is serialised
+    static std::once_flag attr_once[MFGP_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(attr_once[dev & (MFGP_MAX_DEVICES - 1)], [] {
         for (int r = 0; r < 3; ++r)
             for (int t = 0; t < 2; ++t)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[r][t]),
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)gemm_lds_bytes(t == 0 ? 128 : 64));
-        attr_set = true;
-    }
+    });
     if (role == 3 && tile == 64) {   // serial-chain step: slim workgroups that co-reside with the bulk update
         hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain, dim3(ntasks), dim3(GEMM_THREADS), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
                            C, C2, ld);

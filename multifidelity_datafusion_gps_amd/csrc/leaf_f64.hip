@@ -15,6 +15,7 @@
 //     wave 0 factorises the next diagonal block WHILE waves 1-7 finish the rest of the update.
 // Phase 2 inverts in place: the eight 16x16 diagonal inverses are already there, the rest is assembled recursively
 // (X21 = -X22 (L21 X11) over 16 -> 32 -> 64 -> 128) on MFMA.
+#include <mutex>
 #include "mfgp_internal.h"
 
 namespace mfgp {
@@ -291,12 +292,13 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps) {
     constexpr size_t lds = (size_t)(128 * LP + SC_SIZE) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once[MFGP_MAX_DEVICES];   // per device, thread-safe (see launch_gemm)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(attr_once[dev & (MFGP_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_cholinv_f64),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(1), dim3(LEAF_THREADS), lds, s, A, Lout, S, ld, blk,
                        logdet_part, info, stamps);
 }

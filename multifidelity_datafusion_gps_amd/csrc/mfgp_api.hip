@@ -54,7 +54,7 @@ struct mfgp_handle {
     int xs_cap_rows = 0, xs_cap_D = 0;
     double *dXc = nullptr, *dm = nullptr, *doffs = nullptr, *dAug = nullptr;  // level chaining scratch
     int64_t ch_rows = 0;
-    int ch_c = 0;
+    int ch_c = 0, ch_D = 0;             // the chain scratch is sized for (ch_rows, ch_c) at input width ch_D
     double* hres = nullptr;  // pinned
     int* hinfo = nullptr;    // pinned
     bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 1024 unless MFGP_STAGE_TIMING=1)
@@ -69,7 +69,7 @@ struct mfgp_handle {
     double noise = 0, jitter = 0;
     double quad = 0, logdet = 0;
     double grad[2 * MFGP_MAX_PARTS + 1] = {0};
-    hipEvent_t ev[10];
+    hipEvent_t ev[10] = {};
     mfgp_timings tm{};
     mfgp_counters cum{};
     int64_t launches = 0;
@@ -609,6 +609,8 @@ extern "C" {
 
 const char* mfgp_last_error(mfgp_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
+static int create_body(mfgp_handle* h, int device_id);
+
 int32_t mfgp_create(int32_t device_id, mfgp_handle** out) {
     if (!out) return fail(nullptr, -1, "mfgp_create: out is NULL");
     int ndev = 0;
@@ -619,6 +621,17 @@ int32_t mfgp_create(int32_t device_id, mfgp_handle** out) {
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, -1, "mfgp_create: bad device id");
     mfgp_handle* h = new mfgp_handle();
     h->device = device_id;
+    const int rc = create_body(h, device_id);
+    if (rc != 0) {   // report through the global slot (the caller never sees this handle) and release what was made
+        g_err = "mfgp_create: " + h->err;
+        mfgp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+static int create_body(mfgp_handle* h, int device_id) {
     HIPCHK(h, hipSetDevice(device_id));
     int prio_lo = 0, prio_hi = 0;  // lo = least urgent (numerically greatest), hi = most urgent
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -657,7 +670,6 @@ int32_t mfgp_create(int32_t device_id, mfgp_handle** out) {
     char tmp[256];
     snprintf(tmp, sizeof tmp, "mfgp_hip %s %s CUs=%d", prop.gcnArchName, prop.name, prop.multiProcessorCount);
     h->info_str = tmp;
-    *out = h;
     return 0;
 }
 
@@ -675,7 +687,7 @@ static void free_mats(mfgp_handle* h) {
 int32_t mfgp_destroy(mfgp_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    if (h->stream) hipStreamSynchronize(h->stream);
     free_mats(h);
     if (h->dXs) hipFree(h->dXs);
     if (h->dXc) hipFree(h->dXc);
@@ -683,11 +695,11 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->doffs) hipFree(h->doffs);
     if (h->dAug) hipFree(h->dAug);
     if (h->dtasks) hipFree(h->dtasks);
-    hipHostFree(h->hres);
-    for (auto& ev : h->ev) hipEventDestroy(ev);
+    if (h->hres) hipHostFree(h->hres);
+    for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
     if (h->stream2) hipStreamDestroy(h->stream2);
-    hipStreamDestroy(h->stream);
+    if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
@@ -714,7 +726,11 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
     const int64_t Np = (N + NB - 1) / NB * NB;
     if (Np > h->cap || D != h->D) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        const int64_t cap = std::max(Np, h->cap);
+        // growth is geometric (x1.25, rounded to the block) once a handle has to grow: an adaptation run that adds one
+        // row per step (src/abstractMFGP.py:320,354) would otherwise free and re-allocate the four Np^2 buffers at
+        // every 128-row boundary (N_hf 512 -> 8192: 60 times; now 13)
+        int64_t cap = std::max(Np, h->cap);
+        if (h->cap > 0 && Np > h->cap) cap = std::max(Np, (h->cap + h->cap / 4 + NB - 1) / NB * NB);
         free_mats(h);
         for (auto& b : h->buf) HIPCHK(h, hipMalloc(&b, (size_t)cap * cap * sizeof(double)));
         HIPCHK(h, hipMalloc(&h->dX, (size_t)cap * D * sizeof(double)));
@@ -951,7 +967,8 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     hipStream_t s = h->stream;
     const int n = (int)h->N, D = h->D;
     const int64_t Np = h->Np;
-    // stage the new row (host -> X[n], and as a 128-row zero-padded panel operand)
+    // stage the new row as a 128-row zero-padded panel operand; X[n] / Y[n] are written by the finishing kernel, and only
+    // if the extension is positive definite (a rejected append leaves the handle's data untouched)
     if (128 > h->xs_cap_rows || D != h->xs_cap_D) {
         HIPCHK(h, hipStreamSynchronize(s));
         if (h->dXs) HIPCHK(h, hipFree(h->dXs));
@@ -961,9 +978,6 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     }
     HIPCHK(h, hipMemsetAsync(h->dXs, 0, (size_t)128 * D * sizeof(double), s));
     HIPCHK(h, hipMemcpyAsync(h->dXs, x_new, (size_t)D * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->dX + (size_t)n * D, x_new, (size_t)D * sizeof(double), hipMemcpyHostToDevice, s));
-    h->hres[56] = y_new;
-    HIPCHK(h, hipMemcpyAsync(h->dY + n, h->hres + 56, sizeof(double), hipMemcpyHostToDevice, s));
     // k = K(x_new, X[0:n]) -> row 0 of W ; l = X k ; w = X^T l
     launch_kbuild_panel(s, h->spec, h->dXs, 128, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np);
     HIPCHK(h, hipMemsetAsync(h->dvec, 0, (size_t)Np * sizeof(double), s));
@@ -976,7 +990,8 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
         prod *= h->theta[2 * f];
     }
     kdiag += prod + h->noise + h->jitter;
-    launch_append_finish(s, h->buf[BUF_L], h->buf[BUF_S], (int)Np, n, h->dvec, h->dvec2, h->dz, kdiag, y_new, h->dres + 48);
+    launch_append_finish(s, h->buf[BUF_L], h->buf[BUF_S], (int)Np, n, h->dvec, h->dvec2, h->dz, kdiag, y_new, h->dres + 48,
+                         h->dX, h->dXs, D, h->dY);
     launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dz, h->dalpha, n + 1, n + 1, 1);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
@@ -1125,7 +1140,7 @@ int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double*
 // ---- device-resident level chaining ------------------------------------------------------
 static int ensure_chain(mfgp_handle* lf, int64_t rows, int c) {
     const int d = lf->D;
-    if (rows > lf->ch_rows || c > lf->ch_c) {
+    if (rows > lf->ch_rows || c > lf->ch_c || d != lf->ch_D) {   // (a handle reused at another input width re-allocates)
         HIPCHK(lf, hipStreamSynchronize(lf->stream));
         if (lf->dXc) HIPCHK(lf, hipFree(lf->dXc));
         if (lf->dm) HIPCHK(lf, hipFree(lf->dm));
@@ -1134,6 +1149,7 @@ static int ensure_chain(mfgp_handle* lf, int64_t rows, int c) {
         lf->dXc = lf->dm = lf->doffs = lf->dAug = nullptr;
         lf->ch_rows = std::max(rows, lf->ch_rows);
         lf->ch_c = std::max(c, lf->ch_c);
+        lf->ch_D = d;
         HIPCHK(lf, hipMalloc(&lf->dXc, (size_t)lf->ch_rows * d * sizeof(double)));
         HIPCHK(lf, hipMalloc(&lf->dm, (size_t)lf->ch_rows * lf->ch_c * sizeof(double)));
         HIPCHK(lf, hipMalloc(&lf->doffs, (size_t)lf->ch_c * d * sizeof(double)));
@@ -1386,25 +1402,6 @@ int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xou
     HIPCHK(h, hipMemcpy(&info, di, 4, hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dL); hipFree(dS); hipFree(dl); hipFree(di);
     return info;
-}
-
-int32_t mfgp_dbg_probe(mfgp_handle* h, double* mfma_f64_tflops, double* copy_gbs) {
-    if (!h || !mfma_f64_tflops || !copy_gbs) return fail(h, -1, "mfgp_dbg_probe: NULL");
-    HIPCHK(h, hipSetDevice(h->device));
-    run_probe(h->stream, mfma_f64_tflops, copy_gbs);
-    HIPCHK(h, hipGetLastError());
-    return 0;
-}
-
-int32_t mfgp_dbg_probe_detail(mfgp_handle* h, double* out12) {
-    if (!h || !out12) return fail(h, -1, "mfgp_dbg_probe_detail: NULL");
-    HIPCHK(h, hipSetDevice(h->device));
-    run_probe_detail(h->stream, out12);
-    run_probe_valu(h->stream, out12 + 12);
-    run_probe_lowp(h->stream, out12 + 18);
-    run_probe_bw(h->stream, out12 + 20);
-    HIPCHK(h, hipGetLastError());
-    return 0;
 }
 
 }  // extern "C"

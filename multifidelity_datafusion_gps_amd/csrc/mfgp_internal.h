@@ -10,6 +10,7 @@ namespace mfgp {
 
 constexpr int NB = 128;  // leaf block = padding granule = largest GEMM tile edge
 constexpr int BK = 32;   // K-step of the tile GEMM (doubles)
+constexpr int MFGP_MAX_DEVICES = 16;   // (power of two) per-device one-time launch setup slots
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -95,7 +96,7 @@ void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
                    int ncols, int mode);
 void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
-                          double kdiag, double y_new, double* out);
+                          double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y);
 //   rowsumsq[i] = sum_{k < ncols} M[i][k]^2
 void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols);
 //   scalars[0] = sum z^2 ; scalars[1] = 2*sum logdet_part ; (single small block)
@@ -115,12 +116,5 @@ void launch_stencil_rows(hipStream_t s, const double* Xc, const double* offs, in
                          double* T);
 void launch_assemble_aug(hipStream_t s, const double* Xc, const double* m, int rows, int rows_p, int d, int c,
                          double* out, int ld);
-
-// probes
-void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs);
-void run_probe_detail(hipStream_t s, double* out12);
-void run_probe_valu(hipStream_t s, double* out4);
-void run_probe_lowp(hipStream_t s, double* out2);
-void run_probe_bw(hipStream_t s, double* out2);     // [0] write-only, [1] read-only HBM stream GB/s (1 GiB, 16 B per lane)   // [0] int8 MFMA Tops/s, [1] bf16 MFMA TFLOP/s (bare loops)
 
 }  // namespace mfgp

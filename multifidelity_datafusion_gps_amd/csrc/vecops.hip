@@ -73,10 +73,14 @@ __global__ __launch_bounds__(256) void mfgp_finish_solve_f64(const double* __res
 // the mirrored inverse S, the new z entry and the scalars.  One workgroup.
 //   d = sqrt(kdiag - l.l) ; L[r][0:n] = l, L[r][r] = d ; X[r][0:n] = -w/d, X[r][r] = 1/d (both triangles of S)
 //   z[r] = (y_new - l.z) / d ; out = {d, z_r, l.l, status(0 ok / 1 not PD)}
+// The new training row itself (X[r] <- xs_new, Y[r] <- y_new) is committed HERE and only on success: a rejected
+// append leaves the handle's data exactly as it was (padding row r of X and Y stays zero).
 __global__ __launch_bounds__(256) void mfgp_append_finish_f64(double* __restrict__ L, double* __restrict__ S, int ld,
                                                               int n, const double* __restrict__ l,
                                                               const double* __restrict__ w, double* __restrict__ z,
-                                                              double kdiag, double y_new, double* __restrict__ out) {
+                                                              double kdiag, double y_new, double* __restrict__ out,
+                                                              double* __restrict__ X, const double* __restrict__ xs_new,
+                                                              int D, double* __restrict__ Y) {
     __shared__ double red[512];
     const int tid = threadIdx.x;
     double ss = 0.0, lz = 0.0;
@@ -106,7 +110,9 @@ __global__ __launch_bounds__(256) void mfgp_append_finish_f64(double* __restrict
         S[(int64_t)n * ld + i] = xv;
         S[(int64_t)i * ld + n] = xv;
     }
+    if (tid < D) X[(int64_t)n * D + tid] = xs_new[tid];
     if (tid == 0) {
+        Y[n] = y_new;
         L[(int64_t)n * ld + n] = d;
         S[(int64_t)n * ld + n] = rd;
         const double zr = (y_new - red[256]) * rd;
@@ -116,8 +122,9 @@ __global__ __launch_bounds__(256) void mfgp_append_finish_f64(double* __restrict
 }
 
 void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
-                          double kdiag, double y_new, double* out) {
-    hipLaunchKernelGGL(mfgp_append_finish_f64, dim3(1), dim3(256), 0, s, L, S, ld, n, l, w, z, kdiag, y_new, out);
+                          double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y) {
+    hipLaunchKernelGGL(mfgp_append_finish_f64, dim3(1), dim3(256), 0, s, L, S, ld, n, l, w, z, kdiag, y_new, out, X,
+                       xs_new, D, Y);
 }
 
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
@@ -171,329 +178,6 @@ void launch_assemble_aug(hipStream_t s, const double* Xc, const double* m, int r
     const int64_t tot = (int64_t)rows_p * (d + c);
     hipLaunchKernelGGL(mfgp_assemble_aug_f64, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, m, rows, rows_p, d,
                        c, out, ld);
-}
-
-// ---- probes ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mfgp_probe_mfma_f64(double* out, int iters) {
-    d4_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (s == 12345.678) out[0] = s;  // keep the loop alive
-}
-
-__global__ __launch_bounds__(256) void mfgp_probe_copy(const d2_t* __restrict__ src, d2_t* __restrict__ dst,
-                                                       int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = src[i];
-}
-
-// write-only and read-only HBM streams (the K build is a pure write stream, the skinny variance product a pure read)
-__global__ __launch_bounds__(256) void mfgp_probe_write(d2_t* __restrict__ dst, int64_t n, double v) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = (d2_t){v, v + (double)i};
-}
-__global__ __launch_bounds__(256) void mfgp_probe_read(const d2_t* __restrict__ src, int64_t n, double* out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    double s = 0.0;
-    for (; i < n; i += stride) { const d2_t v = src[i]; s += v.x + v.y; }
-    if (s == 1.2345e300) out[0] = s;
-}
-void run_probe_bw(hipStream_t s, double* out2) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    const int64_t bytes = (int64_t)1 << 30;
-    d2_t* buf = nullptr;
-    double* dummy = nullptr;
-    hipMalloc(&buf, bytes);
-    hipMalloc(&dummy, 64);
-    float ms = 0.f;
-    for (int which = 0; which < 2; ++which) {
-        for (int rep = 0; rep < 6; ++rep) {
-            if (rep == 1) hipEventRecord(e0, s);
-            if (which == 0) hipLaunchKernelGGL(mfgp_probe_write, dim3(4096), dim3(256), 0, s, buf, bytes / 16, 1.0);
-            else hipLaunchKernelGGL(mfgp_probe_read, dim3(4096), dim3(256), 0, s, buf, bytes / 16, dummy);
-        }
-        hipEventRecord(e1, s);
-        hipEventSynchronize(e1);
-        hipEventElapsedTime(&ms, e0, e1);
-        out2[which] = 5.0 * (double)bytes / (ms * 1e-3) / 1e9;
-    }
-    hipFree(buf);
-    hipFree(dummy);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-}
-
-// detailed MFMA probe: per-wave shader cycles (s_memtime) and 100 MHz real time around the loop
-template <int NACC>
-__global__ __launch_bounds__(256) void mfgp_probe_mfma_detail(unsigned long long* out, int iters) {
-    d4_t acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    if ((threadIdx.x & 63) == 0) {
-        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-        out[2 * w] = t1 - t0 + (s == 12345.678 ? 1 : 0);
-        out[2 * w + 1] = r1 - r0;
-    }
-}
-
-// VALU probe: NCH independent v_fma_f64 chains per lane; MIX: also issue MFMAs from the same wave
-template <int NCH, bool MIX>
-__global__ __launch_bounds__(256) void mfgp_probe_valu_f64(double* out, int iters) {
-    double x[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) x[i] = 1.0 + 1e-3 * (threadIdx.x + i);
-    const double a = 1.0 - 1e-9, b = 1e-9;
-    d4_t acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) x[i] = __builtin_fma(x[i], a, b);
-        if (MIX) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-        }
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) s += x[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][3];
-    if (s == 12345.678) out[0] = s;
-}
-
-// GEMM-like operand pattern: every FMA reads THREE distinct 64-bit VGPR operands (acc += a[i] * b[j]), 8 x 4 tile
-__global__ __launch_bounds__(256) void mfgp_probe_valu3_f64(double* out, int iters) {
-    double acc[8][4], a[8], b[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        a[i] = 1.0 + 1e-9 * (threadIdx.x + i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = 1.0 - 1e-9 * (threadIdx.x + j);
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(a[i], b[j], acc[i][j]);
-        // keep a and b in VGPRs and changing, so nothing folds to constants / SGPRs
-        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                          "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += acc[i][j];
-    if (s == 12345.678) out[0] = s;
-}
-
-// out4: {VALU-only TFLOP/s (2 waves/SIMD), VALU-only (4 waves/SIMD), mixed total TFLOP/s (2 waves/SIMD: 32 fma + 4 mfma per iter), mixed 4 waves/SIMD}
-void run_probe_valu(hipStream_t s, double* out) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    double* dummy = nullptr;
-    hipMalloc(&dummy, 64);
-    const int iters = 20000;
-    for (int c = 0; c < 4; ++c) {
-        const int blocks = (c & 1) ? 1024 : 512;
-        float ms = 0.f;
-        for (int rep = 0; rep < 2; ++rep) {
-            hipEventRecord(e0, s);
-            if (c < 2) hipLaunchKernelGGL((mfgp_probe_valu_f64<32, false>), dim3(blocks), dim3(256), 0, s, dummy, iters);
-            else hipLaunchKernelGGL((mfgp_probe_valu_f64<32, true>), dim3(blocks), dim3(256), 0, s, dummy, iters);
-            hipEventRecord(e1, s);
-            hipEventSynchronize(e1);
-        }
-        hipEventElapsedTime(&ms, e0, e1);
-        const double waves = blocks * 4.0;
-        double flops = waves * iters * 32.0 * 64.0 * 2.0;
-        if (c >= 2) flops += waves * iters * 4.0 * 2048.0;
-        out[c] = flops / (ms * 1e-3) / 1e12;
-    }
-    for (int c = 0; c < 2; ++c) {   // out[4], out[5]: the three-VGPR-operand pattern at 2 / 4 waves per SIMD
-        const int blocks = c ? 1024 : 512;
-        float ms = 0.f;
-        for (int rep = 0; rep < 2; ++rep) {
-            hipEventRecord(e0, s);
-            hipLaunchKernelGGL(mfgp_probe_valu3_f64, dim3(blocks), dim3(256), 0, s, dummy, iters);
-            hipEventRecord(e1, s);
-            hipEventSynchronize(e1);
-        }
-        hipEventElapsedTime(&ms, e0, e1);
-        out[4 + c] = blocks * 4.0 * iters * 32.0 * 64.0 * 2.0 / (ms * 1e-3) / 1e12;
-    }
-    hipFree(dummy);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-}
-
-// out[3*c + 0..2] = {TFLOP/s, shader cycles per MFMA per wave (median), shader clock GHz} for the configs
-//   c=0: 1 wave/SIMD x 8 acc, c=1: 2 waves/SIMD x 8 acc, c=2: 4 waves/SIMD x 8 acc, c=3: 1 wave/SIMD x 1 acc (dependent)
-// low-precision matrix pipes, for sizing an fp64 emulation (Ozaki splitting) against the fp64 MFMA ceiling:
-// v_mfma_i32_16x16x64_i8 (32768 int8 ops each) and v_mfma_f32_16x16x32_bf16 (16384 flops each), 8 accumulators per wave
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void mfgp_probe_mfma_i8(int* out, int iters) {
-    v4i_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (v4i_t){0, 0, 0, 0};
-    const v4i_t a = {(int)threadIdx.x, 1, 2, 3}, b = {3, 2, 1, (int)threadIdx.x};
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
-    }
-    int sum = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (sum == 123456789) out[0] = sum;
-}
-__global__ __launch_bounds__(256) void mfgp_probe_mfma_bf16(float* out, int iters) {
-    v4f_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (v4f_t){0.f, 0.f, 0.f, 0.f};
-    v8bf_t a, b;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(1.0f + 0.001f * (threadIdx.x & 7)); b[i] = (__bf16)(1.0f - 0.001f * i); }
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (sum == 12345.678f) out[0] = sum;
-}
-void run_probe_lowp(hipStream_t s, double* out2) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    int* dummy = nullptr;
-    hipMalloc(&dummy, 64);
-    const int iters = 20000, blocks = 2048;   // 2 workgroups of 4 waves per SIMD pair: 8 waves per CU x 8
-    for (int which = 0; which < 2; ++which) {
-        for (int rep = 0; rep < 2; ++rep) {
-            hipEventRecord(e0, s);
-            if (which == 0) hipLaunchKernelGGL(mfgp_probe_mfma_i8, dim3(blocks), dim3(256), 0, s, dummy, iters);
-            else hipLaunchKernelGGL(mfgp_probe_mfma_bf16, dim3(blocks), dim3(256), 0, s, reinterpret_cast<float*>(dummy), iters);
-            hipEventRecord(e1, s);
-            hipEventSynchronize(e1);
-        }
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        const double ops = (double)blocks * 4.0 * iters * 8.0 * (which == 0 ? 32768.0 : 16384.0);
-        out2[which] = ops / (ms * 1e-3) / 1e12;   // Tera-ops (int8) / TFLOP (bf16) per second
-    }
-    hipFree(dummy);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-}
-
-void run_probe_detail(hipStream_t s, double* out) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    unsigned long long* dbuf = nullptr;
-    const int maxw = 1024 * 4;
-    hipMalloc(&dbuf, sizeof(unsigned long long) * 2 * maxw);
-    std::vector<unsigned long long> hb(2 * maxw);
-    const int iters = 4000;
-    for (int c = 0; c < 4; ++c) {
-        const int blocks = (c == 1) ? 512 : (c == 2) ? 1024 : 256;
-        const int nacc = (c == 3) ? 1 : 8;
-        for (int rep = 0; rep < 2; ++rep) {
-            hipEventRecord(e0, s);
-            if (nacc == 8) hipLaunchKernelGGL((mfgp_probe_mfma_detail<8>), dim3(blocks), dim3(256), 0, s, dbuf, iters);
-            else hipLaunchKernelGGL((mfgp_probe_mfma_detail<1>), dim3(blocks), dim3(256), 0, s, dbuf, iters * 8);
-            hipEventRecord(e1, s);
-            hipEventSynchronize(e1);
-        }
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        const int nw = blocks * 4;
-        hipMemcpy(hb.data(), dbuf, sizeof(unsigned long long) * 2 * nw, hipMemcpyDeviceToHost);
-        std::vector<double> cyc(nw), clk(nw);
-        const double nm = (double)iters * 8.0;
-        for (int w = 0; w < nw; ++w) {
-            cyc[w] = (double)hb[2 * w] / nm;
-            clk[w] = (double)hb[2 * w] / ((double)hb[2 * w + 1] * 10.0) ;  // cycles per ns = GHz (realtime ticks are 10 ns)
-        }
-        std::sort(cyc.begin(), cyc.end());
-        std::sort(clk.begin(), clk.end());
-        out[3 * c + 0] = (double)nw * nm * 2048.0 / (ms * 1e-3) / 1e12;
-        out[3 * c + 1] = cyc[nw / 2];
-        out[3 * c + 2] = clk[nw / 2];
-    }
-    hipFree(dbuf);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-}
-
-void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    double* dummy = nullptr;
-    hipMalloc(&dummy, 64);
-    // MFMA: 256 CUs x 4 blocks x 4 waves, 8 independent accumulators each
-    const int iters = 20000, blocks = 1024;
-    hipLaunchKernelGGL(mfgp_probe_mfma_f64, dim3(blocks), dim3(256), 0, s, dummy, 100);  // warm
-    hipEventRecord(e0, s);
-    hipLaunchKernelGGL(mfgp_probe_mfma_f64, dim3(blocks), dim3(256), 0, s, dummy, iters);
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
-    *mfma_tflops = flops / (ms * 1e-3) / 1e12;
-    // copy 1 GiB
-    const int64_t bytes = (int64_t)1 << 30;
-    d2_t *src = nullptr, *dst = nullptr;
-    hipMalloc(&src, bytes);
-    hipMalloc(&dst, bytes);
-    hipMemsetAsync(src, 1, bytes, s);
-    hipLaunchKernelGGL(mfgp_probe_copy, dim3(4096), dim3(256), 0, s, src, dst, bytes / 16);
-    hipEventRecord(e0, s);
-    for (int r = 0; r < 5; ++r)
-        hipLaunchKernelGGL(mfgp_probe_copy, dim3(4096), dim3(256), 0, s, src, dst, bytes / 16);
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    hipEventElapsedTime(&ms, e0, e1);
-    *copy_gbs = 5.0 * 2.0 * (double)bytes / (ms * 1e-3) / 1e9;
-    hipFree(src);
-    hipFree(dst);
-    hipFree(dummy);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
 }
 
 }  // namespace mfgp

@@ -32,7 +32,7 @@ from . import _lib
 from ._lib import KERN_MATERN32, KERN_MATERN52, KERN_RBF, NotPositiveDefinite
 
 _LIM_VAL = 36.0
-_EPS = np.finfo(np.float64).resolution
+_LOG_LIM_VAL = np.log(np.finfo(np.float64).max)  # paramz: _log_lim_val
 CONST_JITTER = 1e-8  # GPy adds this to the diagonal in exact inference [GPy-recall]
 
 
@@ -40,8 +40,10 @@ CONST_JITTER = 1e-8  # GPy adds this to the diagonal in exact inference [GPy-rec
 # parameters
 # ------------------------------------------------------------------------------------------------
 def _logexp_f(x):
+    # paramz 0.9.5 transformations.Logexp.f: log1p(exp(clip(x, -log(DBL_MAX), 36))), x itself above 36; the trailing
+    # "+ epsilon" is commented out upstream, so nothing is added [GPy-recall]
     x = np.asarray(x, dtype=np.float64)
-    return np.where(x > _LIM_VAL, x, np.log1p(np.exp(np.clip(x, -_LIM_VAL, _LIM_VAL)))) + _EPS
+    return np.where(x > _LIM_VAL, x, np.log1p(np.exp(np.clip(x, -_LOG_LIM_VAL, _LIM_VAL))))
 
 
 def _logexp_finv(f):
@@ -73,6 +75,12 @@ class Param:
     @value.setter
     def value(self, v):
         v = float(np.asarray(v).reshape(-1)[0])
+        if v == self._value:
+            # assigning the value a parameter already has changes nothing the factorisation depends on:
+            # no notification, so no O(N^3) refactorisation (MultifidelityDataFusion.predict re-assigns
+            # likelihood.variance = 1e-6 on every call with add_noise=True, src/MFDataFusion.py:154-155;
+            # SURVEY 8(b) allows the lazy form)
+            return
         self._value = v
         for o in self._observers:
             o._param_changed(self)

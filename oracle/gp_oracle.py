@@ -224,13 +224,15 @@ def predict_stable(parts, theta, noise, X, state, Xnew, include_noise=True):
 # positivity transform  [GPy-recall: paramz.transformations.Logexp]
 # ------------------------------------------------------------------------------------------------
 _LIM_VAL = 36.0
-_EPS = np.finfo(np.float64).resolution
+_LOG_LIM_VAL = np.log(np.finfo(np.float64).max)   # paramz: _log_lim_val = log(DBL_MAX) ~ 709.78
 
 
 def logexp_f(x):
-    """optimizer space -> positive parameter: log(1 + e^x), linear above 36, clipped below -36; + eps."""
+    """optimizer space -> positive parameter: log(1 + e^x); linear above _lim_val = 36, the argument of exp clipped
+    to [-log(DBL_MAX), 36].  paramz 0.9.5 transformations.Logexp.f ends in `#+ epsilon`: the epsilon term is
+    commented out upstream, so none is added here [GPy-recall]."""
     x = np.asarray(x, dtype=np.float64)
-    return np.where(x > _LIM_VAL, x, np.log1p(np.exp(np.clip(x, -_LIM_VAL, _LIM_VAL)))) + _EPS
+    return np.where(x > _LIM_VAL, x, np.log1p(np.exp(np.clip(x, -_LOG_LIM_VAL, _LIM_VAL))))
 
 
 def logexp_finv(f):

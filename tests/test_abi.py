@@ -38,8 +38,7 @@ def test_struct_layouts_match_header():
 
 
 def test_no_cpu_fallback_engine_fails_loudly_without_gpu():
-    import torch
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present")
     from multifidelity_datafusion_gps_amd import _lib
     with pytest.raises(_lib.EngineUnavailable) as ei:

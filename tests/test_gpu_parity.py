@@ -286,6 +286,15 @@ def test_rank1_append_equals_fresh_factorisation(engine, engine_cls):
     with pytest.raises(NotPositiveDefinite):
         engine.append_row(X[7], Y[7])
     assert engine.n == 50
+    # "state unchanged" includes the padded data rows: the rejected (x, y) must not have been written into the
+    # padding slot, or the next evaluation's quadratic form would gain y_new^2 (z = X y runs over all Np rows)
+    fresh = engine_cls(0)
+    fresh.set_data(X[:50], Y[:50])
+    fresh.set_kernel(parts)
+    f_fresh, g_fresh = fresh.eval(theta, 0.05, 1e-8)
+    f_after, g_after = engine.eval(theta, 0.05, 1e-8)
+    assert f_after == f_fresh and np.array_equal(g_after, g_fresh)
+    fresh.close()
 
 
 def test_repeated_evaluations_are_bitwise_identical(engine):
@@ -385,6 +394,31 @@ def test_device_resident_level_chaining_equals_host_hand_over(engine, engine_cls
         fresh.augment(X_hf, offs)          # no factorisation yet
     fresh.close()
     hf.close()
+
+
+def test_low_fidelity_handle_reused_at_another_input_width(engine_cls):
+    """The level-chaining scratch of a low-fidelity handle is sized for its input width: reusing the handle for a wider
+    level (the `engines=` reuse of the models, or any C-ABI caller) must re-allocate it, not write past its end."""
+    rng = np.random.default_rng(5)
+    lf, hf = engine_cls(0), engine_cls(0)
+    for d, f_lo, f_hi in ((2, cases.lf_2d, cases.hf_2d), (4, cases.lf_4d, cases.hf_4d), (2, cases.lf_2d, cases.hf_2d)):
+        Xl = rng.uniform(size=(150, d))
+        lf.set_data(Xl, f_lo(Xl))
+        lf.set_kernel(cases.single(cases.RBF, d))
+        lf.factorize(np.array([1.0, 0.5]), 1e-3)
+        offs = np.zeros((1, d))
+        Xh = rng.uniform(size=(90, d))
+        aug = lf.augment(Xh, offs)
+        m_host, _ = lf.predict(Xh, want_var=False)
+        assert np.array_equal(aug[:, :d], Xh) and np.array_equal(aug[:, d], m_host)
+        hf.set_data(aug, f_hi(Xh))
+        hf.set_kernel(cases.composite(d, 1))
+        hf.factorize(np.ones(6), 1e-2)
+        Xs = rng.uniform(size=(300, d))
+        m1, v1 = hf.predict_chained(lf, Xs, offs)
+        m2, v2 = hf.predict(lf.augment(Xs, offs))
+        assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+    lf.close(); hf.close()
 
 
 @pytest.mark.parametrize("N", [97, 700, 2100])

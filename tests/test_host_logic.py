@@ -168,3 +168,26 @@ def test_eval_cap_is_exact():
     m.eval_cap = None
     run2 = m.optimize(max_iters=5)          # scipy's own semantics: may overshoot maxfun
     assert run2.n_evals >= 5
+
+
+def test_assigning_an_unchanged_value_does_not_invalidate_the_model():
+    """Param.value: no notification when the value is bit-equal (MultifidelityDataFusion.predict re-assigns
+    likelihood.variance = 1e-6 on every call with add_noise=True, /root/reference/src/MFDataFusion.py:154-155)."""
+    from multifidelity_datafusion_gps_amd import engine as gp
+
+    class Owner:
+        def __init__(self):
+            self.changes = 0
+
+        def _param_changed(self, p):
+            self.changes += 1
+
+    o = Owner()
+    lik = gp.Gaussian(1.0, owner=o)
+    lik.variance = 1e-6
+    assert o.changes == 1 and lik.variance.value == 1e-6
+    for _ in range(50):
+        lik.variance = 1e-6
+    assert o.changes == 1
+    lik.variance = np.array([2e-6])
+    assert o.changes == 2 and lik.variance.value == 2e-6
