@@ -1,12 +1,14 @@
 """Abstract multi-fidelity GP model: configuration, kernel construction, the data-driven low-fidelity
 level, the hyper-parameter recipe and the entropy-reduction adaptation loop.
 
-Fresh restatement of the orchestration surface of /root/reference/src/abstractMFGP.py (ctor :12-33,
-abstract API :35-49, initialize_kernel :51-60, get_NARGP_kernel :62-80, initialize_lf_level :82-106,
-adapt_lf :108-122, get_input_with_highest_uncertainty :124-129, ARD :131-137, the adaptation loop
-:317-359) with every GPy call replaced by the HIP-backed objects of engine.py.  Plotting (matplotlib,
-:139-273 and the drawing branches of :290-352) is out of scope; the loop records the same quantities
-(`mse_history`, `acquired_points`, `acquisition_values`) instead of drawing them.
+Keeps the PUBLIC surface of /root/reference/src/abstractMFGP.py -- constructor arguments (:12-33), the abstract API
+(:35-49), `initialize_kernel` (:51-60), `get_NARGP_kernel` (:62-80), `initialize_lf_level` (:82-106), `adapt_lf`
+(:108-122), `get_input_with_highest_uncertainty` (:124-129), `ARD` (:131-137) and `adapt_and_plot` (:275-359) -- so
+that models written against the reference keep working; the bodies are this package's own, organised around three
+things the reference does not have: device-resident engine handles per fidelity level, concurrent / rank-sharded
+restarts, and a rank-1 append alternative to refitting.  Every GPy call is replaced by the HIP-backed objects of
+engine.py.  Plotting (matplotlib, :139-273 and the drawing branches of :290-352) is out of scope; the loop records
+the quantities it would have drawn (`mse_history`, `acquired_points`, `acquisition_values`).
 """
 import abc
 
@@ -15,6 +17,13 @@ import numpy as np
 from . import engine as gp
 from .adaptation_maximizers import AbstractMaximizer
 from .sharding import LocalComm
+
+
+def _unit_box_where_missing(lower, upper, dim):
+    """the data bounds default to the unit box (src/abstractMFGP.py:28-33); a single missing side is filled too"""
+    lo = np.zeros(dim) if lower is None else lower
+    hi = np.ones(dim) if upper is None else upper
+    return lo, hi
 
 
 class AbstractMFGP(metaclass=abc.ABCMeta):
@@ -27,32 +36,23 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     lf_max_iters = 1000         # lf_model.optimize() default budget (src/abstractMFGP.py:103)
     eval_cap = None             # hard cap on objective evaluations per L-BFGS-B run (benchmarks: exact budgets)
     restart_concurrency = 1     # >1: that many randomized restarts run concurrently with the first run / restart 0
+    diagonal_points = 1000      # resolution of the box diagonal the adaptation loop predicts on every step (:318)
 
     @abc.abstractmethod
     def __init__(self, name: str, input_dim: int, num_derivatives: int, tau: float, f_exact: callable,
                  lower_bound: np.ndarray, upper_bound: np.ndarray, f_low: callable, lf_X: np.ndarray, lf_Y: np.ndarray,
                  lf_hf_adapt_ratio: int, use_composite_kernel: bool, adapt_maximizer: AbstractMaximizer, eps: float):
         super().__init__()
-        self.name = name
-        self.input_dim = input_dim
-        self.num_derivatives = num_derivatives
-        self.tau = tau
-        self.f_exact = f_exact
-        self.f_low = f_low
-        self.lf_hf_adapt_ratio = lf_hf_adapt_ratio
-        self.adapt_maximizer = adapt_maximizer
-        self.eps = eps
+        self.name, self.input_dim = name, input_dim
+        self.num_derivatives, self.tau = num_derivatives, tau
+        self.f_exact, self.f_low = f_exact, f_low
+        self.lf_hf_adapt_ratio, self.adapt_maximizer, self.eps = lf_hf_adapt_ratio, adapt_maximizer, eps
+        self.lower_bound, self.upper_bound = _unit_box_where_missing(lower_bound, upper_bound, input_dim)
+        # not in the reference: rank plumbing, seeded restarts, one engine handle per fidelity level
         self.comm = LocalComm()
         self.seed = None
         self._fit_count = 0
         self._engines = {}
-        # data bounds: the unit box when none are given (src/abstractMFGP.py:28-33)
-        if lower_bound is None and upper_bound is None:
-            self.lower_bound = np.zeros(input_dim)
-            self.upper_bound = np.ones(input_dim)
-        else:
-            self.lower_bound = lower_bound
-            self.upper_bound = upper_bound
 
     @abc.abstractmethod
     def fit(self, hf_X):
@@ -77,62 +77,85 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             self._engines[level] = Engine()
         return self._engines[level]
 
+    def _level_of(self, model):
+        """name under which the model's engine handle is registered (auxiliary handles are derived from it)"""
+        for level, eng in self._engines.items():
+            if eng is model._engine:
+                return level
+        return "aux"
+
     # ---- kernels -------------------------------------------------------------------------------------
+    def _augmented_columns(self):
+        """-> (input columns, augmentation columns) of the high-fidelity level's design matrix [X | stencil values]"""
+        d = self.input_dim
+        c = self.augm_iterator.new_entries_count()
+        return np.arange(d), np.arange(d, d + c)
+
     def initialize_kernel(self, use_composite_kernel: bool):
-        """composite NARGP kernel, or ONE isotropic RBF over all d + c augmented columns
-        (no ARD flag is passed in the reference either, src/abstractMFGP.py:59-60)"""
+        """self.kernel := the composite NARGP kernel, or one isotropic RBF over all d + c augmented columns (the
+        reference passes no ARD flag either, src/abstractMFGP.py:59-60).  Built once per model object: every refit
+        reuses it, so hyper-parameters warm-start (src/MFDataFusion.py:69,96)."""
         if use_composite_kernel:
             self.kernel = self.get_NARGP_kernel()
-        else:
-            new_input_dims = self.input_dim + self.augm_iterator.new_entries_count()
-            self.kernel = gp.RBF(new_input_dims)
+            return
+        cols_in, cols_aug = self._augmented_columns()
+        self.kernel = gp.RBF(len(cols_in) + len(cols_aug))
 
     def get_NARGP_kernel(self, kern_class1=gp.RBF, kern_class2=gp.RBF, kern_class3=gp.RBF):
-        """k1(augmentation columns) * k2(input columns) + k3(input columns)   (src/abstractMFGP.py:73-80)"""
-        std_input_dim = self.input_dim
-        std_indezes = np.arange(self.input_dim)
-        aug_input_dim = self.augm_iterator.new_entries_count()
-        aug_indezes = np.arange(self.input_dim, self.input_dim + aug_input_dim)
-        kern1 = kern_class1(aug_input_dim, active_dims=aug_indezes)
-        kern2 = kern_class2(std_input_dim, active_dims=std_indezes)
-        kern3 = kern_class3(std_input_dim, active_dims=std_indezes)
-        return kern1 * kern2 + kern3
+        """k1(augmentation columns) * k2(input columns) + k3(input columns): the correlation between fidelities
+        modulated over the input space, plus a bias term in the inputs alone (src/abstractMFGP.py:62-80; the three
+        class hooks select the stationary family of each factor)."""
+        cols_in, cols_aug = self._augmented_columns()
+        cross_fidelity = kern_class1(len(cols_aug), active_dims=cols_aug)
+        modulation = kern_class2(len(cols_in), active_dims=cols_in)
+        bias = kern_class3(len(cols_in), active_dims=cols_in)
+        return cross_fidelity * modulation + bias
 
     # ---- low-fidelity level ----------------------------------------------------------------------------
     def initialize_lf_level(self, f_low: callable = None, lf_X: np.ndarray = None, lf_Y: np.ndarray = None):
-        """exactly one of {f_low} / {lf_X, lf_Y}: a python function, or a GP trained on low-fidelity data
-        whose posterior MEAN becomes f_low (src/abstractMFGP.py:93-106)."""
-        lf_model_params_are_valid = (f_low is not None) ^ (
-            (lf_X is not None) and (lf_Y is not None) and (self.lf_hf_adapt_ratio is not None))
-        assert lf_model_params_are_valid, 'define low-fidelity model either by predicition function or by data'
-        self.data_driven_lf_approach = f_low is None
-        if self.data_driven_lf_approach:
-            self.lf_X = lf_X
-            self.lf_Y = lf_Y
-            self.lf_model = gp.GPRegression(X=lf_X, Y=lf_Y, initialize=True, engine=self._engine("lf"))
-            self.lf_model.eval_cap = self.eval_cap
-            self.lf_model.optimize(max_iters=self.lf_max_iters)
-            self.f_low = lambda t: self.lf_model.predict_mean(t)
-        else:
+        """The low-fidelity level is EITHER a python function `f_low` OR a GP trained here on (lf_X, lf_Y) whose
+        posterior mean then plays the role of f_low (src/abstractMFGP.py:82-106) -- never both, never neither."""
+        from_function = f_low is not None
+        from_data = lf_X is not None and lf_Y is not None and self.lf_hf_adapt_ratio is not None
+        assert from_function != from_data, \
+            "the low-fidelity level needs exactly one source: a prediction function f_low, or training data lf_X / lf_Y"
+        self.data_driven_lf_approach = from_data
+        if from_function:
             self.f_low = f_low
+            return
+        self.lf_X, self.lf_Y = lf_X, lf_Y
+        self.lf_model = self._new_lf_model()
+        self.lf_model.optimize(max_iters=self.lf_max_iters)
+        self.f_low = self._lf_posterior_mean
+
+    def _lf_posterior_mean(self, t):
+        """f_low of a data-driven level: the CURRENT low-fidelity GP's posterior mean (mean only: the O(N^2 N*) variance
+        product is never asked for here); looked up per call because adapt_lf replaces self.lf_model"""
+        return self.lf_model.predict_mean(t)
+
+    def _new_lf_model(self):
+        model = gp.GPRegression(X=self.lf_X, Y=self.lf_Y, initialize=True, engine=self._engine("lf"))
+        model.eval_cap = self.eval_cap
+        return model
 
     def adapt_lf(self):
-        """acquire additional low-fidelity points where the LF model is most uncertain and refit it.
-        (The reference's version, src/abstractMFGP.py:108-122, is unreachable: MFDataFusion.adapt calls a
-        name-mangled attribute that does not exist; this is the behaviour its docstring describes.)"""
-        assert hasattr(self, 'lf_model'), "lf-model not initialized"
+        """Grow the low-fidelity training set where the low-fidelity GP itself is most uncertain, refitting it after
+        every acquisition; `adapt_steps * lf_hf_adapt_ratio` points.  (This is what the docstring of the reference's
+        version describes; its code, src/abstractMFGP.py:108-122, is unreachable -- MFDataFusion.adapt calls a
+        name-mangled attribute that does not exist.)"""
+        assert hasattr(self, 'lf_model'), "adapt_lf needs a data-driven low-fidelity level"
         for _ in range(self.adapt_steps * self.lf_hf_adapt_ratio):
-            acquired_x, _ = self.adapt_maximizer.maximize(self.lf_model.predict, self.lower_bound, self.upper_bound)
-            acquired_y = self.lf_model.predict(acquired_x[None])[0][0]
-            self.lf_X = np.vstack((self.lf_X, acquired_x))
-            self.lf_Y = np.vstack((self.lf_Y, acquired_y))
-            self.lf_model = gp.GPRegression(self.lf_X, self.lf_Y, initialize=True, engine=self._engine("lf"))
+            where, _ = self.adapt_maximizer.maximize(self.lf_model.predict, self.lower_bound, self.upper_bound)
+            value = self.lf_model.predict(where[None])[0][0]     # the level has no external truth: its own mean
+            self.lf_X = np.vstack((self.lf_X, where))
+            self.lf_Y = np.vstack((self.lf_Y, value))
+            self.lf_model = self._new_lf_model()
             self.ARD(self.lf_model, self.num_restarts)
 
     def get_input_with_highest_uncertainty(self, model=None):
-        """global maximiser of the model's predictive variance over the box"""
-        x, fopt = self.adapt_maximizer.maximize(self.predict, self.lower_bound, self.upper_bound)
-        return x, fopt
+        """-> (x, f_opt): the maximiser of THIS model's predictive variance over the box and the (negated) value the
+        maximiser reports (src/abstractMFGP.py:124-129; `model` is accepted and unused there as well)"""
+        return self.adapt_maximizer.maximize(self.predict, self.lower_bound, self.upper_bound)
 
     # ---- hyper-parameter recipe ------------------------------------------------------------------------
     def _restart_rng(self):
@@ -141,42 +164,50 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         fit_id = self._fit_count
         return lambda i: np.random.default_rng([int(self.seed), fit_id, i]).normal
 
+    def _pin_noise(self, model):
+        """noise variance := noise_ratio * Var(Y), held fixed (src/abstractMFGP.py:132-133)"""
+        model[".*Gaussian_noise"] = model.Y.var() * self.noise_ratio
+        model[".*Gaussian_noise"].fix()
+        model.eval_cap = self.eval_cap
+
+    @staticmethod
+    def _free_noise(model):
+        """(src/abstractMFGP.py:135-136)"""
+        model[".*Gaussian_noise"].unfix()
+        model[".*Gaussian_noise"].constrain_positive()
+
     def ARD(self, model, num_restarts):
-        """noise := 0.01 Var(Y), fixed -> one L-BFGS-B run (500) -> free the noise -> `num_restarts`
-        restarts (1000 each), best wins (src/abstractMFGP.py:131-137).  1 + num_restarts runs per fit.
+        """The reference's recipe (src/abstractMFGP.py:131-137): pin the noise at 1 % of Var(Y), one L-BFGS-B run
+        (500), free the noise, `num_restarts` restarts (1000 each), the best run wins: 1 + num_restarts runs per fit.
 
         With `restart_concurrency` > 1 the randomized restarts 1.. (which, by paramz' semantics, start from fresh
         N(0,1) draws and so do not depend on the first run) execute on auxiliary engine handles in background
         threads WHILE the main thread does the first run and restart 0; same runs, same winner rule."""
-        model[".*Gaussian_noise"] = model.Y.var() * self.noise_ratio
-        model[".*Gaussian_noise"].fix()
-        model.eval_cap = self.eval_cap
-        conc = int(self.restart_concurrency)
-        rank, size = self.comm.rank, self.comm.size
-        if conc <= 1:
+        self._pin_noise(model)
+        if int(self.restart_concurrency) <= 1:
             model.optimize(max_iters=self.first_run_max_iters)
-            model[".*Gaussian_noise"].unfix()
-            model[".*Gaussian_noise"].constrain_positive()
+            self._free_noise(model)
             model.optimize_restarts(num_restarts, optimizer="bfgs", max_iters=self.restart_max_iters, verbose=False,
                                     rand_gen=self._restart_rng(), comm=self.comm)
             return
+        self._ard_concurrent(model, num_restarts, int(self.restart_concurrency))
+
+    def _ard_concurrent(self, model, num_restarts, conc):
         # Rank 0 owns the only sequential piece (first run -> restart 0, which continues from it); the randomized
         # restarts go to the least-loaded rank.  No other rank needs the first run: the winner overwrites every
         # free parameter on every rank.
+        rank, size = self.comm.rank, self.comm.size
         mine_bg = self.assign_restarts(num_restarts, size)[rank]
         handle = None
         if mine_bg:
-            level = [k for k, e in self._engines.items() if e is model._engine]
-            tag = level[0] if level else "aux"
+            tag = self._level_of(model)
             aux = [self._engine("%s#%d" % (tag, j)) for j in range(1, min(conc, len(mine_bg)) + 1)]
-            free = [p for p in model.parameters()]       # every parameter is free during the restarts
-            handle = model.start_background_restarts(mine_bg, aux, free=free, rand_gen=self._restart_rng(),
-                                                     max_iters=self.restart_max_iters)
+            handle = model.start_background_restarts(mine_bg, aux, free=list(model.parameters()),   # all free during restarts
+                                                     rand_gen=self._restart_rng(), max_iters=self.restart_max_iters)
         runs = []
         if rank == 0:
             model.optimize(max_iters=self.first_run_max_iters)
-        model[".*Gaussian_noise"].unfix()
-        model[".*Gaussian_noise"].constrain_positive()
+        self._free_noise(model)
         if rank == 0 and num_restarts > 0:
             r0 = model.optimize(max_iters=self.restart_max_iters)   # restart 0 continues from the current point
             if r0 is not None:
@@ -206,28 +237,29 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     # ---- adaptation loop ---------------------------------------------------------------------------------
     def adapt_and_plot(self, plot_means: bool = False, plot_uncertainties: bool = False, plot_error: bool = False,
                        eps: float = 1e-8):
-        """the entropy-reduction loop of src/abstractMFGP.py:317-359 without the drawing: per step
-        maximise the predictive variance, predict on the 1000-point diagonal of the box, refit with the
-        acquired point appended, stop early once |max variance| < eps."""
-        X = np.linspace(self.lower_bound, self.upper_bound, 1000)
+        """The entropy-reduction loop of src/abstractMFGP.py:317-359 without the drawing.  One step = maximise the
+        predictive variance over the box, predict on the box diagonal (what the reference plots), take the maximiser
+        as a new high-fidelity point, and either refit from scratch (the reference) or append at fixed
+        hyper-parameters (`reoptimize=False`).  Stops early once the reported maximum falls below `self.eps`."""
+        diagonal = np.linspace(self.lower_bound, self.upper_bound, self.diagonal_points)
+        track_error = (plot_error or plot_uncertainties) and getattr(self, "X_test", None) is not None
         self.mse_history, self.acquired_points, self.acquisition_values = [], [], []
-        for i in range(self.adapt_steps):
-            acquired_x, fopt = self.get_input_with_highest_uncertainty(self)
-            means, uncertainties = self.predict(X)
-            self.last_diagonal_prediction = (means, uncertainties)
-            new_hf_X = np.vstack((self.hf_X, acquired_x))
-            self.acquired_points.append(np.array(acquired_x))
-            self.acquisition_values.append(fopt)
-            if (plot_error or plot_uncertainties) and getattr(self, "X_test", None) is not None:
+        planned = self.adapt_steps
+        for step in range(1, planned + 1):
+            where, reported = self.get_input_with_highest_uncertainty(self)
+            self.last_diagonal_prediction = self.predict(diagonal)
+            self.acquired_points.append(np.array(where))
+            self.acquisition_values.append(reported)
+            if track_error:
                 self.mse_history.append(self.get_mse(self.X_test, self.Y_test))
             if getattr(self, "reoptimize", True):
-                self.fit(new_hf_X)                       # the reference: full re-optimisation at N + 1 rows
+                self.fit(np.vstack((self.hf_X, where)))   # full re-optimisation at N + 1 rows
             else:
-                self.append_hf_point(acquired_x)         # hyper-parameters kept: O(N^2) rank-1 append on the device
-            if np.abs(fopt) < self.eps:
-                self.adapt_steps = i + 1
-                print("Iteration stopped after {} iterations!".format(i + 1)
-                      + " minimum uncertainty reached: {:e}".format(fopt))
+                self.append_hf_point(where)               # hyper-parameters kept: O(N^2) rank-1 append on the device
+            if abs(reported) < self.eps:
+                self.adapt_steps = step                   # callers read the number of acquisitions made (gpc driver)
+                print("adaptation stopped after %d of %d steps: largest predictive variance %.3e is below eps = %.1e"
+                      % (step, planned, abs(reported), self.eps))
                 break
 
     def close(self):

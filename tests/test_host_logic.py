@@ -1,6 +1,7 @@
 """CPU tests of the host layer that does not need the GPU: kernel-spec flattening, stencils, DIRECT, transforms,
 row sharding.  (-m "not gpu")"""
 import json
+import re
 import os
 
 import numpy as np
@@ -16,14 +17,23 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def test_augmentation_sequences_match_reference_fixture():
-    """sequences captured by running the reference's two iterator files (GPy-free) -- SURVEY.md 2.1"""
+    """every sequence of tests/golden/augm_sequences.json -- produced by RUNNING the reference's two iterator files
+    (tests/golden/make_augm_sequences.py) -- against this package's iterators: offsets, order, count, re-iterability"""
     fx = json.load(open(os.path.join(GOLD, "augm_sequences.json")))
-    assert [list(map(int, v)) for v in BackwardAugmentation(2, 2)] == fx["backward_n2_dim2"]
-    assert [list(map(int, v)) for v in EvenAugmentation(2, 2)] == fx["even_n2_dim2"]
-    assert [list(map(int, v)) for v in BackwardAugmentation(0, 3)] == fx["backward_n0_dim3"]
-    b = BackwardAugmentation(2, 2)
-    assert len(list(b)) == len(list(b)) == b.new_entries_count() == 5   # re-iterable, count = n*dim + 1
-    assert EvenAugmentation(3, 2).new_entries_count() == 13            # 2*n*dim + 1
+    kinds = {"backward": BackwardAugmentation, "even": EvenAugmentation}
+    checked = 0
+    for key, want in fx.items():
+        m = re.fullmatch(r"(backward|even)_n(\d+)_dim(\d+)", key)
+        if not m:
+            continue
+        it = kinds[m.group(1)](int(m.group(2)), int(m.group(3)))
+        assert [list(map(int, v)) for v in it] == want, key
+        assert [list(map(int, v)) for v in it] == want, key + " (second pass)"   # the reference's objects re-iterate
+        assert fx[key + "_second_pass_equal"] is True
+        assert it.new_entries_count() == fx[key + "_count"] == len(want), key
+        np.testing.assert_array_equal(it.offsets(), np.array(want, dtype=float).reshape(len(want), it.dim))
+        checked += 1
+    assert checked == 14
 
 
 def test_nargp_kernel_flattens_to_the_abi_description():
