@@ -71,6 +71,9 @@ typedef struct mfgp_counters {
     double evals, grad_evals, predicts, predict_rows;
     double kbuild_ms, cholinv_ms, solve_ms, kinv_ms, grad_ms, total_ms, predict_ms;
     double kbuild_bytes, kinv_flops, cholinv_flops;
+    double predict_panel_ms;   /* K(X*,X) panel + mean                                                          */
+    double predict_var_ms;     /* V = K(X*,X) L^-T + row sums of squares                                         */
+    double predict_var_flops;  /* algorithmic flops of the variance products: Np^2 * rows per predict */
 } mfgp_counters;
 
 /* ---- lifecycle --------------------------------------------------------------------------------- */
@@ -157,6 +160,9 @@ int32_t mfgp_get_Kinv(mfgp_handle* h, double* out);   /* Ky^-1 full symmetric (v
 int32_t mfgp_get_alpha(mfgp_handle* h, double* out);  /* alpha (N)                                        */
 int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out);
 int32_t mfgp_get_counters(mfgp_handle* h, mfgp_counters* out, int32_t reset);
+/* hipDeviceSynchronize on the handle's device: what a benchmark brackets its timed region with (every stream of
+ * every handle on that device has drained when it returns) */
+int32_t mfgp_device_synchronize(mfgp_handle* h);
 
 /* ---- kernel-level test hooks (tests/ only) -------------------------------------------------------- */
 /* C = alpha * A B^T + beta * C on Mp x Np x Kp host matrices (multiples of 128) through the MFMA

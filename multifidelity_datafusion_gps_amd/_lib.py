@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "mfgp_set_kernel", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
-    "mfgp_get_counters",
+    "mfgp_get_counters", "mfgp_device_synchronize",
     "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf",
 ]
 
@@ -55,7 +55,8 @@ class Timings(ctypes.Structure):
 class Counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in (
         "evals", "grad_evals", "predicts", "predict_rows", "kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms",
-        "grad_ms", "total_ms", "predict_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops")]
+        "grad_ms", "total_ms", "predict_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops", "predict_panel_ms",
+        "predict_var_ms", "predict_var_flops")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -106,6 +107,7 @@ def load_library(path=None):
         "mfgp_get_alpha": (i32, [H, dp]),
         "mfgp_get_timings": (i32, [H, ctypes.POINTER(Timings)]),
         "mfgp_get_counters": (i32, [H, ctypes.POINTER(Counters), i32]),
+        "mfgp_device_synchronize": (i32, [H]),
         "mfgp_dbg_gemm_nt": (i32, [H, dp, dp, dp, i32, i32, i32, f64, f64, i32]),
         "mfgp_dbg_leaf": (i32, [H, dp, dp, dp, dp]),
     }
@@ -305,6 +307,10 @@ class Engine:
         t = Timings()
         self._check(self._lib.mfgp_get_timings(self._h, ctypes.byref(t)), "mfgp_get_timings")
         return t.as_dict()
+
+    def device_synchronize(self):
+        """hipDeviceSynchronize on this engine's device (benchmarks bracket their timed region with it)"""
+        self._check(self._lib.mfgp_device_synchronize(self._h), "mfgp_device_synchronize")
 
     def counters(self, reset=False):
         c = Counters()

@@ -1106,6 +1106,9 @@ static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double
     h->cum.predicts += 1;
     h->cum.predict_rows += (double)Nstar;
     h->cum.predict_ms += pan_ms + var_ms;
+    h->cum.predict_panel_ms += pan_ms;
+    h->cum.predict_var_ms += var_ms;
+    if (var_ms > 0) h->cum.predict_var_flops += (double)h->Np * (double)h->Np * (double)Nstar;
     h->tm.n_launches = h->launches;
 }
 
@@ -1319,6 +1322,12 @@ int32_t mfgp_get_counters(mfgp_handle* h, mfgp_counters* out, int32_t reset) {
     if (!h || !out) return fail(h, -1, "mfgp_get_counters: NULL");
     *out = h->cum;
     if (reset) memset(&h->cum, 0, sizeof h->cum);
+    return 0;
+}
+int32_t mfgp_device_synchronize(mfgp_handle* h) {
+    if (!h) return fail(h, -1, "mfgp_device_synchronize: NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
     return 0;
 }
 int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out) {

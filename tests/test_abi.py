@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     from multifidelity_datafusion_gps_amd import _lib
     assert ctypes.sizeof(_lib.KernPart) == 16
     assert ctypes.sizeof(_lib.Timings) == 12 * 8
-    assert ctypes.sizeof(_lib.Counters) == 14 * 8
+    assert ctypes.sizeof(_lib.Counters) == 17 * 8
 
 
 def test_no_cpu_fallback_engine_fails_loudly_without_gpu():

@@ -1,0 +1,282 @@
+"""GPU tests of BASELINE.json configurations 3, 4 and 5 at their stated sizes.
+
+  cfg3: 2-fidelity NARGP, 4-D, N_lf = 16384 (single RBF) / N_hf = 4096 (composite kernel on D = 5)
+  cfg4: three chained fidelity levels, 2-D, N = 8192 per level, + the row-block K build in 8 blocks
+  cfg5: NARGP + entropy-reduction adaptation with add_noise=True, N_hf growing across 128-row boundaries
+
+Where a host O(N^3) run is affordable (N <= 8192) the checker is the oracle at the FITTED hyper-parameters; the
+N = 16384 level is checked through size-independent properties (sampled residual of Ky alpha = y, permutation
+invariance, directional central difference).  Flows follow /root/reference/tests/utils.py:38-47,75-86 and
+/root/reference/src/abstractMFGP.py:317-359.
+"""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as orc
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def col(f):
+    return lambda x: f(x)[:, None]
+
+
+def _theta_noise(model):
+    parts, plist = model.kernel.engine_parts()
+    theta = np.array([p.value for pair in plist for p in pair])
+    return parts, theta, model.hf_model.likelihood.variance.value
+
+
+def _budgeted(evals=4, restarts=2, conc=1):
+    """NARGP with a fixed evaluation budget per L-BFGS-B run.  A subclass, not attribute assignment on the instance:
+    the data-driven low-fidelity level is fitted inside the constructor and must see the budget too."""
+    import multifidelity_datafusion_gps_amd as mf
+
+    class BudgetNARGP(mf.NARGP):
+        lf_max_iters = first_run_max_iters = restart_max_iters = evals
+        eval_cap = evals
+        num_restarts = restarts
+        restart_concurrency = conc
+    return BudgetNARGP
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cfg3
+# ---------------------------------------------------------------------------------------------------------------
+def test_cfg3_lf_level_n16384_properties(engine):
+    """The N_lf = 16384 level of cfg3 (single RBF over d = 4; K = 2.15 GB, 128 leaf blocks, 32 macro panels): one
+    objective+gradient evaluation and a prediction, checked without any O(N^3) host work."""
+    rng = np.random.default_rng(2)
+    N = 16384
+    X = rng.uniform(size=(N, 4))
+    Y = cases.lf_4d(X)
+    parts, theta, noise = cases.single(cases.RBF, 4), np.array([1.3, 0.45]), 0.01 * Y.var()
+    engine.set_data(X, Y)
+    engine.set_kernel(parts)
+    nlml, grad = engine.eval(theta, noise)
+    t = engine.timings()
+    print("cfg3 LF N=16384: total %.1f ms, cholinv %.1f ms, kinv %.1f ms, kbuild %.3f ms"
+          % (t["total_ms"], t["cholinv_ms"], t["kinv_ms"], t["kbuild_ms"]))
+    assert np.isfinite(nlml) and np.all(np.isfinite(grad))
+    alpha = engine.get_alpha()
+    # (1) alpha solves Ky alpha = y: residual on sampled rows, the rows of Ky from the oracle's kernel
+    rows = rng.choice(N, 96, replace=False)
+    res = orc.cov(parts, theta, X[rows], X) @ alpha + (noise + 1e-8) * alpha[rows] - Y[rows]
+    assert np.abs(res).max() <= 1e-8 * np.abs(Y).max()
+    # (2) posterior mean at fresh points = k(x*, X) alpha with the oracle's kernel rows; variance within [0, sigma^2]
+    Xs = rng.uniform(size=(200, 4))
+    mean, var = engine.predict(Xs, include_noise=False)
+    np.testing.assert_allclose(mean, orc.cov(parts, theta, Xs, X) @ alpha, rtol=0, atol=1e-8 * np.abs(Y).max())
+    assert np.all(var >= 1e-15) and np.all(var <= theta[0] + 1e-12)
+    assert np.abs(mean - cases.lf_4d(Xs)).max() < 0.05            # it also regresses the function
+    # (3) permutation invariance of NLML and gradient
+    perm = rng.permutation(N)
+    engine.set_data(X[perm], Y[perm])
+    nlml_p, grad_p = engine.eval(theta, noise)
+    assert nlml_p == pytest.approx(nlml, rel=1e-10)
+    np.testing.assert_allclose(grad_p, grad, rtol=0, atol=1e-7 * np.abs(grad).max())
+    # (4) the gradient against a directional central difference of the HIP objective itself
+    d = rng.standard_normal(3)
+    d /= np.linalg.norm(d)
+    p = np.concatenate([theta, [noise]])
+    h = 1e-5
+    fp = engine.eval((p + h * d * p)[:-1], (p + h * d * p)[-1], want_grad=False)
+    fm = engine.eval((p - h * d * p)[:-1], (p - h * d * p)[-1], want_grad=False)
+    assert (fp - fm) / (2 * h) == pytest.approx(float(grad_p @ (d * p)), rel=5e-4)
+
+
+def test_cfg3_two_level_flow_hf_n4096_against_oracle():
+    """cfg3 end to end at full size through the model surface: data-driven LF GP on 16384 points, HF composite
+    level on 4096 augmented points (D = 5), then the fitted HF level against the oracle at the fitted
+    hyper-parameters (N = 4096: a few seconds of host LAPACK)."""
+    import multifidelity_datafusion_gps_amd as mf
+    rng = np.random.default_rng(2)
+    X_lf = rng.uniform(size=(16384, 4))
+    X_hf = rng.uniform(size=(4096, 4))
+    Xs = rng.uniform(size=(500, 4))
+    model = _budgeted(evals=4, restarts=2, conc=2)(4, col(cases.hf_4d), None, lf_X=X_lf, lf_Y=col(cases.lf_4d)(X_lf),
+                                                   seed=2)
+    model.fit(X_hf)
+    assert model.lf_model.X.shape == (16384, 4) and model.hf_model.X.shape == (4096, 5)
+    # the augmentation column is the LF posterior mean: check it against the oracle's kernel rows x the device alpha
+    alpha_lf = model.lf_model._engine.get_alpha()
+    th_lf = np.array([model.lf_model.kern.variance.value, model.lf_model.kern.lengthscale.value])
+    sample = rng.choice(4096, 128, replace=False)
+    want = orc.cov(cases.single(cases.RBF, 4), th_lf, X_hf[sample], X_lf) @ alpha_lf
+    np.testing.assert_allclose(model.hf_model.X[sample, 4], want, rtol=0, atol=1e-8 * np.abs(want).max())
+    mean, var = model.predict(Xs)
+    parts, theta, noise = _theta_noise(model)
+    Xa = model.hf_model.X
+    st = orc.inference(parts, theta, noise, Xa, model.hf_Y[:, 0])
+    mu, v = orc.predict_stable(parts, theta, noise, Xa, st, model._augment_data(Xs))
+    assert model.hf_model.objective_function() == pytest.approx(st["nlml"], rel=1e-9)
+    g = model.hf_model._engine.eval(theta, noise, want_grad=True)[1]
+    np.testing.assert_allclose(g, st["grad"], rtol=0, atol=1e-7 * np.abs(st["grad"]).max())
+    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-7)
+    assert float(np.mean((mean - col(cases.hf_4d)(Xs)) ** 2)) < 1e-2
+    model.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cfg4
+# ---------------------------------------------------------------------------------------------------------------
+def f3(x):
+    return (np.sin(10 * x[:, 0]) ** 2 + np.cos(10 * x[:, 1]))[:, None]
+
+
+def f2(x):
+    return 1.5 * f3(x) + 3
+
+
+def f1(x):
+    return f2(x) - 1.2 * (np.sin(0.1 * np.pi * x[:, :1]) + np.sin(0.1 * np.pi * x[:, 1:2]))
+
+
+def test_cfg4_three_chained_levels_n8192():
+    """Three fidelity levels at N = 8192 each (the reference's classes are two-level; level 3 takes level 2's
+    posterior mean as its f_low, which is any callable: src/abstractMFGP.py:82-106).  Level 1 -> 2 is handed over on
+    the device (device_chaining) and must equal the host hand-over bit for bit; the top level is checked against the
+    oracle at its fitted hyper-parameters."""
+    import multifidelity_datafusion_gps_amd as mf
+    n = 8192
+    rng = np.random.default_rng(3)
+    X1, X2, X3 = (rng.uniform(size=(n, 2)) for _ in range(3))
+    Xs = rng.uniform(size=(300, 2))
+    level2 = {}
+    for chained in (True, False):
+        m = _budgeted(evals=3, restarts=1)(2, f2, None, lf_X=X1, lf_Y=f1(X1), seed=3, name="level2",
+                                           device_chaining=chained)
+        m.fit(X2)
+        assert m._chained() == chained
+        level2[chained] = (m, m.hf_model.X.copy(), m.predict(Xs))
+    (m_on, aug_on, (mean_on, var_on)), (m_off, aug_off, (mean_off, var_off)) = level2[True], level2[False]
+    assert np.array_equal(aug_on, aug_off)                         # same augmented training inputs
+    assert [p.value for p in m_on.hf_model.parameters()] == [p.value for p in m_off.hf_model.parameters()]
+    assert np.array_equal(mean_on, mean_off) and np.array_equal(var_on, var_off)
+    m_off.close()
+    lvl2 = m_on
+    lvl3 = _budgeted(evals=3, restarts=1)(2, f3, lambda x: lvl2.predict(x)[0], seed=4, name="level3")
+    lvl3.fit(X3)
+    assert lvl3.hf_model.X.shape == (n, 3)
+    np.testing.assert_array_equal(lvl3.hf_model.X[:, 2], lvl2.predict(X3)[0][:, 0])   # level 3 sits on level 2's mean
+    mean, var = lvl3.predict(Xs)
+    parts, theta, noise = _theta_noise(lvl3)
+    st = orc.inference(parts, theta, noise, lvl3.hf_model.X, lvl3.hf_Y[:, 0])
+    mu, v = orc.predict_stable(parts, theta, noise, lvl3.hf_model.X, st, lvl3._augment_data(Xs))
+    assert lvl3.hf_model.objective_function() == pytest.approx(st["nlml"], rel=1e-9)
+    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-7)
+    assert float(np.mean((mean - f3(Xs)) ** 2)) < 0.05
+    lvl2.close()
+    lvl3.close()
+
+
+def test_cfg4_rowblock_build_in_eight_blocks_equals_fused_eval(engine):
+    """SURVEY 8(e3) at cfg4's size: K(X,X) of one N = 8192 level built as eight blocks of 1024 full rows (what eight
+    ranks would build and all-gather), then factorised in place: bitwise the fused evaluation."""
+    rng = np.random.default_rng(33)
+    n = 8192
+    X = rng.uniform(size=(n, 2))
+    Xa = np.hstack([X, f1(X)])
+    Y = f2(X)[:, 0]
+    parts, theta, noise = cases.composite(2, 1), np.array([1.1, 0.9, 0.8, 0.3, 0.5, 0.7]), 0.01 * Y.var()
+    engine.set_data(Xa, Y)
+    engine.set_kernel(parts)
+    f0, g0 = engine.eval(theta, noise, 1e-8)
+    ptr, npad = engine.dev_matrix()
+    assert npad == n and ptr
+    for b in range(8):
+        engine.kbuild_rows(theta, noise, 1e-8, b * 1024, (b + 1) * 1024)
+    f1_, g1 = engine.eval_prebuilt(True)
+    assert f1_ == f0 and np.array_equal(g1, g0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cfg5
+# ---------------------------------------------------------------------------------------------------------------
+def _cfg5_model(n_lf, seed, evals, restarts):
+    import multifidelity_datafusion_gps_amd as mf
+    rng = np.random.default_rng(4)
+    X_lf = rng.uniform(size=(n_lf, 4))
+    m = _budgeted(evals, restarts)(4, col(cases.hf_4d), None, lf_X=X_lf, lf_Y=col(cases.lf_4d)(X_lf), seed=seed,
+                                   add_noise=True, adapt_maximizer=mf.DIRECT1Maximizer())
+    return m, rng
+
+
+def _against_oracle(model, rng, atol):
+    Xs = rng.uniform(size=(64, 4))
+    mean, var = model.predict(Xs)                                  # add_noise: the noise variance is 1e-6 from here on
+    parts, theta, noise = _theta_noise(model)
+    assert noise == 1e-6
+    st = orc.inference(parts, theta, noise, model.hf_model.X, model.hf_Y[:, 0])
+    mu, v = orc.predict_stable(parts, theta, noise, model.hf_model.X, st, model._augment_data(Xs))
+    assert model.hf_model.objective_function() == pytest.approx(st["nlml"], rel=1e-7)   # add_noise regime tolerance
+    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=atol)
+    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=atol)
+
+
+def test_cfg5_adaptation_across_block_boundaries_rank1_append():
+    """cfg5 with hyper-parameters kept (reoptimize=False): N_hf 250 -> 390 crosses the 128-row boundaries at 256 and
+    384 (re-upload + refactorisation there, rank-1 appends elsewhere), add_noise=True as in the reference's
+    adaptation scripts (tests/utils.py:38-47).  The final model equals the oracle's at the same hyper-parameters."""
+    model, rng = _cfg5_model(2048, seed=5, evals=10, restarts=2)
+    model.data_driven_lf_approach = False      # adapt the HF level only (the reference's LF adaptation is unreachable)
+    model.fit(rng.uniform(size=(250, 4)))
+    model.predict(rng.uniform(size=(2, 4)))    # add_noise: noise := 1e-6, one refactorisation
+    evals0 = model.hf_model.n_evals
+    model.adapt(140, reoptimize=False)
+    assert len(model.hf_X) == 390 and model.hf_model.X.shape == (390, 5)
+    # no refits: appends, plus one lazy refactorisation after each of the two boundary re-uploads
+    assert model.hf_model.n_evals <= evals0 + 2
+    assert len(model.acquired_points) == 140 and np.all(np.array(model.acquisition_values) <= 0)
+    _against_oracle(model, rng, atol=1e-6)
+    model.close()
+
+
+def test_cfg5_adaptation_with_refit_and_add_noise_counts_evaluations():
+    """cfg5 as the reference runs it (refit after every acquisition, add_noise=True), across the boundary at 256.
+    Every fit builds a fresh GPRegression, so after the last fit the evaluation count is that fit's L-BFGS-B
+    evaluations plus ONE refactorisation for the noise overwrite -- however many predictions the batched DIRECT and
+    the caller issue afterwards (each of them re-assigns likelihood.variance = 1e-6)."""
+    model, rng = _cfg5_model(2048, seed=6, evals=5, restarts=2)
+    model.data_driven_lf_approach = False
+    model.fit(rng.uniform(size=(252, 4)))
+    model.adapt(8)                                                  # 252 -> 260, refit each step
+    assert len(model.hf_X) == 260 and model.hf_model.X.shape == (260, 5)
+    fit_evals = sum(r.n_evals for r in model.hf_model.optimization_runs)
+    n0 = model.hf_model.n_evals
+    assert n0 == fit_evals                                          # nothing but the fit so far on this model object
+    for _ in range(25):
+        model.predict(rng.uniform(size=(3, 4)))
+    assert model.hf_model.n_evals == n0 + 1                         # one refactorisation at noise = 1e-6, then none
+    _against_oracle(model, rng, atol=1e-6)
+    model.close()
+
+
+def test_add_noise_adapt_does_not_refactorise_per_prediction():
+    """add_noise=True, adapt(3) with the batched DIRECT at N ~ 1000: the high-fidelity model's
+    evaluation count grows by the refits only, not by one per predict()."""
+    import multifidelity_datafusion_gps_amd as mf
+    rng = np.random.default_rng(12)
+    model = _budgeted(evals=6, restarts=2)(4, col(cases.hf_4d), col(cases.lf_4d), seed=9, add_noise=True,
+                                           adapt_maximizer=mf.DIRECT1Maximizer())
+    model.fit(rng.uniform(size=(1000, 4)))
+    calls = {"n": 0}
+    inner = model.predict
+
+    def counting_predict(X):
+        calls["n"] += 1
+        return inner(X)
+
+    model.predict = counting_predict
+    model.adapt(3)
+    assert calls["n"] >= 3 * 10                                     # DIRECT issued many batched predictions per step
+    # after the last refit: that fit's evaluations, nothing from the predictions that preceded it
+    assert model.hf_model.n_evals == sum(r.n_evals for r in model.hf_model.optimization_runs)
+    total_before = model.hf_model.n_evals
+    model.adapt(2, reoptimize=False)                                # 2 acquisitions, appended
+    assert model.hf_model.n_evals <= total_before + 1              # ONE refactorisation (noise -> 1e-6), never per predict
+    assert len(model.hf_X) == 1005
+    model.close()
