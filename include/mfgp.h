@@ -108,13 +108,32 @@ int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitt
 
 /* Row-block form of the K build for the multi-GPU layout of SURVEY 8(e3) / north_star: each rank builds rows
  * [row_begin, row_end) (multiples of 64, within the padded size) of Ky = K + (noise+jitter) I -- all columns --
- * in place in the device matrix, the ranks all-gather their blocks through the pointer mfgp_dev_matrix returns
- * (RCCL, e.g. torch.distributed.all_gather_into_tensor on a tensor wrapping that pointer), then
+ * in place in the device matrix, the ranks all-gather their blocks (mfgp_allgather_rows: RCCL inside the library;
+ * or any other transport through mfgp_rows_download / mfgp_rows_upload or the pointer mfgp_dev_matrix returns), then
  * mfgp_eval_prebuilt factorises what is there instead of building K itself.  Same arithmetic as mfgp_eval. */
 int32_t mfgp_kbuild_rows(mfgp_handle* h, const double* theta, double noise, double jitter, int64_t row_begin,
                          int64_t row_end);
 int32_t mfgp_dev_matrix(mfgp_handle* h, void** dev_ptr, int64_t* padded_n); /* Np x Np fp64, row-major, ld = Np */
 int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, double* grad);
+
+/* ---- multi-GPU exchange steps (one process per GPU, RCCL over xGMI) -----------------------------
+ * The reference has no multi-device path; these are the collectives of the decompositions SURVEY 8(e) lists.
+ * mfgp_comm_unique_id: 128 opaque bytes (ncclUniqueId), produced on rank 0 and carried to the other ranks by the
+ *   host side's own rendezvous; mfgp_comm_init: collective over all ranks, binds a communicator to the handle
+ *   (its device, its stream); librccl is loaded lazily by these two calls only.
+ * mfgp_allgather_rows: after every rank has run mfgp_kbuild_rows on its block [rank*Np/size, (rank+1)*Np/size),
+ *   ONE in-place ncclAllGather on the device matrix completes Ky on every rank (8 Np^2/size bytes per rank).
+ * mfgp_allgather_host: recv[rank*count .. ) = send of that rank, for the small results that shard by rows
+ *   (predictive mean / variance of hf_model.predict(X*), src/MFDataFusion.py:156: 16 B per test row).
+ * mfgp_rows_download / mfgp_rows_upload: the same row blocks of the device matrix through host memory, for
+ *   transports other than RCCL. */
+int32_t mfgp_comm_unique_id(uint8_t* out128);
+int32_t mfgp_comm_init(mfgp_handle* h, const uint8_t* id128, int32_t rank, int32_t size);
+int32_t mfgp_comm_destroy(mfgp_handle* h);
+int32_t mfgp_allgather_rows(mfgp_handle* h);
+int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, double* recv);
+int32_t mfgp_rows_download(mfgp_handle* h, int64_t row_begin, int64_t row_end, double* out);
+int32_t mfgp_rows_upload(mfgp_handle* h, int64_t row_begin, int64_t row_end, const double* in);
 
 /* the pieces of mfgp_eval, for callers that want them separately (same state machine) */
 int32_t mfgp_factorize(mfgp_handle* h, const double* theta, double noise, double jitter);

@@ -22,6 +22,8 @@ EXPORTED_SYMBOLS = [
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters", "mfgp_device_synchronize",
+    "mfgp_comm_unique_id", "mfgp_comm_init", "mfgp_comm_destroy", "mfgp_allgather_rows", "mfgp_allgather_host",
+    "mfgp_rows_download", "mfgp_rows_upload",
     "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf",
 ]
 
@@ -108,6 +110,13 @@ def load_library(path=None):
         "mfgp_get_timings": (i32, [H, ctypes.POINTER(Timings)]),
         "mfgp_get_counters": (i32, [H, ctypes.POINTER(Counters), i32]),
         "mfgp_device_synchronize": (i32, [H]),
+        "mfgp_comm_unique_id": (i32, [ctypes.POINTER(ctypes.c_uint8)]),
+        "mfgp_comm_init": (i32, [H, ctypes.POINTER(ctypes.c_uint8), i32, i32]),
+        "mfgp_comm_destroy": (i32, [H]),
+        "mfgp_allgather_rows": (i32, [H]),
+        "mfgp_allgather_host": (i32, [H, dp, i64, dp]),
+        "mfgp_rows_download": (i32, [H, i64, i64, dp]),
+        "mfgp_rows_upload": (i32, [H, i64, i64, dp]),
         "mfgp_dbg_gemm_nt": (i32, [H, dp, dp, dp, i32, i32, i32, f64, f64, i32]),
         "mfgp_dbg_leaf": (i32, [H, dp, dp, dp, dp]),
     }
@@ -144,6 +153,7 @@ class Engine:
         self.device = device
         self.n = 0
         self.n_parts = 0
+        self.comm_rank, self.comm_size = 0, 1
 
     # -- plumbing -------------------------------------------------------------------------------
     def close(self):
@@ -208,6 +218,50 @@ class Engine:
         p, n = ctypes.c_void_p(), ctypes.c_int64()
         self._check(self._lib.mfgp_dev_matrix(self._h, ctypes.byref(p), ctypes.byref(n)), "mfgp_dev_matrix")
         return p.value, n.value
+
+    # -- exchange steps of the multi-GPU path (RCCL inside the library; comm_rccl.hip) ------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes (ncclUniqueId) to be produced on rank 0 and handed to every rank's comm_init"""
+        lib = load_library()
+        buf = (ctypes.c_uint8 * 128)()
+        rc = lib.mfgp_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("mfgp_comm_unique_id failed (%d): %s" % (rc, lib.mfgp_last_error(None).decode()))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, size):
+        """collective: bind an RCCL communicator of `size` ranks to this handle (its device, its stream)"""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.mfgp_comm_init(self._h, buf, int(rank), int(size)), "mfgp_comm_init")
+        self.comm_rank, self.comm_size = int(rank), int(size)
+
+    def comm_destroy(self):
+        self._check(self._lib.mfgp_comm_destroy(self._h), "mfgp_comm_destroy")
+
+    def allgather_rows(self):
+        """in-place RCCL all-gather of the ranks' row blocks of the device matrix (after kbuild_rows)"""
+        self._check(self._lib.mfgp_allgather_rows(self._h), "mfgp_allgather_rows")
+
+    def allgather_host(self, send):
+        """-> (size, count) array: row r = rank r's `send` (equal counts on every rank), through RCCL"""
+        send = _c64(send).reshape(-1)
+        out = np.empty((self.comm_size, send.shape[0]))
+        self._check(self._lib.mfgp_allgather_host(self._h, _dptr(send), send.shape[0], _dptr(out)), "mfgp_allgather_host")
+        return out
+
+    def rows_download(self, row_begin, row_end):
+        _, npad = self.dev_matrix()
+        out = np.empty((int(row_end) - int(row_begin), npad))
+        self._check(self._lib.mfgp_rows_download(self._h, int(row_begin), int(row_end), _dptr(out)), "mfgp_rows_download")
+        return out
+
+    def rows_upload(self, row_begin, block):
+        block = _c64(block)
+        self._check(self._lib.mfgp_rows_upload(self._h, int(row_begin), int(row_begin) + block.shape[0], _dptr(block)),
+                    "mfgp_rows_upload")
 
     def eval_prebuilt(self, want_grad=True):
         nlml = ctypes.c_double()

@@ -21,579 +21,36 @@
 
 using namespace mfgp;
 
-namespace {
-thread_local std::string g_err;
-
-enum Buf { BUF_A = 0, BUF_L = 1, BUF_S = 2, BUF_W = 3 };
-
-struct Step {
-    int kind;  // 0 = leaf, 1 = gemm
-    int role;  // gemm kernel symbol: 0 recursion, 1 K^-1, 2 predictive variance, 3 serial-chain step (slim workgroups)
-    int strm;  // 0 = main stream (the serial chain), 1 = bulk-update stream (look-ahead)
-    int wait_ev, rec_ev;  // 1-based indices into the event pool (0 = none): wait before / record after the launch
-    int blk;   // leaf block
-    int tile, first, count, a, b, c, c2;  // gemm
-};
-}  // namespace
-
-struct mfgp_handle {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;      // bulk trailing updates of the look-ahead Cholesky
-    std::vector<hipEvent_t> evpool;     // cross-stream dependencies of the plan
-    std::string err, info_str;
-    int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
-    int D = 0, nblk = 0;
-    double* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    double *dX = nullptr, *dXs = nullptr, *dY = nullptr, *dz = nullptr, *dalpha = nullptr;
-    double *dlogdet = nullptr, *dres = nullptr, *dpart = nullptr, *dvec = nullptr,
-           *dvec2 = nullptr;
-    int* dinfo = nullptr;
-    GemmTask* dtasks = nullptr;
-    size_t tasks_cap = 0;
-    int xs_cap_rows = 0, xs_cap_D = 0;
-    double *dXc = nullptr, *dm = nullptr, *doffs = nullptr, *dAug = nullptr;  // level chaining scratch
-    int64_t ch_rows = 0;
-    int ch_c = 0, ch_D = 0;             // the chain scratch is sized for (ch_rows, ch_c) at input width ch_D
-    double* hres = nullptr;  // pinned
-    int* hinfo = nullptr;    // pinned
-    bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 1024 unless MFGP_STAGE_TIMING=1)
-    std::vector<GemmTask> tasks;
-    std::vector<Step> plan;         // cholinv
-    Step kinv_step{}, predv_step{};
-    int predv_rows = 0;
-    KernSpecDev spec{};
-    bool have_kernel = false, have_data = false, factorized = false, kinv_valid = false, grad_valid = false,
-         params_set = false;
-    double theta[2 * MFGP_MAX_PARTS] = {0};
-    double noise = 0, jitter = 0;
-    double quad = 0, logdet = 0;
-    double grad[2 * MFGP_MAX_PARTS + 1] = {0};
-    hipEvent_t ev[10] = {};
-    mfgp_timings tm{};
-    mfgp_counters cum{};
-    int64_t launches = 0;
-};
-
-#define HIPCHK(h, call)                                                                         \
-    do {                                                                                        \
-        hipError_t e_ = (call);                                                                 \
-        if (e_ != hipSuccess) {                                                                 \
-            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);                 \
-            if (h) (h)->err = m_; else g_err = m_;                                              \
-            return -2;                                                                          \
-        }                                                                                       \
-    } while (0)
-
-static int fail(mfgp_handle* h, int code, const std::string& msg) {
-    if (h) h->err = msg; else g_err = msg;
-    return code;
-}
-
-// ------------------------------------------------------------------------------------------------
-// planner
-// ------------------------------------------------------------------------------------------------
-static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group);
-static int pick_tile(int ntiles128) {
-    // 128-tiles run the MFMA pipe better, but a launch of few tiles is bound by its LONGEST tile (one tile per CU, 256
-    // CUs): below ~300 tiles four times as many 64-tiles balance better (top inverse level at N = 4096: 2 x 330 -> 2 x 220 us)
-    static const int t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : 300;
-    return ntiles128 >= t128_min ? 128 : 64;
-}
-
-static void add_gemm(mfgp_handle* h, std::vector<Step>& plan, int tile, int first, int a, int b, int c, int c2) {
-    Step s{};
-    s.kind = 1;
-    s.tile = tile;
-    s.first = first;
-    s.count = (int)h->tasks.size() - first;
-    s.a = a; s.b = b; s.c = c; s.c2 = c2;
-    if (s.count > 0) plan.push_back(s);
-}
-
-// recursive Cholesky + inverse over leaf blocks [b0, b1)
-static void plan_cholinv(mfgp_handle* h, int b0, int b1) {
-    const int64_t ld = h->Np;
-    if (b1 - b0 == 1) {
-        Step s{};
-        s.kind = 0;
-        s.blk = b0;
-        h->plan.push_back(s);
-        return;
-    }
-    const int bm = b0 + (b1 - b0 + 1) / 2;
-    plan_cholinv(h, b0, bm);
-    const int n1 = bm - b0, n2 = b1 - bm;
-    const int T = pick_tile(n1 * n2);
-    const int sc = NB / T;
-    const int64_t k0 = (int64_t)b0 * NB, km = (int64_t)bm * NB;
-    // L21 = A21 * X11^T      (A: A, B: S lower rows j, C: L)
-    {
-        const int first = (int)h->tasks.size();
-        for (int j = b0 * sc; j < bm * sc; ++j)       // long K first
-            for (int i = bm * sc; i < b1 * sc; ++i) {
-                GemmTask t{};
-                t.a_off = (int64_t)i * T * ld + k0;
-                t.b_off = (int64_t)j * T * ld + k0;
-                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                t.c2_off = -1;
-                t.klen = (int)((int64_t)(j + 1) * T - k0);
-                t.flags = TF_B_LOWER;
-                t.alpha = 1.0; t.beta = 0.0;
-                h->tasks.push_back(t);
-            }
-        // descending K length for load balance
-        std::stable_sort(h->tasks.begin() + first, h->tasks.end(),
-                         [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
-        add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
-    }
-    // A22 -= L21 L21^T       (A: L, B: L, C: A), lower tiles only
-    {
-        const int T2 = pick_tile(n2 * (n2 + 1) / 2);
-        const int s2 = NB / T2;
-        const int first = (int)h->tasks.size();
-        for (int i = bm * s2; i < b1 * s2; ++i)
-            for (int j = bm * s2; j <= i; ++j) {
-                GemmTask t{};
-                t.a_off = (int64_t)i * T2 * ld + k0;
-                t.b_off = (int64_t)j * T2 * ld + k0;
-                t.c_off = (int64_t)i * T2 * ld + (int64_t)j * T2;
-                t.c2_off = -1;
-                t.klen = n1 * NB;
-                t.flags = 0;
-                t.alpha = -1.0; t.beta = 1.0;
-                h->tasks.push_back(t);
-            }
-        add_gemm(h, h->plan, T2, first, BUF_L, BUF_L, BUF_A, -1);
-    }
-    plan_cholinv(h, bm, b1);
-    // P^T[j][i] = sum_{k>=j} X11^T[j][k] L21[i][k]     (A: S upper rows j, B: L rows i, C: W[j][i])
-    {
-        const int first = (int)h->tasks.size();
-        for (int j = b0 * sc; j < bm * sc; ++j)
-            for (int i = bm * sc; i < b1 * sc; ++i) {
-                GemmTask t{};
-                t.a_off = (int64_t)j * T * ld + (int64_t)j * T;
-                t.b_off = (int64_t)i * T * ld + (int64_t)j * T;
-                t.c_off = (int64_t)j * T * ld + (int64_t)i * T;
-                t.c2_off = -1;
-                t.klen = (int)(km - (int64_t)j * T);
-                t.flags = TF_A_UPPER;
-                t.alpha = 1.0; t.beta = 0.0;
-                h->tasks.push_back(t);
-            }
-        add_gemm(h, h->plan, T, first, BUF_S, BUF_L, BUF_W, -1);
-    }
-    // X21[i][j] = - sum_{k<=i} X22[i][k] P^T[j][k]     (A: S lower rows i, B: W rows j, C: S lower + mirror)
-    {
-        const int first = (int)h->tasks.size();
-        for (int i = b1 * sc - 1; i >= bm * sc; --i)  // long K first
-            for (int j = b0 * sc; j < bm * sc; ++j) {
-                GemmTask t{};
-                t.a_off = (int64_t)i * T * ld + km;
-                t.b_off = (int64_t)j * T * ld + km;
-                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                t.c2_off = (int64_t)j * T * ld + (int64_t)i * T;
-                t.klen = (int)((int64_t)(i + 1) * T - km);
-                t.flags = TF_A_LOWER;
-                t.alpha = -1.0; t.beta = 0.0;
-                h->tasks.push_back(t);
-            }
-        add_gemm(h, h->plan, T, first, BUF_S, BUF_W, BUF_S, BUF_S);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// plan B (default): right-looking blocked Cholesky (NB = 128) followed by a level-batched recursive
-// triangular inverse.  Per block column k: leaf(k) factorises AND inverts the diagonal block, the
-// panel below becomes L[i,k] = A[i,k] X_kk^T (tile GEMMs, K = 128), then the trailing SYRK update.
-// The inverse X = L^-1 is then assembled bottom-up: every node of one tree level is independent, so a
-// level is TWO launches (P^T = X11^T L21^T ; X21 = -X22 P) however many nodes it has.
-// ------------------------------------------------------------------------------------------------
-static int new_event(mfgp_handle* h, int& counter) {
-    ++counter;
-    while ((int)h->evpool.size() < counter) {
-        hipEvent_t e;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        h->evpool.push_back(e);
-    }
-    return counter;  // 1-based
-}
-
-static void plan_potrf_rl(mfgp_handle* h) {
-    // Blocked Cholesky with macro panels of MB leaf blocks and look-ahead over two streams.
-    //   main stream (the serial chain), for every block column c of a macro panel [M0, M1):
-    //       leaf(c)     : L_cc, X_cc = L_cc^-1
-    //       panel(c)    : L[i,c] = A[i,c] X_cc^T, i > c
-    //       inner(c)    : A[i,j] -= L[i,c] L[j,c]^T for the macro's later columns j in (c, M1), K = 128 (right-looking
-    //                     inside the macro; MFGP_INNER_RIGHT=0: left-looking colupdate(c) before leaf(c) instead)
-    //   bulk stream, after the macro's chain: A[i,j] -= L[i,M0:M1] L[j,M0:M1]^T (K = MB*128), first the block
-    //       columns of the NEXT macro panel one by one (each releases the chain step that needs it), then the rest,
-    //       which overlaps the next macro's chain.
-    const int64_t ld = h->Np;
-    const int nb = h->nblk;
-    int MB = 4;   // 2 is ~1.5 % faster for one evaluation alone, 4 is ~5 % faster with evaluations in flight (bench)
-    if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
-    bool lookahead = true;
-    if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
-    // inside a macro panel: right-looking (after panel(c), column c's K = 128 contribution to the macro's later columns)
-    // instead of left-looking (before leaf(c), the K <= (MB-1)*128 contribution of the macro's earlier columns to
-    // column c): a step on the chain costs launch + K-depth, and K = 128 three times beats 128 + 256 + 384
-    // (N = 8192: 11.28 -> 11.04 ms, 4096: 3.57 -> 3.43, 2048: 1.46 -> 1.36)
-    bool inner_right = true;
-    if (const char* e = getenv("MFGP_INNER_RIGHT")) inner_right = atoi(e) != 0;
-    // `shift`: the chain's K = 128 inner updates also cover the NEXT macro panel's first column, so that no K = MB*128
-    // step (and no wait for the previous macro's bulk update) gates its first leaf.  Pays where the factorisation is
-    // chain-bound throughout (N = 4096: 3.42 -> 3.28 ms, 2048: 1.37 -> 1.28); neutral at N = 8192, where the first half
-    // is bound by the bulk updates and the gating step's slack is worth as much as its latency.
-    bool shift = nb < 48;
-    if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
-    shift = shift && lookahead && inner_right;
-    bool merge_cols = true;
-    if (const char* e = getenv("MFGP_MERGE_COLS")) merge_cols = atoi(e) != 0;
-    // slim chain workgroups (role 3) co-reside with the bulk update's workgroups; alone they are ~30 % slower than the
-    // double-buffered 64-tile kernel, so they only pay where bulk updates are long enough to overlap the chain
-    int chain_role = (lookahead && nb >= 48) ? 3 : 0;
-    if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
-    int nev = 0;
-    auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
-        // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
-        const int sc = NB / T;
-        for (int j = jlo * sc; j < jhi * sc; ++j)
-            for (int i = j; i < nb * sc; ++i) {
-                GemmTask t{};
-                t.a_off = (int64_t)i * T * ld + (int64_t)klo * NB;
-                t.b_off = (int64_t)j * T * ld + (int64_t)klo * NB;
-                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                t.c2_off = -1;
-                t.klen = (khi - klo) * NB;
-                t.flags = 0;
-                t.alpha = -1.0; t.beta = 1.0;
-                h->tasks.push_back(t);
-            }
-    };
-    auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
-    std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
-    int ev_rest_prev = 0;            // event after the previous macro's bulk update of the REST (bulk stream)
-    for (int M0 = 0; M0 < nb; M0 += MB) {
-        const int M1 = std::min(M0 + MB, nb);
-        const int M2 = std::min(M1 + MB, nb);
-        int main_waited_ev = 0;   // the merged column launch signals ONE event for several columns: wait for it once
-        for (int c = M0; c < M1; ++c) {
-            bool waited = false;
-            if (c > M0 && !inner_right) {   // left-looking update of block column c with the macro's finished columns
-                const int T = 64;  // latency-bound, on the serial chain: many small tiles
-                const int first = (int)h->tasks.size();
-                syrk_tasks(T, c, c + 1, M0, c);
-                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-                h->plan.back().role = chain_role;
-                if (lookahead && ev_col[c] > 0) {
-                    if (ev_col[c] != main_waited_ev) h->plan.back().wait_ev = main_waited_ev = ev_col[c];
-                    waited = true;   // (an event wait costs ~6 us on the chain even when already signalled)
-                }
-            }
-            Step s{};
-            s.kind = 0;
-            s.blk = c;
-            if (lookahead && !waited && ev_col[c] > 0 && ev_col[c] != main_waited_ev) s.wait_ev = main_waited_ev = ev_col[c];
-            h->plan.push_back(s);
-            const int rem = nb - 1 - c;
-            if (rem == 0) break;
-            const int64_t kc = (int64_t)c * NB;
-            {   // panel: L[i,c] = A[i,c] * X_cc^T
-                const int T = pick_tile(rem);
-                const int sc = NB / T;
-                const int first = (int)h->tasks.size();
-                for (int i = (c + 1) * sc; i < nb * sc; ++i)
-                    for (int j = c * sc; j < (c + 1) * sc; ++j) {
-                        GemmTask t{};
-                        t.a_off = (int64_t)i * T * ld + kc;
-                        t.b_off = (int64_t)j * T * ld + kc;
-                        t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                        t.c2_off = -1;
-                        t.klen = (int)((int64_t)(j + 1) * T - kc);
-                        t.flags = TF_B_LOWER;
-                        t.alpha = 1.0; t.beta = 0.0;
-                        h->tasks.push_back(t);
-                    }
-                add_gemm(h, h->plan, T, first, BUF_A, BUF_S, BUF_L, -1);
-                if (T == 64) h->plan.back().role = chain_role;
-            }
-            // right-looking inside the macro: column c -> the macro's later columns, K = 128.  `shift`: also -> the first
-            // column of the NEXT macro panel, so that no K = MB*128 step gates its first leaf
-            const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
-            if (inner_right && c + 1 < inner_hi) {
-                const int first = (int)h->tasks.size();
-                syrk_tasks(64, c + 1, inner_hi, c, c + 1);
-                add_gemm(h, h->plan, 64, first, BUF_L, BUF_L, BUF_A, -1);
-                h->plan.back().role = chain_role;
-                const int e = ev_col[c + 1];
-                if (lookahead && e > 0 && e != main_waited_ev) h->plan.back().wait_ev = main_waited_ev = e;
-            }
-        }
-        if (M1 >= nb) break;
-        if (!lookahead) {
-            const int r = nb - M1;
-            const int T = pick_tile(r * (r + 1) / 2);
-            const int first = (int)h->tasks.size();
-            syrk_tasks(T, M1, nb, M0, M1);
-            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-            continue;
-        }
-        const int ev_chain = new_event(h, nev);
-        h->plan.back().rec_ev = ev_chain;   // chain(M) complete: every L[:, M0:M1] panel is final
-        bool first_bulk = true;
-        if (shift) {
-            // the chain has already brought the next macro panel's first column up to date; the bulk stream takes the
-            // columns (M1, M1+MB] in one launch (the next chain waits for its event once) and everything beyond in another
-            const int lo = M1 + 1, hi = std::min(M1 + MB, nb - 1);
-            if (lo <= hi) {
-                const int T = pick_tile(ntiles_cols(lo, hi + 1));
-                const int first = (int)h->tasks.size();
-                syrk_tasks(T, lo, hi + 1, M0, M1);
-                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-                Step& st = h->plan.back();
-                st.strm = 1;
-                st.wait_ev = ev_chain;
-                first_bulk = false;
-                const int ev = new_event(h, nev);
-                st.rec_ev = ev;
-                for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
-            }
-            if (hi + 1 < nb) {
-                const int T = pick_tile(ntiles_cols(hi + 1, nb));
-                const int first = (int)h->tasks.size();
-                syrk_tasks(T, hi + 1, nb, M0, M1);
-                add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-                h->plan.back().strm = 1;
-                if (first_bulk) h->plan.back().wait_ev = ev_chain;
-            }
-            continue;
-        }
-        {
-            // the column that gates the next leaf stays on the MAIN stream: no event round trip on the chain.
-            // It must still come after the previous macro's rest-update, which covers this column too and
-            // runs on the bulk stream (normally long finished: the wait is on an already signalled event).
-            const int T = pick_tile(nb - M1);
-            const int first = (int)h->tasks.size();
-            syrk_tasks(T, M1, M1 + 1, M0, M1);
-            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-            Step& st = h->plan.back();
-            st.strm = 0;
-            if (T == 64) st.role = chain_role;
-            st.wait_ev = ev_rest_prev;
-            ev_col[M1] = 0;
-        }
-        if (M1 + 1 < M2) {
-            // the other block columns of the next macro panel: ONE launch on the bulk stream (each is needed one chain
-            // step later than the previous; a launch per column left the GPU at ~140 workgroups three times in a row)
-            const int cols = M2 - (M1 + 1);
-            const int T = merge_cols ? pick_tile(cols * (nb - M1 - 1)) : 64;
-            for (int c = M1 + 1; c < M2; c += merge_cols ? cols : 1) {
-                const int first = (int)h->tasks.size();
-                syrk_tasks(merge_cols ? T : pick_tile(nb - c), c, merge_cols ? M2 : c + 1, M0, M1);
-                add_gemm(h, h->plan, merge_cols ? T : pick_tile(nb - c), first, BUF_L, BUF_L, BUF_A, -1);
-                Step& st = h->plan.back();
-                st.strm = 1;
-                if (first_bulk) st.wait_ev = ev_chain;
-                first_bulk = false;
-                const int ev = new_event(h, nev);
-                st.rec_ev = ev;
-                for (int cc = c; cc < (merge_cols ? M2 : c + 1); ++cc) ev_col[cc] = ev;
-            }
-        }
-        if (M2 < nb) {   // the rest of the trailing matrix: overlaps the next macro panel's chain
-            const int T = pick_tile(ntiles_cols(M2, nb));
-            const int first = (int)h->tasks.size();
-            syrk_tasks(T, M2, nb, M0, M1);
-            add_gemm(h, h->plan, T, first, BUF_L, BUF_L, BUF_A, -1);
-            h->plan.back().strm = 1;
-            if (first_bulk) h->plan.back().wait_ev = ev_chain;   // MB = 1: nothing else waited on the chain yet
-            ev_rest_prev = new_event(h, nev);
-            h->plan.back().rec_ev = ev_rest_prev;
-        } else {
-            ev_rest_prev = 0;
-        }
-    }
-}
-
-
-struct TriNode { int b0, bm, b1, level; };
-static int collect_nodes(int b0, int b1, std::vector<TriNode>& out) {
-    if (b1 - b0 <= 1) return 0;
-    const int bm = b0 + (b1 - b0 + 1) / 2;
-    const int l = std::max(collect_nodes(b0, bm, out), collect_nodes(bm, b1, out)) + 1;
-    out.push_back(TriNode{b0, bm, b1, l});
-    return l;
-}
-
-static void plan_trtri_levels(mfgp_handle* h) {
-    const int64_t ld = h->Np;
-    std::vector<TriNode> nodes;
-    const int top = collect_nodes(0, h->nblk, nodes);
-    for (int lev = 1; lev <= top; ++lev) {
-        int ntiles = 0;
-        for (const TriNode& n : nodes)
-            if (n.level == lev) ntiles += (n.bm - n.b0) * (n.b1 - n.bm);
-        const int T = pick_tile(ntiles);
-        const int sc = NB / T;
-        {   // P^T[j][i] = sum_{k>=j} X11^T[j][k] L21[i][k]
-            const int first = (int)h->tasks.size();
-            for (const TriNode& n : nodes) {
-                if (n.level != lev) continue;
-                const int64_t km = (int64_t)n.bm * NB;
-                for (int j = n.b0 * sc; j < n.bm * sc; ++j)
-                    for (int i = n.bm * sc; i < n.b1 * sc; ++i) {
-                        GemmTask t{};
-                        t.a_off = (int64_t)j * T * ld + (int64_t)j * T;
-                        t.b_off = (int64_t)i * T * ld + (int64_t)j * T;
-                        t.c_off = (int64_t)j * T * ld + (int64_t)i * T;
-                        t.c2_off = -1;
-                        t.klen = (int)(km - (int64_t)j * T);
-                        t.flags = TF_A_UPPER;
-                        t.alpha = 1.0; t.beta = 0.0;
-                        h->tasks.push_back(t);
-                    }
-            }
-            std::stable_sort(h->tasks.begin() + first, h->tasks.end(),
-                             [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
-            add_gemm(h, h->plan, T, first, BUF_S, BUF_L, BUF_W, -1);
-        }
-        {   // X21[i][j] = - sum_{k<=i} X22[i][k] P^T[j][k]
-            const int first = (int)h->tasks.size();
-            for (const TriNode& n : nodes) {
-                if (n.level != lev) continue;
-                const int64_t km = (int64_t)n.bm * NB;
-                for (int i = n.bm * sc; i < n.b1 * sc; ++i)
-                    for (int j = n.b0 * sc; j < n.bm * sc; ++j) {
-                        GemmTask t{};
-                        t.a_off = (int64_t)i * T * ld + km;
-                        t.b_off = (int64_t)j * T * ld + km;
-                        t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                        t.c2_off = (int64_t)j * T * ld + (int64_t)i * T;
-                        t.klen = (int)((int64_t)(i + 1) * T - km);
-                        t.flags = TF_A_LOWER;
-                        t.alpha = -1.0; t.beta = 0.0;
-                        h->tasks.push_back(t);
-                    }
-            }
-            std::stable_sort(h->tasks.begin() + first, h->tasks.end(),
-                             [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
-            add_gemm(h, h->plan, T, first, BUF_S, BUF_W, BUF_S, BUF_S);
-        }
-    }
-}
-
-// XCD-aware task placement.  Workgroup p of a launch lands on XCD p mod 8 (each XCD has its own L2); a task list in
-// row-major tile order therefore hands every XCD tiles that share almost no operand panel.  `tasks[first..)` arrives
-// in LOCALITY order (runs of `group` consecutive tasks = one compact block of output tiles sharing operand panels);
-// the runs are dealt to the 8 XCDs in serpentine order (0..7, 7..0: the work per run decreases along the list, a plain
-// round-robin would give XCD 0 the longest run of every round) and the per-XCD sequences interleaved, so that XCD x executes whole
-// runs back to back.  Pure reordering: every tile's arithmetic (and the result bits) is unchanged.
-static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group) {
-    static const bool on = !(getenv("MFGP_XCD_ORDER") && atoi(getenv("MFGP_XCD_ORDER")) == 0);
-    const int n = (int)tasks.size() - first;
-    if (!on || n < 8 * group) return;
-    std::vector<GemmTask> lists[8];
-    int g = 0;
-    for (int t0 = 0; t0 < n; t0 += group, ++g)
-        for (int t = t0; t < std::min(n, t0 + group); ++t)   // serpentine deal: the runs come in descending work
-            lists[(g & 8) ? 7 - (g & 7) : (g & 7)].push_back(tasks[first + t]);
-    int out = first;
-    for (size_t m = 0; out < first + n; ++m)
-        for (int x = 0; x < 8; ++x)
-            if (m < lists[x].size()) tasks[out++] = lists[x][m];
-}
-
-static void plan_kinv(mfgp_handle* h) {
-    const int64_t ld = h->Np;
-    const int nb = h->nblk;
-    static const int kinv_t128_min = getenv("MFGP_KINV_T128_MIN") ? atoi(getenv("MFGP_KINV_T128_MIN")) : 600;   // N = 4096: 0.65 -> 0.54 ms, N = 3072: 0.48 -> 0.25 ms
-    const int T = nb * (nb + 1) / 2 >= kinv_t128_min ? 128 : 64;
-    const int sc = NB / T;
-    const int first = (int)h->tasks.size();
-    // locality order: super-blocks of BI x BJ output tiles (BI row panels + BJ column panels feed BI*BJ tiles);
-    // small i (= long K range) first.  Measured at N = 8192 (tools/sweep_kinv_order.sh): 1x8 3.73 ms / 3.05 GB fetched,
-    // 4x8 3.85 ms / 2.28 GB, row-major without XCD placement 3.9 ms / 3.69 GB -- the launch is FMA-bound, so the
-    // finer run (better balance over the XCDs) wins over the larger one (fewer panel re-reads).
-    int BI = 1, BJ = 8;
-    if (const char* e = getenv("MFGP_KINV_BI")) BI = std::max(1, atoi(e));
-    if (const char* e = getenv("MFGP_KINV_BJ")) BJ = std::max(1, atoi(e));
-    const int nt = nb * sc;
-    for (int i0 = 0; i0 < nt; i0 += BI)
-        for (int j0 = 0; j0 <= std::min(nt - 1, i0 + BI - 1); j0 += BJ)
-            for (int i = i0; i < std::min(nt, i0 + BI); ++i)
-                for (int j = j0; j < std::min(j0 + BJ, i + 1); ++j) {
-                    GemmTask t{};
-                    t.a_off = (int64_t)i * T * ld + (int64_t)i * T;
-                    t.b_off = (int64_t)j * T * ld + (int64_t)i * T;
-                    t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
-                    t.c2_off = -1;
-                    t.klen = (int)(h->Np - (int64_t)i * T);
-                    t.flags = TF_A_UPPER | (i == j ? TF_B_UPPER : 0);
-                    t.alpha = 1.0; t.beta = 0.0;
-                    h->tasks.push_back(t);
-                }
-    xcd_interleave(h->tasks, first, BI * BJ);
-    std::vector<Step> tmp;
-    add_gemm(h, tmp, T, first, BUF_S, BUF_S, BUF_A, -1);
-    h->kinv_step = tmp.empty() ? Step{} : tmp[0];
-    h->kinv_step.role = 1;
-}
-
-// V[r][i] = sum_{k<=i} Kx[r][k] X[i][k]   (A: W = Kx panel, B: S lower rows i, C: A)
-static void plan_predv(mfgp_handle* h, int rows_p) {
-    const int64_t ld = h->Np;
-    const int nb = h->nblk, rb = rows_p / NB;
-    const int T = pick_tile(nb * rb);
-    const int sc = NB / T;
-    const int first = (int)h->tasks.size();
-    const int BI = 8, BR = 4, ni = nb * sc, nr = rb * sc;   // super-blocks: BI rows of X  x  BR panel rows
-    for (int i0 = ni - 1; i0 >= 0; i0 -= BI)                 // large i (= long K range) first
-        for (int r0 = 0; r0 < nr; r0 += BR)
-            for (int i = i0; i > std::max(-1, i0 - BI); --i)
-                for (int r = r0; r < std::min(nr, r0 + BR); ++r) {
-                    GemmTask t{};
-                    t.a_off = (int64_t)r * T * ld;
-                    t.b_off = (int64_t)i * T * ld;
-                    t.c_off = (int64_t)r * T * ld + (int64_t)i * T;
-                    t.c2_off = -1;
-                    t.klen = (int)((int64_t)(i + 1) * T);
-                    t.flags = TF_B_LOWER;
-                    t.alpha = 1.0; t.beta = 0.0;
-                    h->tasks.push_back(t);
-                }
-    xcd_interleave(h->tasks, first, BI * BR);
-    std::vector<Step> tmp;
-    add_gemm(h, tmp, T, first, BUF_W, BUF_S, BUF_A, -1);
-    h->predv_step = tmp.empty() ? Step{} : tmp[0];
-    h->predv_step.role = 2;
-    h->predv_rows = rows_p;
-}
+thread_local std::string mfgp::g_err;
 
 static int upload_tasks(mfgp_handle* h) {
-    const size_t need = h->tasks.size();
+    const size_t need = h->pl.tasks.size();
     if (need > h->tasks_cap) {
         if (h->dtasks) HIPCHK(h, hipFree(h->dtasks));
         h->tasks_cap = need + need / 2 + 1024;
         HIPCHK(h, hipMalloc(&h->dtasks, h->tasks_cap * sizeof(GemmTask)));
     }
-    HIPCHK(h, hipMemcpyAsync(h->dtasks, h->tasks.data(), need * sizeof(GemmTask), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->dtasks, h->pl.tasks.data(), need * sizeof(GemmTask), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
-static void run_step(mfgp_handle* h, const Step& s) {
+static void run_step(mfgp_handle* h, const Step& s, bool want_grad = true) {
     hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
     if (s.wait_ev > 0) (void)hipStreamWaitEvent(st, h->evpool[s.wait_ev - 1], 0);
     if (s.kind == 0) {
         launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
-    } else {
-        launch_gemm(st, s.tile, h->dtasks + s.first, s.count, h->buf[s.a], h->buf[s.b], h->buf[s.c],
-                    s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np, s.role);
-    }
+        h->launches++;
+    } else if (s.kind == 1) {
+        const int n = s.count + (want_grad ? s.count_grad : 0);   // the K^-1 accumulation rides along only for a gradient
+        if (n > 0) {
+            launch_gemm(st, s.tile, h->dtasks + s.first, n, h->buf[s.a], h->buf[s.b], h->buf[s.c],
+                        s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np, s.role);
+            h->launches++;
+        }
+    }   // kind 2: join -- the wait above is all there is
     if (s.rec_ev > 0) (void)hipEventRecord(h->evpool[s.rec_ev - 1], st);
-    h->launches++;
+    if (s.rec_ev_final > 0) (void)hipEventRecord(h->evpool[s.rec_ev_final - 1], st);
 }
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) {
@@ -676,7 +133,9 @@ static int create_body(mfgp_handle* h, int device_id) {
 const char* mfgp_device_info(mfgp_handle* h) { return h ? h->info_str.c_str() : ""; }
 
 static void free_mats(mfgp_handle* h) {
-    for (auto& b : h->buf) { if (b) hipFree(b); b = nullptr; }
+    if (h->slab) hipFree(h->slab);
+    h->slab = nullptr;
+    for (auto& b : h->buf) b = nullptr;
     for (double** p : {&h->dX, &h->dY, &h->dz, &h->dalpha, &h->dlogdet, &h->dpart, &h->dvec, &h->dvec2}) {
         if (*p) hipFree(*p);
         *p = nullptr;
@@ -695,6 +154,8 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->doffs) hipFree(h->doffs);
     if (h->dAug) hipFree(h->dAug);
     if (h->dtasks) hipFree(h->dtasks);
+    comm_release(h);
+    if (h->dstage) hipFree(h->dstage);
     if (h->hres) hipHostFree(h->hres);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
@@ -705,17 +166,12 @@ int32_t mfgp_destroy(mfgp_handle* h) {
 }
 
 static int build_plans(mfgp_handle* h) {
-    h->tasks.clear();
-    h->plan.clear();
-    const char* pm = getenv("MFGP_PLAN");
-    if (pm && strcmp(pm, "recursive") == 0) {
-        plan_cholinv(h, 0, h->nblk);
-    } else {
-        plan_potrf_rl(h);
-        plan_trtri_levels(h);
+    build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap);
+    while ((int)h->evpool.size() < h->pl.n_events) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->evpool.push_back(e);
     }
-    plan_kinv(h);
-    h->predv_rows = 0;
     return upload_tasks(h);
 }
 
@@ -724,6 +180,7 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
     if (N < 1 || D < 1 || D > 32) return fail(h, -1, "mfgp_set_data: need N >= 1 and 1 <= D <= 32 (LDS staging of the covariance kernels)");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t Np = (N + NB - 1) / NB * NB;
+    bool realloc_ = false;
     if (Np > h->cap || D != h->D) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         // growth is geometric (x1.25, rounded to the block) once a handle has to grow: an adaptation run that adds one
@@ -732,7 +189,11 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
         int64_t cap = std::max(Np, h->cap);
         if (h->cap > 0 && Np > h->cap) cap = std::max(Np, (h->cap + h->cap / 4 + NB - 1) / NB * NB);
         free_mats(h);
-        for (auto& b : h->buf) HIPCHK(h, hipMalloc(&b, (size_t)cap * cap * sizeof(double)));
+        // ONE slab for the four Np^2 matrices A | L | S | W: the sweep plan addresses all of them from the slab base, so a
+        // single launch can mix tasks whose operands live in different matrices
+        HIPCHK(h, hipMalloc(&h->slab, (size_t)4 * cap * cap * sizeof(double)));
+        for (int k = 0; k < 4; ++k) h->buf[k] = h->slab + (size_t)k * cap * cap;
+        realloc_ = true;
         HIPCHK(h, hipMalloc(&h->dX, (size_t)cap * D * sizeof(double)));
         for (double** p : {&h->dY, &h->dz, &h->dalpha, &h->dvec, &h->dvec2})
             HIPCHK(h, hipMalloc(p, (size_t)cap * sizeof(double)));
@@ -740,7 +201,7 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
         HIPCHK(h, hipMalloc(&h->dpart, (size_t)grad_num_partials((int)cap) * (2 * MFGP_MAX_PARTS + 1) * sizeof(double)));
         h->cap = cap;
     }
-    const bool replan = (Np != h->Np);
+    const bool replan = (Np != h->Np) || realloc_;   // (the plan's offsets depend on the slab stride = cap^2)
     h->N = N; h->Np = Np; h->D = D; h->nblk = (int)(Np / NB);
     h->stage_timing = Np >= 1024;
     if (const char* e = getenv("MFGP_STAGE_TIMING")) h->stage_timing = atoi(e) != 0;
@@ -829,7 +290,8 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     }
     const bool stages = h->stage_timing;   // an event record costs 6-8 us of stream time: per-stage stamps only where that is noise
     if (stages) HIPCHK(h, hipEventRecord(h->ev[1], s));
-    for (const Step& st : h->plan) run_step(h, st);
+    const bool stream_kinv = want_grad && h->pl.kinv_streamed;
+    for (const Step& st : h->pl.steps) run_step(h, st, stream_kinv);
     if (stages) HIPCHK(h, hipEventRecord(h->ev[2], s));
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dY, h->dz, (int)h->Np, (int)h->Np, 0);       // z = X y
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dz, h->dalpha, (int)h->Np, (int)h->Np, 1);   // alpha = X^T z
@@ -837,7 +299,7 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     h->launches += 3;
     if (stages || !want_grad) HIPCHK(h, hipEventRecord(h->ev[3], s));
     if (want_grad) {
-        run_step(h, h->kinv_step);
+        if (!stream_kinv) run_step(h, h->pl.kinv_step);   // (streamed plans have accumulated K^-1 behind the chain already)
         if (stages) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
@@ -865,8 +327,10 @@ static int finish_eval(mfgp_handle* h, bool want_grad) {
     t.total_ms = ev_ms(h->ev[0], h->ev[want_grad ? 5 : 3]);
     const double np = (double)h->Np;
     t.kbuild_bytes = 4.0 * np * (np + 64.0);
-    t.kinv_flops = np * np * np / 3.0;
-    t.cholinv_flops = 2.0 * np * np * np / 3.0;
+    // a streamed plan accumulates K^-1 inside the sweep (between the cholinv stamps): its N^3/3 flops are counted there
+    const bool streamed = want_grad && h->pl.kinv_streamed;
+    t.kinv_flops = streamed ? 0.0 : np * np * np / 3.0;
+    t.cholinv_flops = (streamed ? 3.0 : 2.0) * np * np * np / 3.0;
     t.n_launches = h->launches;
     h->cum.evals += 1;
     h->cum.grad_evals += want_grad ? 1 : 0;
@@ -1024,7 +488,7 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
     if (!h->grad_valid) {
         hipStream_t s = h->stream;
         HIPCHK(h, hipEventRecord(h->ev[3], s));
-        run_step(h, h->kinv_step);
+        run_step(h, h->pl.kinv_step);
         HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
@@ -1069,10 +533,9 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     static const bool skinny_on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
     const bool skinny = want_var && skinny_on && rows <= 64;
     const int rows16 = rows <= 16 ? 1 : (rows <= 32 ? 2 : 4);
-    if (want_var && !skinny && h->predv_rows != rows_p) {
+    if (want_var && !skinny && h->pl.predv_rows != rows_p) {
         // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
-        h->tasks.resize((size_t)h->kinv_step.first + h->kinv_step.count);
-        plan_predv(h, rows_p);
+        plan_predv(h->pl, rows_p);
         rc = upload_tasks(h);
         if (rc) return rc;
     }
@@ -1086,7 +549,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         h->kinv_valid = false;  // V overwrites the K^-1 storage
         const int vrows = skinny ? 16 * rows16 : rows_p;
         if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
-        else run_step(h, h->predv_step);
+        else run_step(h, h->pl.predv_step);
         launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
         launch_finish_var(s, h->spec, h->dvec2, h->dvec2, vrows, include_noise ? h->noise : 0.0);
         h->launches += 2;

@@ -5,44 +5,14 @@
 #include <string>
 #include <vector>
 #include "../../include/mfgp.h"
+#include "plan.h"
 
 namespace mfgp {
 
-constexpr int NB = 128;  // leaf block = padding granule = largest GEMM tile edge
-constexpr int BK = 32;   // K-step of the tile GEMM (doubles)
 constexpr int MFGP_MAX_DEVICES = 16;   // (power of two) per-device one-time launch setup slots
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
-
-// ---------------------------------------------------------------------------------------------
-// Tile-GEMM task: one workgroup computes
-//     C[i0+r][j0+c] = beta * C[..] + alpha * sum_{k<klen} A[i0+r][k0+k] * B[j0+c][k0'+k]
-// (both operands K-contiguous, "NT").  All matrices share the leading dimension ld.
-// Triangular operands are expressed by trimming [k0, k0+klen) to the non-zero range and masking
-// the one diagonal window that remains (the buffers hold mirrored data in the other triangle).
-// ---------------------------------------------------------------------------------------------
-enum : int32_t {
-    TF_A_LOWER = 1,  // A rows are rows of a lower-triangular matrix; K range ends on the diagonal:
-                     //   zero where k > r + klen - BM
-    TF_A_UPPER = 2,  // A rows are rows of an upper-triangular matrix; K range starts on the diagonal:
-                     //   zero where k < r
-    TF_B_LOWER = 4,  //   zero where k > c + klen - BN
-    TF_B_UPPER = 8,  //   zero where k < c
-};
-
-struct GemmTask {
-    int64_t a_off;   // element offset of A[i0][k0]
-    int64_t b_off;   // element offset of B[j0][k0']
-    int64_t c_off;   // element offset of C[i0][j0]
-    int64_t c2_off;  // element offset of the mirrored copy C2[j0][i0] (written transposed), or -1
-    int32_t klen;    // multiple of BK
-    int32_t flags;
-    double alpha;
-    double beta;
-    int64_t pad_;
-};
-static_assert(sizeof(GemmTask) == 64, "GemmTask layout");
 
 // kernel-structure descriptor passed by value to the covariance kernels
 struct KernSpecDev {
@@ -116,5 +86,70 @@ void launch_stencil_rows(hipStream_t s, const double* Xc, const double* offs, in
                          double* T);
 void launch_assemble_aug(hipStream_t s, const double* Xc, const double* m, int rows, int rows_p, int d, int c,
                          double* out, int ld);
+
+// ---- host-side state ---------------------------------------------------------------------------------
+extern thread_local std::string g_err;   // error text of calls that have no handle to hang it on
+
+}  // namespace mfgp
+
+struct mfgp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // bulk trailing updates of the look-ahead Cholesky
+    std::vector<hipEvent_t> evpool;     // cross-stream dependencies of the plan
+    std::string err, info_str;
+    int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
+    int D = 0, nblk = 0;
+    double* slab = nullptr;          // ONE allocation holding the four Np^2 matrices
+    double* buf[4] = {nullptr, nullptr, nullptr, nullptr};   // A | L | S | W inside the slab (stride cap^2)
+    double *dX = nullptr, *dXs = nullptr, *dY = nullptr, *dz = nullptr, *dalpha = nullptr;
+    double *dlogdet = nullptr, *dres = nullptr, *dpart = nullptr, *dvec = nullptr,
+           *dvec2 = nullptr;
+    int* dinfo = nullptr;
+    mfgp::GemmTask* dtasks = nullptr;
+    size_t tasks_cap = 0;
+    int xs_cap_rows = 0, xs_cap_D = 0;
+    double *dXc = nullptr, *dm = nullptr, *doffs = nullptr, *dAug = nullptr;  // level chaining scratch
+    int64_t ch_rows = 0;
+    int ch_c = 0, ch_D = 0;             // the chain scratch is sized for (ch_rows, ch_c) at input width ch_D
+    double* hres = nullptr;  // pinned
+    int* hinfo = nullptr;    // pinned
+    bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 1024 unless MFGP_STAGE_TIMING=1)
+    mfgp::Plan pl;                  // factorisation / inverse / K^-1 / predictive-variance launch lists (plan.cpp)
+    mfgp::KernSpecDev spec{};
+    bool have_kernel = false, have_data = false, factorized = false, kinv_valid = false, grad_valid = false,
+         params_set = false;
+    double theta[2 * MFGP_MAX_PARTS] = {0};
+    double noise = 0, jitter = 0;
+    double quad = 0, logdet = 0;
+    double grad[2 * MFGP_MAX_PARTS + 1] = {0};
+    hipEvent_t ev[10] = {};
+    mfgp_timings tm{};
+    mfgp_counters cum{};
+    int64_t launches = 0;
+    // multi-GPU (comm_rccl.hip): one RCCL communicator per handle, created by mfgp_comm_init; opaque here
+    void* comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    double* dstage = nullptr;            // device staging of mfgp_allgather_host
+    size_t stage_cap = 0;
+};
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            if (h) (h)->err = m_; else mfgp::g_err = m_;                                        \
+            return -2;                                                                          \
+        }                                                                                       \
+    } while (0)
+
+namespace mfgp {
+inline int fail(mfgp_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_err = msg;
+    return code;
+}
+// releases the communicator of a handle (no-op without one); defined in comm_rccl.hip
+void comm_release(mfgp_handle* h);
 
 }  // namespace mfgp

@@ -1,0 +1,735 @@
+// plan.cpp -- the planner: turns "factorise / invert / accumulate K^-1 / predictive variance" into lists of tile-GEMM
+// tasks (gemm_f64.hip) and leaf launches (leaf_f64.hip) on two streams.  PURE HOST C++ (see plan.h): compiled into
+// libmfgp_hip.so by hipcc and into the CPU plan checker (tests/host_plan) by g++.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include "plan.h"
+
+namespace mfgp {
+
+// ------------------------------------------------------------------------------------------------
+// planner
+// ------------------------------------------------------------------------------------------------
+static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group);
+static int pick_tile(int ntiles128) {
+    // 128-tiles run the MFMA pipe better, but a launch of few tiles is bound by its LONGEST tile (one tile per CU, 256
+    // CUs): below ~300 tiles four times as many 64-tiles balance better (top inverse level at N = 4096: 2 x 330 -> 2 x 220 us)
+    static const int t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : 300;
+    return ntiles128 >= t128_min ? 128 : 64;
+}
+
+static void add_gemm(Plan& p, std::vector<Step>& plan, int tile, int first, int a, int b, int c, int c2) {
+    Step s{};
+    s.kind = 1;
+    s.tile = tile;
+    s.first = first;
+    s.count = (int)p.tasks.size() - first;
+    s.a = a; s.b = b; s.c = c; s.c2 = c2;
+    if (s.count > 0) plan.push_back(s);
+}
+
+// recursive Cholesky + inverse over leaf blocks [b0, b1)
+static void plan_cholinv(Plan& p, int b0, int b1) {
+    const int64_t ld = p.ld;
+    if (b1 - b0 == 1) {
+        Step s{};
+        s.kind = 0;
+        s.blk = b0;
+        p.steps.push_back(s);
+        return;
+    }
+    const int bm = b0 + (b1 - b0 + 1) / 2;
+    plan_cholinv(p, b0, bm);
+    const int n1 = bm - b0, n2 = b1 - bm;
+    const int T = pick_tile(n1 * n2);
+    const int sc = NB / T;
+    const int64_t k0 = (int64_t)b0 * NB, km = (int64_t)bm * NB;
+    // L21 = A21 * X11^T      (A: A, B: S lower rows j, C: L)
+    {
+        const int first = (int)p.tasks.size();
+        for (int j = b0 * sc; j < bm * sc; ++j)       // long K first
+            for (int i = bm * sc; i < b1 * sc; ++i) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T * ld + k0;
+                t.b_off = (int64_t)j * T * ld + k0;
+                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c2_off = -1;
+                t.klen = (int)((int64_t)(j + 1) * T - k0);
+                t.flags = TF_B_LOWER;
+                t.alpha = 1.0; t.beta = 0.0;
+                p.tasks.push_back(t);
+            }
+        // descending K length for load balance
+        std::stable_sort(p.tasks.begin() + first, p.tasks.end(),
+                         [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+        add_gemm(p, p.steps, T, first, BUF_A, BUF_S, BUF_L, -1);
+    }
+    // A22 -= L21 L21^T       (A: L, B: L, C: A), lower tiles only
+    {
+        const int T2 = pick_tile(n2 * (n2 + 1) / 2);
+        const int s2 = NB / T2;
+        const int first = (int)p.tasks.size();
+        for (int i = bm * s2; i < b1 * s2; ++i)
+            for (int j = bm * s2; j <= i; ++j) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T2 * ld + k0;
+                t.b_off = (int64_t)j * T2 * ld + k0;
+                t.c_off = (int64_t)i * T2 * ld + (int64_t)j * T2;
+                t.c2_off = -1;
+                t.klen = n1 * NB;
+                t.flags = 0;
+                t.alpha = -1.0; t.beta = 1.0;
+                p.tasks.push_back(t);
+            }
+        add_gemm(p, p.steps, T2, first, BUF_L, BUF_L, BUF_A, -1);
+    }
+    plan_cholinv(p, bm, b1);
+    // P^T[j][i] = sum_{k>=j} X11^T[j][k] L21[i][k]     (A: S upper rows j, B: L rows i, C: W[j][i])
+    {
+        const int first = (int)p.tasks.size();
+        for (int j = b0 * sc; j < bm * sc; ++j)
+            for (int i = bm * sc; i < b1 * sc; ++i) {
+                GemmTask t{};
+                t.a_off = (int64_t)j * T * ld + (int64_t)j * T;
+                t.b_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c_off = (int64_t)j * T * ld + (int64_t)i * T;
+                t.c2_off = -1;
+                t.klen = (int)(km - (int64_t)j * T);
+                t.flags = TF_A_UPPER;
+                t.alpha = 1.0; t.beta = 0.0;
+                p.tasks.push_back(t);
+            }
+        add_gemm(p, p.steps, T, first, BUF_S, BUF_L, BUF_W, -1);
+    }
+    // X21[i][j] = - sum_{k<=i} X22[i][k] P^T[j][k]     (A: S lower rows i, B: W rows j, C: S lower + mirror)
+    {
+        const int first = (int)p.tasks.size();
+        for (int i = b1 * sc - 1; i >= bm * sc; --i)  // long K first
+            for (int j = b0 * sc; j < bm * sc; ++j) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T * ld + km;
+                t.b_off = (int64_t)j * T * ld + km;
+                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c2_off = (int64_t)j * T * ld + (int64_t)i * T;
+                t.klen = (int)((int64_t)(i + 1) * T - km);
+                t.flags = TF_A_LOWER;
+                t.alpha = -1.0; t.beta = 0.0;
+                p.tasks.push_back(t);
+            }
+        add_gemm(p, p.steps, T, first, BUF_S, BUF_W, BUF_S, BUF_S);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan B (default): right-looking blocked Cholesky (NB = 128) followed by a level-batched recursive
+// triangular inverse.  Per block column k: leaf(k) factorises AND inverts the diagonal block, the
+// panel below becomes L[i,k] = A[i,k] X_kk^T (tile GEMMs, K = 128), then the trailing SYRK update.
+// The inverse X = L^-1 is then assembled bottom-up: every node of one tree level is independent, so a
+// level is TWO launches (P^T = X11^T L21^T ; X21 = -X22 P) however many nodes it has.
+// ------------------------------------------------------------------------------------------------
+static int new_event(Plan& p) { return ++p.n_events; }   // 1-based
+
+static void plan_potrf_rl(Plan& p) {
+    // Blocked Cholesky with macro panels of MB leaf blocks and look-ahead over two streams.
+    //   main stream (the serial chain), for every block column c of a macro panel [M0, M1):
+    //       leaf(c)     : L_cc, X_cc = L_cc^-1
+    //       panel(c)    : L[i,c] = A[i,c] X_cc^T, i > c
+    //       inner(c)    : A[i,j] -= L[i,c] L[j,c]^T for the macro's later columns j in (c, M1), K = 128 (right-looking
+    //                     inside the macro; MFGP_INNER_RIGHT=0: left-looking colupdate(c) before leaf(c) instead)
+    //   bulk stream, after the macro's chain: A[i,j] -= L[i,M0:M1] L[j,M0:M1]^T (K = MB*128), first the block
+    //       columns of the NEXT macro panel one by one (each releases the chain step that needs it), then the rest,
+    //       which overlaps the next macro's chain.
+    const int64_t ld = p.ld;
+    const int nb = p.nblk;
+    int MB = 4;   // 2 is ~1.5 % faster for one evaluation alone, 4 is ~5 % faster with evaluations in flight (bench)
+    if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
+    bool lookahead = true;
+    if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
+    // inside a macro panel: right-looking (after panel(c), column c's K = 128 contribution to the macro's later columns)
+    // instead of left-looking (before leaf(c), the K <= (MB-1)*128 contribution of the macro's earlier columns to
+    // column c): a step on the chain costs launch + K-depth, and K = 128 three times beats 128 + 256 + 384
+    // (N = 8192: 11.28 -> 11.04 ms, 4096: 3.57 -> 3.43, 2048: 1.46 -> 1.36)
+    bool inner_right = true;
+    if (const char* e = getenv("MFGP_INNER_RIGHT")) inner_right = atoi(e) != 0;
+    // `shift`: the chain's K = 128 inner updates also cover the NEXT macro panel's first column, so that no K = MB*128
+    // step (and no wait for the previous macro's bulk update) gates its first leaf.  Pays where the factorisation is
+    // chain-bound throughout (N = 4096: 3.42 -> 3.28 ms, 2048: 1.37 -> 1.28); neutral at N = 8192, where the first half
+    // is bound by the bulk updates and the gating step's slack is worth as much as its latency.
+    bool shift = nb < 48;
+    if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
+    shift = shift && lookahead && inner_right;
+    bool merge_cols = true;
+    if (const char* e = getenv("MFGP_MERGE_COLS")) merge_cols = atoi(e) != 0;
+    // slim chain workgroups (role 3) co-reside with the bulk update's workgroups; alone they are ~30 % slower than the
+    // double-buffered 64-tile kernel, so they only pay where bulk updates are long enough to overlap the chain
+    int chain_role = (lookahead && nb >= 48) ? 3 : 0;
+    if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
+    auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
+        // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
+        const int sc = NB / T;
+        for (int j = jlo * sc; j < jhi * sc; ++j)
+            for (int i = j; i < nb * sc; ++i) {
+                GemmTask t{};
+                t.a_off = (int64_t)i * T * ld + (int64_t)klo * NB;
+                t.b_off = (int64_t)j * T * ld + (int64_t)klo * NB;
+                t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                t.c2_off = -1;
+                t.klen = (khi - klo) * NB;
+                t.flags = 0;
+                t.alpha = -1.0; t.beta = 1.0;
+                p.tasks.push_back(t);
+            }
+    };
+    auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
+    std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
+    int ev_rest_prev = 0;            // event after the previous macro's bulk update of the REST (bulk stream)
+    for (int M0 = 0; M0 < nb; M0 += MB) {
+        const int M1 = std::min(M0 + MB, nb);
+        const int M2 = std::min(M1 + MB, nb);
+        int main_waited_ev = 0;   // the merged column launch signals ONE event for several columns: wait for it once
+        for (int c = M0; c < M1; ++c) {
+            bool waited = false;
+            if (c > M0 && !inner_right) {   // left-looking update of block column c with the macro's finished columns
+                const int T = 64;  // latency-bound, on the serial chain: many small tiles
+                const int first = (int)p.tasks.size();
+                syrk_tasks(T, c, c + 1, M0, c);
+                add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
+                p.steps.back().role = chain_role;
+                if (lookahead && ev_col[c] > 0) {
+                    if (ev_col[c] != main_waited_ev) p.steps.back().wait_ev = main_waited_ev = ev_col[c];
+                    waited = true;   // (an event wait costs ~6 us on the chain even when already signalled)
+                }
+            }
+            Step s{};
+            s.kind = 0;
+            s.blk = c;
+            if (lookahead && !waited && ev_col[c] > 0 && ev_col[c] != main_waited_ev) s.wait_ev = main_waited_ev = ev_col[c];
+            p.steps.push_back(s);
+            const int rem = nb - 1 - c;
+            if (rem == 0) break;
+            const int64_t kc = (int64_t)c * NB;
+            {   // panel: L[i,c] = A[i,c] * X_cc^T
+                const int T = pick_tile(rem);
+                const int sc = NB / T;
+                const int first = (int)p.tasks.size();
+                for (int i = (c + 1) * sc; i < nb * sc; ++i)
+                    for (int j = c * sc; j < (c + 1) * sc; ++j) {
+                        GemmTask t{};
+                        t.a_off = (int64_t)i * T * ld + kc;
+                        t.b_off = (int64_t)j * T * ld + kc;
+                        t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                        t.c2_off = -1;
+                        t.klen = (int)((int64_t)(j + 1) * T - kc);
+                        t.flags = TF_B_LOWER;
+                        t.alpha = 1.0; t.beta = 0.0;
+                        p.tasks.push_back(t);
+                    }
+                add_gemm(p, p.steps, T, first, BUF_A, BUF_S, BUF_L, -1);
+                if (T == 64) p.steps.back().role = chain_role;
+            }
+            // right-looking inside the macro: column c -> the macro's later columns, K = 128.  `shift`: also -> the first
+            // column of the NEXT macro panel, so that no K = MB*128 step gates its first leaf
+            const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
+            if (inner_right && c + 1 < inner_hi) {
+                const int first = (int)p.tasks.size();
+                syrk_tasks(64, c + 1, inner_hi, c, c + 1);
+                add_gemm(p, p.steps, 64, first, BUF_L, BUF_L, BUF_A, -1);
+                p.steps.back().role = chain_role;
+                const int e = ev_col[c + 1];
+                if (lookahead && e > 0 && e != main_waited_ev) p.steps.back().wait_ev = main_waited_ev = e;
+            }
+        }
+        if (M1 >= nb) break;
+        if (!lookahead) {
+            const int r = nb - M1;
+            const int T = pick_tile(r * (r + 1) / 2);
+            const int first = (int)p.tasks.size();
+            syrk_tasks(T, M1, nb, M0, M1);
+            add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
+            continue;
+        }
+        const int ev_chain = new_event(p);
+        p.steps.back().rec_ev = ev_chain;   // chain(M) complete: every L[:, M0:M1] panel is final
+        bool first_bulk = true;
+        if (shift) {
+            // the chain has already brought the next macro panel's first column up to date; the bulk stream takes the
+            // columns (M1, M1+MB] in one launch (the next chain waits for its event once) and everything beyond in another
+            const int lo = M1 + 1, hi = std::min(M1 + MB, nb - 1);
+            if (lo <= hi) {
+                const int T = pick_tile(ntiles_cols(lo, hi + 1));
+                const int first = (int)p.tasks.size();
+                syrk_tasks(T, lo, hi + 1, M0, M1);
+                add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
+                Step& st = p.steps.back();
+                st.strm = 1;
+                st.wait_ev = ev_chain;
+                first_bulk = false;
+                const int ev = new_event(p);
+                st.rec_ev = ev;
+                for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
+            }
+            if (hi + 1 < nb) {
+                const int T = pick_tile(ntiles_cols(hi + 1, nb));
+                const int first = (int)p.tasks.size();
+                syrk_tasks(T, hi + 1, nb, M0, M1);
+                add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
+                p.steps.back().strm = 1;
+                if (first_bulk) p.steps.back().wait_ev = ev_chain;
+            }
+            continue;
+        }
+        {
+            // the column that gates the next leaf stays on the MAIN stream: no event round trip on the chain.
+            // It must still come after the previous macro's rest-update, which covers this column too and
+            // runs on the bulk stream (normally long finished: the wait is on an already signalled event).
+            const int T = pick_tile(nb - M1);
+            const int first = (int)p.tasks.size();
+            syrk_tasks(T, M1, M1 + 1, M0, M1);
+            add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
+            Step& st = p.steps.back();
+            st.strm = 0;
+            if (T == 64) st.role = chain_role;
+            st.wait_ev = ev_rest_prev;
+            ev_col[M1] = 0;
+        }
+        if (M1 + 1 < M2) {
+            // the other block columns of the next macro panel: ONE launch on the bulk stream (each is needed one chain
+            // step later than the previous; a launch per column left the GPU at ~140 workgroups three times in a row)
+            const int cols = M2 - (M1 + 1);
+            const int T = merge_cols ? pick_tile(cols * (nb - M1 - 1)) : 64;
+            for (int c = M1 + 1; c < M2; c += merge_cols ? cols : 1) {
+                const int first = (int)p.tasks.size();
+                syrk_tasks(merge_cols ? T : pick_tile(nb - c), c, merge_cols ? M2 : c + 1, M0, M1);
+                add_gemm(p, p.steps, merge_cols ? T : pick_tile(nb - c), first, BUF_L, BUF_L, BUF_A, -1);
+                Step& st = p.steps.back();
+                st.strm = 1;
+                if (first_bulk) st.wait_ev = ev_chain;
+                first_bulk = false;
+                const int ev = new_event(p);
+                st.rec_ev = ev;
+                for (int cc = c; cc < (merge_cols ? M2 : c + 1); ++cc) ev_col[cc] = ev;
+            }
+        }
+        if (M2 < nb) {   // the rest of the trailing matrix: overlaps the next macro panel's chain
+            const int T = pick_tile(ntiles_cols(M2, nb));
+            const int first = (int)p.tasks.size();
+            syrk_tasks(T, M2, nb, M0, M1);
+            add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
+            p.steps.back().strm = 1;
+            if (first_bulk) p.steps.back().wait_ev = ev_chain;   // MB = 1: nothing else waited on the chain yet
+            ev_rest_prev = new_event(p);
+            p.steps.back().rec_ev = ev_rest_prev;
+        } else {
+            ev_rest_prev = 0;
+        }
+    }
+}
+
+
+struct TriNode { int b0, bm, b1, level; };
+static int collect_nodes(int b0, int b1, std::vector<TriNode>& out) {
+    if (b1 - b0 <= 1) return 0;
+    const int bm = b0 + (b1 - b0 + 1) / 2;
+    const int l = std::max(collect_nodes(b0, bm, out), collect_nodes(bm, b1, out)) + 1;
+    out.push_back(TriNode{b0, bm, b1, l});
+    return l;
+}
+
+static void plan_trtri_levels(Plan& p) {
+    const int64_t ld = p.ld;
+    std::vector<TriNode> nodes;
+    const int top = collect_nodes(0, p.nblk, nodes);
+    for (int lev = 1; lev <= top; ++lev) {
+        int ntiles = 0;
+        for (const TriNode& n : nodes)
+            if (n.level == lev) ntiles += (n.bm - n.b0) * (n.b1 - n.bm);
+        const int T = pick_tile(ntiles);
+        const int sc = NB / T;
+        {   // P^T[j][i] = sum_{k>=j} X11^T[j][k] L21[i][k]
+            const int first = (int)p.tasks.size();
+            for (const TriNode& n : nodes) {
+                if (n.level != lev) continue;
+                const int64_t km = (int64_t)n.bm * NB;
+                for (int j = n.b0 * sc; j < n.bm * sc; ++j)
+                    for (int i = n.bm * sc; i < n.b1 * sc; ++i) {
+                        GemmTask t{};
+                        t.a_off = (int64_t)j * T * ld + (int64_t)j * T;
+                        t.b_off = (int64_t)i * T * ld + (int64_t)j * T;
+                        t.c_off = (int64_t)j * T * ld + (int64_t)i * T;
+                        t.c2_off = -1;
+                        t.klen = (int)(km - (int64_t)j * T);
+                        t.flags = TF_A_UPPER;
+                        t.alpha = 1.0; t.beta = 0.0;
+                        p.tasks.push_back(t);
+                    }
+            }
+            std::stable_sort(p.tasks.begin() + first, p.tasks.end(),
+                             [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+            add_gemm(p, p.steps, T, first, BUF_S, BUF_L, BUF_W, -1);
+        }
+        {   // X21[i][j] = - sum_{k<=i} X22[i][k] P^T[j][k]
+            const int first = (int)p.tasks.size();
+            for (const TriNode& n : nodes) {
+                if (n.level != lev) continue;
+                const int64_t km = (int64_t)n.bm * NB;
+                for (int i = n.bm * sc; i < n.b1 * sc; ++i)
+                    for (int j = n.b0 * sc; j < n.bm * sc; ++j) {
+                        GemmTask t{};
+                        t.a_off = (int64_t)i * T * ld + km;
+                        t.b_off = (int64_t)j * T * ld + km;
+                        t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                        t.c2_off = (int64_t)j * T * ld + (int64_t)i * T;
+                        t.klen = (int)((int64_t)(i + 1) * T - km);
+                        t.flags = TF_A_LOWER;
+                        t.alpha = -1.0; t.beta = 0.0;
+                        p.tasks.push_back(t);
+                    }
+            }
+            std::stable_sort(p.tasks.begin() + first, p.tasks.end(),
+                             [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+            add_gemm(p, p.steps, T, first, BUF_S, BUF_W, BUF_S, BUF_S);
+        }
+    }
+}
+
+// XCD-aware task placement.  Workgroup p of a launch lands on XCD p mod 8 (each XCD has its own L2); a task list in
+// row-major tile order therefore hands every XCD tiles that share almost no operand panel.  `tasks[first..)` arrives
+// in LOCALITY order (runs of `group` consecutive tasks = one compact block of output tiles sharing operand panels);
+// the runs are dealt to the 8 XCDs in serpentine order (0..7, 7..0: the work per run decreases along the list, a plain
+// round-robin would give XCD 0 the longest run of every round) and the per-XCD sequences interleaved, so that XCD x executes whole
+// runs back to back.  Pure reordering: every tile's arithmetic (and the result bits) is unchanged.
+static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group) {
+    static const bool on = !(getenv("MFGP_XCD_ORDER") && atoi(getenv("MFGP_XCD_ORDER")) == 0);
+    const int n = (int)tasks.size() - first;
+    if (!on || n < 8 * group) return;
+    std::vector<GemmTask> lists[8];
+    int g = 0;
+    for (int t0 = 0; t0 < n; t0 += group, ++g)
+        for (int t = t0; t < std::min(n, t0 + group); ++t)   // serpentine deal: the runs come in descending work
+            lists[(g & 8) ? 7 - (g & 7) : (g & 7)].push_back(tasks[first + t]);
+    int out = first;
+    for (size_t m = 0; out < first + n; ++m)
+        for (int x = 0; x < 8; ++x)
+            if (m < lists[x].size()) tasks[out++] = lists[x][m];
+}
+
+static void plan_kinv(Plan& p) {
+    const int64_t ld = p.ld;
+    const int nb = p.nblk;
+    static const int kinv_t128_min = getenv("MFGP_KINV_T128_MIN") ? atoi(getenv("MFGP_KINV_T128_MIN")) : 600;   // N = 4096: 0.65 -> 0.54 ms, N = 3072: 0.48 -> 0.25 ms
+    const int T = nb * (nb + 1) / 2 >= kinv_t128_min ? 128 : 64;
+    const int sc = NB / T;
+    const int first = (int)p.tasks.size();
+    // locality order: super-blocks of BI x BJ output tiles (BI row panels + BJ column panels feed BI*BJ tiles);
+    // small i (= long K range) first.  Measured at N = 8192 (tools/sweep_kinv_order.sh): 1x8 3.73 ms / 3.05 GB fetched,
+    // 4x8 3.85 ms / 2.28 GB, row-major without XCD placement 3.9 ms / 3.69 GB -- the launch is FMA-bound, so the
+    // finer run (better balance over the XCDs) wins over the larger one (fewer panel re-reads).
+    int BI = 1, BJ = 8;
+    if (const char* e = getenv("MFGP_KINV_BI")) BI = std::max(1, atoi(e));
+    if (const char* e = getenv("MFGP_KINV_BJ")) BJ = std::max(1, atoi(e));
+    const int nt = nb * sc;
+    for (int i0 = 0; i0 < nt; i0 += BI)
+        for (int j0 = 0; j0 <= std::min(nt - 1, i0 + BI - 1); j0 += BJ)
+            for (int i = i0; i < std::min(nt, i0 + BI); ++i)
+                for (int j = j0; j < std::min(j0 + BJ, i + 1); ++j) {
+                    GemmTask t{};
+                    t.a_off = (int64_t)i * T * ld + (int64_t)i * T;
+                    t.b_off = (int64_t)j * T * ld + (int64_t)i * T;
+                    t.c_off = (int64_t)i * T * ld + (int64_t)j * T;
+                    t.c2_off = -1;
+                    t.klen = (int)(p.ld - (int64_t)i * T);
+                    t.flags = TF_A_UPPER | (i == j ? TF_B_UPPER : 0);
+                    t.alpha = 1.0; t.beta = 0.0;
+                    p.tasks.push_back(t);
+                }
+    xcd_interleave(p.tasks, first, BI * BJ);
+    std::vector<Step> tmp;
+    add_gemm(p, tmp, T, first, BUF_S, BUF_S, BUF_A, -1);
+    p.kinv_step = tmp.empty() ? Step{} : tmp[0];
+    p.kinv_step.role = 1;
+}
+
+// V[r][i] = sum_{k<=i} Kx[r][k] X[i][k]   (A: W = Kx panel, B: S lower rows i, C: A)
+void plan_predv(Plan& p, int rows_p) {
+    p.tasks.resize(p.n_fixed_tasks);   // drop the product planned for another panel height, keep everything else
+    const int64_t ld = p.ld;
+    const int nb = p.nblk, rb = rows_p / NB;
+    const int T = pick_tile(nb * rb);
+    const int sc = NB / T;
+    const int first = (int)p.tasks.size();
+    const int BI = 8, BR = 4, ni = nb * sc, nr = rb * sc;   // super-blocks: BI rows of X  x  BR panel rows
+    for (int i0 = ni - 1; i0 >= 0; i0 -= BI)                 // large i (= long K range) first
+        for (int r0 = 0; r0 < nr; r0 += BR)
+            for (int i = i0; i > std::max(-1, i0 - BI); --i)
+                for (int r = r0; r < std::min(nr, r0 + BR); ++r) {
+                    GemmTask t{};
+                    t.a_off = (int64_t)r * T * ld;
+                    t.b_off = (int64_t)i * T * ld;
+                    t.c_off = (int64_t)r * T * ld + (int64_t)i * T;
+                    t.c2_off = -1;
+                    t.klen = (int)((int64_t)(i + 1) * T);
+                    t.flags = TF_B_LOWER;
+                    t.alpha = 1.0; t.beta = 0.0;
+                    p.tasks.push_back(t);
+                }
+    xcd_interleave(p.tasks, first, BI * BR);
+    std::vector<Step> tmp;
+    add_gemm(p, tmp, T, first, BUF_W, BUF_S, BUF_A, -1);
+    p.predv_step = tmp.empty() ? Step{} : tmp[0];
+    p.predv_step.role = 2;
+    p.predv_rows = rows_p;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// plan C (default, "sweep"): ONE right-looking sweep over the block columns produces L, X = L^-1 and (when the gradient
+// is wanted) K^-1 = X^T X; everything except the Cholesky's own serial chain is bulk work that streams BEHIND the chain
+// on the second stream instead of following it as separate phases.
+//
+// The inverse rides on the factorisation as the augmented system [A; I]: the column operations that turn A into L turn
+// I into X^T (A L^-T = L, I L^-T = X^T).  With B the running image of I (B[i,j] = -sum_{k=i}^{j-1} X^T[i,k] L[j,k]^T,
+// kept in the upper part of the workspace W):
+//     X^T[i,c] = B[i,c] X_cc^T                       (a "panel" row above the diagonal, same product as L[i,c] = A[i,c] X_cc^T)
+//     B[i,j]  -= X^T[i,c] L[j,c]^T ,  i <= c < j      (a "trailing update" above the diagonal, same product as the SYRK)
+// and K^-1 accumulates as the columns of X^T complete:  K^-1[i,j] += X^T[i,c] X^T[j,c]^T , j <= i <= c, written over the
+// dead part of A.  N^3/3 flops each, exactly those of dtrtri and dpotri/lauum -- as K = 512 macro-panel GEMMs.
+//
+// Per macro panel M = [M0, M1) of MB block columns:
+//   main stream (serial chain), per column c:   leaf(c);  panel(c): L[i,c] for i > c  +  X^T[i,c] for M0 <= i < c;
+//       inner(c): K = 128 updates of the macro's later columns of A  +  of B[M0..c, c+1..M1)
+//   bulk stream, after chain(M):  the next macro's columns of A (release its chain);  X^T[0:M0, M] = B[0:M0, M] X_MM^T;
+//       then ONE launch: the rest of A's trailing update  +  B[0:M1, M1:] update  (+ K^-1[0:M1, 0:M1] update, gradient only).
+// Task offsets are ABSOLUTE within the handle's single slab of the four matrices (offset = buffer * stride + row * ld +
+// col), so one launch mixes tasks whose operands live in different matrices.
+// ------------------------------------------------------------------------------------------------
+static void plan_sweep(Plan& p) {
+    const int64_t ld = p.ld, bs = p.stride;
+    const int nb = p.nblk;
+    int MB = 4;
+    if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
+    bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
+    if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
+    int chain_role = nb >= 48 ? 3 : 0;   // slim chain workgroups co-resident with bulk workgroups
+    if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
+    p.kinv_streamed = !(getenv("MFGP_KINV_STREAM") && atoi(getenv("MFGP_KINV_STREAM")) == 0);
+    auto at = [&](int buf, int64_t row, int64_t col) { return (int64_t)buf * bs + row * ld + col; };
+    auto push = [&](int64_t a, int64_t b, int64_t c, int64_t c2, int klen, int flags, double alpha, double beta) {
+        GemmTask t{};
+        t.a_off = a; t.b_off = b; t.c_off = c; t.c2_off = c2; t.klen = klen; t.flags = flags; t.alpha = alpha; t.beta = beta;
+        p.tasks.push_back(t);
+    };
+    // A[i,j] -= L[i,klo:khi] L[j,klo:khi]^T for block columns j in [jlo,jhi), rows i >= j
+    auto a_update = [&](int T, int jlo, int jhi, int klo, int khi) {
+        const int sc = NB / T;
+        for (int j = jlo * sc; j < jhi * sc; ++j)
+            for (int i = j; i < nb * sc; ++i)
+                push(at(BUF_L, (int64_t)i * T, (int64_t)klo * NB), at(BUF_L, (int64_t)j * T, (int64_t)klo * NB),
+                     at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1, (khi - klo) * NB, 0, -1.0, 1.0);
+    };
+    // L[i,c] = A[i,c] X_cc^T, block rows i in (c, nb)
+    auto l_panel = [&](int T, int c) {
+        const int sc = NB / T;
+        const int64_t kc = (int64_t)c * NB;
+        for (int i = (c + 1) * sc; i < nb * sc; ++i)
+            for (int j = c * sc; j < (c + 1) * sc; ++j)
+                push(at(BUF_A, (int64_t)i * T, kc), at(BUF_S, (int64_t)j * T, kc), at(BUF_L, (int64_t)i * T, (int64_t)j * T), -1,
+                     (int)((int64_t)(j + 1) * T - kc), TF_B_LOWER, 1.0, 0.0);
+    };
+    // X^T[i, c] = B[i, klo*NB : (c+1)*NB) X[c, same]^T for block rows i in [ilo, ihi): result into S (upper) + mirror
+    auto x_panel = [&](int T, int c, int klo, int ilo, int ihi) {
+        const int sc = NB / T;
+        const int64_t k0 = (int64_t)klo * NB;
+        for (int i = ilo * sc; i < ihi * sc; ++i)
+            for (int j = c * sc; j < (c + 1) * sc; ++j)
+                push(at(BUF_W, (int64_t)i * T, k0), at(BUF_S, (int64_t)j * T, k0), at(BUF_S, (int64_t)i * T, (int64_t)j * T),
+                     at(BUF_S, (int64_t)j * T, (int64_t)i * T), (int)((int64_t)(j + 1) * T - k0), TF_B_LOWER, 1.0, 0.0);
+    };
+    // B[i,j] -= X^T[i, klo:khi] L[j, klo:khi]^T for block rows i in [ilo, ihi), block columns j in [jlo, jhi); a row that
+    // lies inside [klo, khi) starts at its own diagonal block (X^T is upper triangular) and is the FIRST touch of its
+    // B tiles (beta = 0)
+    auto b_update = [&](int T, int ilo, int ihi, int jlo, int jhi, int klo, int khi) {
+        const int sc = NB / T;
+        for (int i = ilo * sc; i < ihi * sc; ++i) {
+            const bool inside = (int64_t)i * T >= (int64_t)klo * NB;
+            const int64_t k0 = inside ? (int64_t)i * T : (int64_t)klo * NB;
+            for (int j = jlo * sc; j < jhi * sc; ++j)
+                push(at(BUF_S, (int64_t)i * T, k0), at(BUF_L, (int64_t)j * T, k0), at(BUF_W, (int64_t)i * T, (int64_t)j * T), -1,
+                     (int)((int64_t)khi * NB - k0), inside ? TF_A_UPPER : 0, -1.0, inside ? 0.0 : 1.0);
+        }
+    };
+    // K^-1[i,j] (+)= X^T[i, klo:khi] X^T[j, klo:khi]^T for block rows i < khi, j <= i (lower tiles, over the dead part of A)
+    auto kinv_update = [&](int T, int klo, int khi) {
+        const int sc = NB / T;
+        for (int i = 0; i < khi * sc; ++i) {
+            const bool inside = (int64_t)i * T >= (int64_t)klo * NB;
+            const int64_t k0 = inside ? (int64_t)i * T : (int64_t)klo * NB;
+            for (int j = 0; j <= i; ++j)
+                push(at(BUF_S, (int64_t)i * T, k0), at(BUF_S, (int64_t)j * T, k0), at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1,
+                     (int)((int64_t)khi * NB - k0), inside ? (TF_A_UPPER | (i == j ? TF_B_UPPER : 0)) : 0, 1.0,
+                     inside ? 0.0 : 1.0);
+        }
+    };
+    auto launch = [&](int T, int first, int strm, int role) -> Step* {
+        Step s{};
+        s.kind = 1; s.tile = T; s.first = first; s.count = (int)p.tasks.size() - first;
+        s.a = s.b = s.c = s.c2 = BUF_A;   // absolute offsets: every operand is addressed from the slab base
+        s.strm = strm; s.role = role;
+        if (s.count <= 0) return nullptr;
+        p.steps.push_back(s);
+        return &p.steps.back();
+    };
+    auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
+
+    std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
+    int ev_rest_prev = 0;            // event after the previous macro's last bulk launch
+    bool bulk_used = false;
+    // Events recorded on the bulk stream are ordered; once the main stream has waited for one, every earlier one is
+    // implied (an event wait costs ~6 us on the chain even when the event signalled long ago: never wait twice)
+    std::vector<int> bulk_order(1, 0);   // event id -> position among the bulk stream's records (0 = not a bulk event)
+    int main_waited_order = 0, n_bulk_records = 0;
+    auto bulk_event = [&]() {
+        const int e = new_event(p);
+        bulk_order.resize(e + 1, 0);
+        bulk_order[e] = ++n_bulk_records;
+        return e;
+    };
+    auto main_wait = [&](Step& st, int e) {   // make a main-stream step wait for bulk event e unless that is implied
+        if (e <= 0 || bulk_order[e] <= main_waited_order) return;
+        st.wait_ev = e;
+        main_waited_order = bulk_order[e];
+    };
+    for (int M0 = 0; M0 < nb; M0 += MB) {
+        const int M1 = std::min(M0 + MB, nb);
+        const int M2 = std::min(M1 + MB, nb);
+        // ---- the chain of this macro panel (main stream) ----
+        for (int c = M0; c < M1; ++c) {
+            Step s{};
+            s.kind = 0;
+            s.blk = c;
+            main_wait(s, ev_col[c]);
+            p.steps.push_back(s);
+            {   // panel(c): the column of L below the diagonal and the in-macro part of the column of X^T above it
+                const int rows = (nb - 1 - c) + (c - M0);
+                if (rows > 0) {
+                    const int T = pick_tile(rows);
+                    const int first = (int)p.tasks.size();
+                    l_panel(T, c);
+                    x_panel(T, c, c, M0, c);
+                    launch(T, first, 0, T == 64 ? chain_role : 0);
+                }
+            }
+            {   // inner(c): right-looking K = 128 updates inside the macro (A: also the next macro's first column if `shift`)
+                const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
+                const int first = (int)p.tasks.size();
+                if (c + 1 < inner_hi) a_update(64, c + 1, inner_hi, c, c + 1);
+                if (c + 1 < M1) b_update(64, M0, c + 1, c + 1, M1, c, c + 1);
+                Step* st = launch(64, first, 0, chain_role);
+                if (st)   // the columns it touches were last written by the previous macro's bulk launches
+                    for (int j = c + 1; j < inner_hi; ++j) main_wait(*st, ev_col[j]);
+            }
+        }
+        // ---- bulk work released by this chain ----
+        const bool last = (M1 >= nb);
+        const size_t chain_last = p.steps.size() - 1;   // index of the chain's last step
+        std::vector<size_t> bulk_steps;                 // bulk launches of this macro, in stream order
+        if (!last && !shift) {
+            // the column that gates the next leaf stays on the MAIN stream (no event round trip on the chain); it must
+            // still follow the previous macro's last bulk launch, whose A-rest part covers this column too
+            const int T = pick_tile(nb - M1);
+            const int first = (int)p.tasks.size();
+            a_update(T, M1, M1 + 1, M0, M1);
+            Step* st = launch(T, first, 0, T == 64 ? chain_role : 0);
+            if (st) main_wait(*st, ev_rest_prev);
+            ev_col[M1] = 0;
+        }
+        if (!last) {
+            // the other block columns of the next macro panel: ONE bulk launch (the next chain waits for its event once)
+            const int lo = M1 + 1, hi = shift ? std::min(M1 + MB, nb - 1) : M2 - 1;
+            if (lo <= hi) {
+                const int T = pick_tile(ntiles_cols(lo, hi + 1));
+                const int first = (int)p.tasks.size();
+                a_update(T, lo, hi + 1, M0, M1);
+                if (launch(T, first, 1, 0)) {
+                    bulk_steps.push_back(p.steps.size() - 1);
+                    const int ev = bulk_event();
+                    p.steps.back().rec_ev = ev;
+                    for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
+                }
+            }
+        }
+        if (M0 > 0) {   // X^T[0:M0, M] = B[0:M0, M] X_MM^T   (rows above the macro; the in-macro rows came with the chain)
+            const int T = pick_tile(M0 * (M1 - M0));
+            const int first = (int)p.tasks.size();
+            for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
+            if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
+        }
+        {   // the rest: A's trailing update beyond the columns already done, B's update, and (gradient only) K^-1's
+            const int a_lo = last ? nb : (shift ? std::min(M1 + MB, nb - 1) + 1 : M2);
+            const int n_a = a_lo < nb ? ntiles_cols(a_lo, nb) : 0;
+            const int n_b = last ? 0 : M1 * (nb - M1);
+            const int n_k = p.kinv_streamed ? M1 * (M1 + 1) / 2 : 0;
+            const int T = pick_tile(n_a + n_b + n_k);
+            const int first = (int)p.tasks.size();
+            if (a_lo < nb) a_update(T, a_lo, nb, M0, M1);
+            if (!last) b_update(T, 0, M1, M1, nb, M0, M1);
+            const int n_base = (int)p.tasks.size() - first;
+            if (p.kinv_streamed) kinv_update(T, M0, M1);
+            Step* st = launch(T, first, 1, 0);
+            if (st) {
+                st->count = n_base;
+                st->count_grad = (int)p.tasks.size() - first - n_base;
+                bulk_steps.push_back(p.steps.size() - 1);
+            }
+        }
+        if (!bulk_steps.empty()) {
+            bulk_used = true;
+            const int ev_chain = new_event(p);
+            bulk_order.resize(ev_chain + 1, 0);
+            p.steps[chain_last].rec_ev = ev_chain;            // chain(M) complete: L[:, M], X_MM, B's in-macro part are final
+            p.steps[bulk_steps.front()].wait_ev = ev_chain;
+            if (!last) {
+                ev_rest_prev = bulk_event();
+                Step& lastb = p.steps[bulk_steps.back()];
+                if (lastb.rec_ev == 0) lastb.rec_ev = ev_rest_prev; else lastb.rec_ev_final = ev_rest_prev;
+            }
+        } else if (!last) {
+            ev_rest_prev = 0;
+        }
+    }
+    if (bulk_used) {   // join: whatever follows on the main stream (solve, gradient) needs the bulk stream's results
+        const int ev = new_event(p);
+        // the last bulk launch in the list is the last on its stream
+        for (size_t i = p.steps.size(); i-- > 0;)
+            if (p.steps[i].strm == 1) {
+                if (p.steps[i].rec_ev == 0) p.steps[i].rec_ev = ev; else p.steps[i].rec_ev_final = ev;
+                break;
+            }
+        Step j{};
+        j.kind = 2;
+        j.wait_ev = ev;
+        p.steps.push_back(j);
+    }
+}
+
+void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride) {
+    p = Plan{};
+    p.nblk = nblk;
+    p.ld = ld;
+    p.stride = stride;
+    const char* pm = getenv("MFGP_PLAN");
+    if (pm && strcmp(pm, "recursive") == 0) {
+        plan_cholinv(p, 0, nblk);
+    } else if (pm && strcmp(pm, "levels") == 0) {
+        plan_potrf_rl(p);
+        plan_trtri_levels(p);
+    } else {
+        plan_sweep(p);
+    }
+    plan_kinv(p);
+    p.n_fixed_tasks = p.tasks.size();
+    p.predv_rows = 0;
+}
+
+}  // namespace mfgp

@@ -1,0 +1,75 @@
+// plan.h -- the factorisation planner's types: PURE HOST C++ (no HIP), so that the planner also compiles with g++ into
+// the CPU plan checker of tests/host_plan (sequential executor + cross-stream race check of every plan it emits).
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace mfgp {
+
+constexpr int NB = 128;  // leaf block = padding granule = largest GEMM tile edge
+constexpr int BK = 32;   // K-step of the tile GEMM (doubles)
+
+// ---------------------------------------------------------------------------------------------
+// Tile-GEMM task: one workgroup computes
+//     C[i0+r][j0+c] = beta * C[..] + alpha * sum_{k<klen} A[i0+r][k0+k] * B[j0+c][k0'+k]
+// (both operands K-contiguous, "NT").  All matrices share the leading dimension ld.
+// Triangular operands are expressed by trimming [k0, k0+klen) to the non-zero range and masking
+// the one diagonal window that remains (the buffers hold mirrored data in the other triangle).
+// ---------------------------------------------------------------------------------------------
+enum : int32_t {
+    TF_A_LOWER = 1,  // A rows are rows of a lower-triangular matrix; K range ends on the diagonal:
+                     //   zero where k > r + klen - BM
+    TF_A_UPPER = 2,  // A rows are rows of an upper-triangular matrix; K range starts on the diagonal:
+                     //   zero where k < r
+    TF_B_LOWER = 4,  //   zero where k > c + klen - BN
+    TF_B_UPPER = 8,  //   zero where k < c
+};
+
+struct GemmTask {
+    int64_t a_off;   // element offset of A[i0][k0]
+    int64_t b_off;   // element offset of B[j0][k0']
+    int64_t c_off;   // element offset of C[i0][j0]
+    int64_t c2_off;  // element offset of the mirrored copy C2[j0][i0] (written transposed), or -1
+    int32_t klen;    // multiple of BK
+    int32_t flags;
+    double alpha;
+    double beta;
+    int64_t pad_;
+};
+static_assert(sizeof(GemmTask) == 64, "GemmTask layout");
+
+enum Buf { BUF_A = 0, BUF_L = 1, BUF_S = 2, BUF_W = 3 };
+
+// one launch of a plan
+struct Step {
+    int kind;  // 0 = leaf, 1 = gemm, 2 = join (no launch: the stream only waits for wait_ev)
+    int role;  // gemm kernel symbol: 0 recursion, 1 K^-1, 2 predictive variance, 3 serial-chain step (slim workgroups)
+    int strm;  // 0 = main stream (the serial chain), 1 = bulk-update stream (look-ahead)
+    int wait_ev, rec_ev;  // 1-based event indices (0 = none): wait before / record after the launch
+    int blk;   // leaf block
+    int tile, first, count, a, b, c, c2;  // gemm: tile edge, task range, operand / result buffers
+    int count_grad;     // further tasks [first + count, first + count + count_grad) that run only when the gradient is
+                        // wanted (the K^-1 accumulation streamed behind the chain)
+    int rec_ev_final;   // a second event recorded after the launch (the plan's final join), 0 = none
+};
+
+struct Plan {
+    int nblk = 0;
+    int64_t ld = 0;                 // = padded size Np
+    int64_t stride = 0;             // elements between the four matrices A, L, S, W in the handle's slab
+    size_t n_fixed_tasks = 0;       // tasks of the factorisation plan + the stand-alone K^-1 launch (predict plans follow)
+    std::vector<GemmTask> tasks;
+    std::vector<Step> steps;        // Cholesky + inverse (+ streamed K^-1)
+    Step kinv_step{};               // stand-alone K^-1 = X^T X launch (lazy gradient after a gradient-free factorisation)
+    Step predv_step{};              // predictive-variance product for predv_rows panel rows
+    int predv_rows = 0;
+    int n_events = 0;               // events the steps refer to (1-based ids 1..n_events)
+    bool kinv_streamed = false;     // the steps accumulate K^-1 behind the chain (grad_only steps)
+};
+
+// environment-selected planner variants (read once per plan; defaults = the measured best, DESIGN.md "Planner switches")
+void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride);
+// (re)plan the predictive-variance product for a panel of rows_p rows; keeps everything planned before it
+void plan_predv(Plan& p, int rows_p);
+
+}  // namespace mfgp

@@ -290,6 +290,18 @@ class _BudgetExhausted(Exception):
     pass
 
 
+_F_FAILED = np.finfo(np.float64).max   # objective reported for a failed evaluation [GPy-recall: paramz Model._objective_grads
+_G_CLIP_FAILED = 1e10                  # returns DBL_MAX, not inf -- an infinite value turns L-BFGS-B's cubic line-search
+                                       # interpolation into NaN steps -- and the previous gradient clipped to +-1e10]
+
+
+def _check_parameters(theta, noise):
+    """a NaN / infinite / non-positive parameter (a line search gone astray) is a FAILED evaluation, handled like a failed
+    Cholesky (GPy: the NaNs end in jitchol's LinAlgError), not an argument error of the engine"""
+    if not (np.all(np.isfinite(theta)) and np.all(theta > 0.0) and np.isfinite(noise) and noise >= 0.0):
+        raise np.linalg.LinAlgError("hyper-parameters left the positive finite domain")
+
+
 def _capped(f_fp, cap, x0):
     """-> (f, state): f evaluates f_fp at most `cap` times and then raises _BudgetExhausted; state holds the best point
     seen.  scipy's maxfun is only checked between iterations, so a run may overshoot it by a line search; a benchmark
@@ -423,6 +435,7 @@ class GPRegression:
         if not self._dirty and (self._have_grad or not want_grad):
             return
         theta, noise = self._theta(), self.likelihood.variance.value
+        _check_parameters(theta, noise)
         if not self._dirty and want_grad:
             self._grad_nat = self._engine.nlml_grad()
             self._have_grad = True
@@ -481,11 +494,15 @@ class GPRegression:
             f = self.objective_function()
             g = self.objective_function_gradients()
             self._fail_count = 0
+            self._last_good_grad = g
         except (np.linalg.LinAlgError, ZeroDivisionError, ValueError):
             if self._fail_count >= self._allowed_failures:
                 raise
             self._fail_count += 1
-            return np.inf, np.clip(np.zeros_like(x), -1e100, 1e100)
+            stale = getattr(self, "_last_good_grad", None)
+            if stale is None or len(stale) != len(x):
+                stale = np.zeros_like(x)
+            return _F_FAILED, np.clip(stale, -_G_CLIP_FAILED, _G_CLIP_FAILED)
         return f, np.clip(g, -1e100, 1e100)
 
     # ---- optimisation --------------------------------------------------------------------------------
@@ -519,7 +536,7 @@ class GPRegression:
         part_ids = [(id(v), id(l)) for v, l in self._part_params]
         term_ids = [[id(f.variance) for f in term] for term in self.kern._terms()]
         noise_id = id(self.likelihood.variance)
-        state = {"fails": 0}
+        state = {"fails": 0, "g": None}
 
         def f_fp(x):
             vals = dict(base)
@@ -530,6 +547,7 @@ class GPRegression:
             noise = vals[noise_id]
             jitter_extra, tries = 0.0, 0
             try:
+                _check_parameters(theta, noise)
                 while True:
                     try:
                         nlml, g = eng.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=True)
@@ -547,13 +565,15 @@ class GPRegression:
                 if state["fails"] >= self._allowed_failures:
                     raise
                 state["fails"] += 1
-                return np.inf, np.zeros_like(pv)
+                stale = state["g"] if state["g"] is not None else np.zeros_like(pv)
+                return _F_FAILED, np.clip(stale, -_G_CLIP_FAILED, _G_CLIP_FAILED)
             acc = {}
             for i, (kv, kl) in enumerate(part_ids):
                 acc[kv] = acc.get(kv, 0.0) + g[2 * i]
                 acc[kl] = acc.get(kl, 0.0) + g[2 * i + 1]
             acc[noise_id] = g[-1]
             gf = _logexp_gradfactor(pv, np.array([acc[k] for k in free_ids]))
+            state["g"] = gf
             return nlml, np.clip(gf, -1e100, 1e100)
 
         return f_fp

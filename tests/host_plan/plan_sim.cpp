@@ -1,0 +1,356 @@
+// plan_sim.cpp -- CPU checker of the factorisation planner (csrc/plan.cpp, compiled into this library by g++).
+// TEST INFRASTRUCTURE: never linked into libmfgp_hip.so.
+//
+// For a plan built exactly as the engine builds it (same code, same environment switches) it
+//   (1) executes the steps in enqueue order with a plain-C restatement of the tile-GEMM task semantics (masks, beta,
+//       mirrored store) and of the leaf (Cholesky + inverse of a 128-block), on matrices pre-filled with NaN wherever
+//       the K build does not write -- so any read of data that no earlier step produced poisons the result --
+//       and checks  L L^T = A,  X L = I,  S mirrored,  K^-1 = X^T X;
+//   (2) checks the two-stream schedule for DATA RACES: every pair of conflicting accesses (write/write, write/read) to
+//       the same 64x64 cell of the same matrix must be ordered by stream order or by an event recorded before it is
+//       waited for (vector clocks over the two streams); tasks of one launch run concurrently and must not conflict.
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <limits>
+#include <string>
+#include <vector>
+#include "../../multifidelity_datafusion_gps_amd/csrc/plan.h"
+
+using namespace mfgp;
+
+namespace {
+
+struct Clock { int t[2]; };
+
+struct Cell {
+    int w_step = -1, w_task = -1;          // last writer
+    std::vector<std::pair<int, int>> readers;   // (step, task) since the last write
+};
+
+struct Sim {
+    Plan p;
+    int64_t ld, stride;
+    std::vector<double> mem;
+    std::vector<Cell> cells;
+    std::vector<Clock> step_clock;
+    std::vector<int> step_strm;
+    int cpr;   // cells per row of one matrix
+    int races = 0;
+    std::string first_race;
+
+    bool hb(int a, int b) const {   // step a happens-before step b
+        const int sa = step_strm[a];
+        return step_clock[b].t[sa] >= step_clock[a].t[sa];
+    }
+    Cell& cell(int64_t off) {
+        const int buf = (int)(off / stride);
+        const int64_t r = (off % stride) / ld, c = off % ld;
+        return cells[(size_t)buf * cpr * cpr + (size_t)(r / 64) * cpr + (size_t)(c / 64)];
+    }
+    void report(const char* kind, int64_t off, int s0, int t0, int s1, int t1) {
+        ++races;
+        if (first_race.empty()) {
+            char tmp[256];
+            const int buf = (int)(off / stride);
+            snprintf(tmp, sizeof tmp, "%s on matrix %d cell (%lld,%lld): step %d task %d vs step %d task %d", kind, buf,
+                     (long long)((off % stride) / ld / 64), (long long)(off % ld / 64), s0, t0, s1, t1);
+            first_race = tmp;
+        }
+    }
+    void read(int64_t off, int step, int task) {
+        Cell& c = cell(off);
+        if (c.w_step >= 0 && !(c.w_step == step && c.w_task == task)) {
+            if (c.w_step == step || !hb(c.w_step, step)) report("read-after-write race", off, c.w_step, c.w_task, step, task);
+        }
+        if (c.readers.empty() || c.readers.back() != std::make_pair(step, task)) c.readers.push_back({step, task});
+    }
+    void write(int64_t off, int step, int task) {
+        Cell& c = cell(off);
+        if (c.w_step >= 0 && !(c.w_step == step && c.w_task == task)) {
+            if (c.w_step == step || !hb(c.w_step, step)) report("write-after-write race", off, c.w_step, c.w_task, step, task);
+        }
+        for (auto& r : c.readers) {
+            if (r.first == step && r.second == task) continue;
+            if (r.first == step || !hb(r.first, step)) report("write-after-read race", off, r.first, r.second, step, task);
+        }
+        c.readers.clear();
+        c.w_step = step;
+        c.w_task = task;
+    }
+};
+
+// operand window of a task: rows [0,T), k in [0,klen); cell (rb, kb) in 64-units; is it entirely masked (read as zero)?
+bool operand_cell_masked(int T, int klen, bool lower, bool upper, int rb, int kb) {
+    const int r0 = rb * 64, r1 = r0 + 63, k0 = kb * 64, k1 = k0 + 63;
+    if (lower && k0 > r1 + (klen - T)) return true;   // zero where k > r + klen - T
+    if (upper && k1 < r0) return true;                // zero where k < r
+    return false;
+}
+
+void task_accesses(Sim& s, const GemmTask& t, int T, int64_t base_a, int64_t base_b, int64_t base_c, int64_t base_c2, int step,
+                   int task) {
+    const bool a_lo = t.flags & TF_A_LOWER, a_up = t.flags & TF_A_UPPER, b_lo = t.flags & TF_B_LOWER, b_up = t.flags & TF_B_UPPER;
+    for (int rb = 0; rb < T / 64; ++rb)
+        for (int kb = 0; kb < (t.klen + 63) / 64; ++kb) {
+            if (!operand_cell_masked(T, t.klen, a_lo, a_up, rb, kb)) s.read(base_a + t.a_off + (int64_t)rb * 64 * s.ld + kb * 64, step, task);
+            if (!operand_cell_masked(T, t.klen, b_lo, b_up, rb, kb)) s.read(base_b + t.b_off + (int64_t)rb * 64 * s.ld + kb * 64, step, task);
+        }
+    for (int rb = 0; rb < T / 64; ++rb)
+        for (int cb = 0; cb < T / 64; ++cb) {
+            const int64_t off = base_c + t.c_off + (int64_t)rb * 64 * s.ld + cb * 64;
+            if (t.beta != 0.0) s.read(off, step, task);
+            s.write(off, step, task);
+            if (t.c2_off >= 0) s.write(base_c2 + t.c2_off + (int64_t)cb * 64 * s.ld + rb * 64, step, task);
+        }
+}
+
+void task_compute(Sim& s, const GemmTask& t, int T, int64_t base_a, int64_t base_b, int64_t base_c, int64_t base_c2) {
+    const bool a_lo = t.flags & TF_A_LOWER, a_up = t.flags & TF_A_UPPER, b_lo = t.flags & TF_B_LOWER, b_up = t.flags & TF_B_UPPER;
+    const double* A = s.mem.data() + base_a + t.a_off;
+    const double* B = s.mem.data() + base_b + t.b_off;
+    double* C = s.mem.data() + base_c + t.c_off;
+    double* C2 = t.c2_off >= 0 ? s.mem.data() + base_c2 + t.c2_off : nullptr;
+    const int64_t ld = s.ld;
+    std::vector<double> out((size_t)T * T);
+    std::vector<double> arow(t.klen), brow((size_t)T * t.klen);
+    for (int c = 0; c < T; ++c)
+        for (int k = 0; k < t.klen; ++k) {
+            double v = B[(int64_t)c * ld + k];
+            if (b_lo && k > c + t.klen - T) v = 0.0;
+            if (b_up && k < c) v = 0.0;
+            brow[(size_t)c * t.klen + k] = v;
+        }
+    for (int r = 0; r < T; ++r) {
+        for (int k = 0; k < t.klen; ++k) {
+            double v = A[(int64_t)r * ld + k];
+            if (a_lo && k > r + t.klen - T) v = 0.0;
+            if (a_up && k < r) v = 0.0;
+            arow[k] = v;
+        }
+        for (int c = 0; c < T; ++c) {
+            const double* bp = &brow[(size_t)c * t.klen];
+            double acc = 0.0;
+            for (int k = 0; k < t.klen; ++k) acc += arow[k] * bp[k];
+            out[(size_t)r * T + c] = acc;
+        }
+    }
+    for (int r = 0; r < T; ++r)
+        for (int c = 0; c < T; ++c) {
+            double v = t.alpha * out[(size_t)r * T + c];
+            double* pc = C + (int64_t)r * ld + c;
+            if (t.beta != 0.0) v += t.beta * (*pc);
+            *pc = v;
+            if (C2) C2[(int64_t)c * ld + r] = v;
+        }
+}
+
+// Cholesky + inverse of the 128-block `blk` of A (lower part read), L block (zeros above) and mirrored inverse out
+int leaf_compute(Sim& s, int blk) {
+    const int64_t ld = s.ld, g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;
+    const double* A = s.mem.data() + (int64_t)BUF_A * s.stride + g0;
+    double* Lo = s.mem.data() + (int64_t)BUF_L * s.stride + g0;
+    double* So = s.mem.data() + (int64_t)BUF_S * s.stride + g0;
+    std::vector<double> L((size_t)NB * NB, 0.0), X((size_t)NB * NB, 0.0);
+    for (int j = 0; j < NB; ++j) {
+        double d = A[(int64_t)j * ld + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * NB + k] * L[(size_t)j * NB + k];
+        if (!(d > 0.0)) return blk * NB + j + 1;
+        const double ljj = sqrt(d);
+        L[(size_t)j * NB + j] = ljj;
+        for (int i = j + 1; i < NB; ++i) {
+            double v = A[(int64_t)i * ld + j];
+            for (int k = 0; k < j; ++k) v -= L[(size_t)i * NB + k] * L[(size_t)j * NB + k];
+            L[(size_t)i * NB + j] = v / ljj;
+        }
+    }
+    for (int j = 0; j < NB; ++j) {   // X = L^-1 column by column
+        X[(size_t)j * NB + j] = 1.0 / L[(size_t)j * NB + j];
+        for (int i = j + 1; i < NB; ++i) {
+            double v = 0.0;
+            for (int k = j; k < i; ++k) v += L[(size_t)i * NB + k] * X[(size_t)k * NB + j];
+            X[(size_t)i * NB + j] = -v / L[(size_t)i * NB + i];
+        }
+    }
+    for (int r = 0; r < NB; ++r)
+        for (int c = 0; c < NB; ++c) {
+            Lo[(int64_t)r * ld + c] = L[(size_t)r * NB + c];
+            const int hi = std::max(r, c), lo = std::min(r, c);
+            So[(int64_t)r * ld + c] = X[(size_t)hi * NB + lo];
+        }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// report[0] = |L L^T - A|_F / |A|_F, [1] = max |X L - I|, [2] = max |S - S^T| over the lower/upper pairs that hold X,
+// [3] = max |K^-1 - X^T X| / max |X^T X| (want_grad only), [4] = number of races, [5] = steps, [6] = tasks, [7] = events
+// numeric = 0: race check only (any size); 1: also execute.  slack = extra rows of capacity (stride = (ld + slack)^2).
+// mutate (self-test of the checker): 1 = the first bulk launch forgets to wait for the chain; 2 = the main stream forgets
+// the final join; 3 = the second macro's first leaf forgets its event wait
+int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double* report, char* msg, int msglen) {
+    Sim s;
+    s.ld = (int64_t)nblk * NB;
+    s.stride = (s.ld + slack) * (s.ld + slack);
+    build_plan(s.p, nblk, s.ld, s.stride);
+    if (mutate == 1) {
+        for (Step& st : s.p.steps)
+            if (st.strm == 1 && st.wait_ev > 0) { st.wait_ev = 0; break; }
+    } else if (mutate == 2) {
+        for (Step& st : s.p.steps)
+            if (st.kind == 2) st.wait_ev = 0;
+    } else if (mutate == 3) {
+        int seen = 0;
+        for (Step& st : s.p.steps)
+            if (st.strm == 0 && st.wait_ev > 0 && st.kind != 2 && ++seen == 1) { st.wait_ev = 0; break; }
+    }
+    const Plan& p = s.p;
+    s.cpr = (int)(s.ld / 64);
+    s.cells.assign((size_t)4 * s.cpr * s.cpr, Cell());
+    for (int i = 0; i < 8; ++i) report[i] = 0.0;
+    report[5] = (double)p.steps.size();
+    report[6] = (double)p.n_fixed_tasks;
+    report[7] = (double)p.n_events;
+    if (msg && msglen) msg[0] = 0;
+    const int64_t N = s.ld;
+    std::vector<double> A0;
+    if (numeric) {
+        s.mem.assign((size_t)4 * s.stride, std::numeric_limits<double>::quiet_NaN());
+        // SPD test matrix: smooth kernel + diagonal; only what the K build writes (64-tiles of the lower triangle)
+        A0.assign((size_t)N * N, 0.0);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j <= i; ++j) {
+                const double d = (double)(i - j) / 40.0;
+                double v = exp(-0.5 * d * d) + 0.3 * exp(-d) * cos(0.05 * (double)(i - j));   // sum of two stationary PSD kernels
+                if (i == j) v += 0.5 + 0.001 * (double)(i % 17);
+                A0[(size_t)i * N + j] = A0[(size_t)j * N + i] = v;
+            }
+        double* A = s.mem.data() + (int64_t)BUF_A * s.stride;
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < N; ++j)
+                if (j / 64 <= i / 64) A[i * s.ld + j] = A0[(size_t)i * N + j];
+    }
+    // ---- walk the steps in enqueue order ----
+    Clock vc[2] = {{{0, 0}}, {{0, 0}}};
+    std::vector<Clock> evclock(p.n_events + 1, Clock{{-1, -1}});
+    s.step_clock.resize(p.steps.size());
+    s.step_strm.resize(p.steps.size());
+    // the K build (one launch on the main stream, before every step) wrote the lower 64-tiles of A: model it as step -1
+    // by leaving the cells without a writer -- every plan step is ordered after it by stream order / the chain events
+    for (size_t si = 0; si < p.steps.size(); ++si) {
+        const Step& st = p.steps[si];
+        const int strm = st.strm == 1 ? 1 : 0;
+        if (st.wait_ev > 0) {
+            if (evclock[st.wait_ev].t[0] < 0) {
+                snprintf(msg, msglen, "step %zu waits for event %d before it is recorded", si, st.wait_ev);
+                return -1;
+            }
+            for (int k = 0; k < 2; ++k) vc[strm].t[k] = std::max(vc[strm].t[k], evclock[st.wait_ev].t[k]);
+        }
+        vc[strm].t[strm] += 1;
+        s.step_clock[si] = vc[strm];
+        s.step_strm[si] = strm;
+        if (st.kind == 0) {
+            const int64_t g0 = (int64_t)st.blk * NB * s.ld + (int64_t)st.blk * NB;
+            for (int rb = 0; rb < 2; ++rb)
+                for (int cb = 0; cb < 2; ++cb) {
+                    if (cb <= rb) s.read((int64_t)BUF_A * s.stride + g0 + (int64_t)rb * 64 * s.ld + cb * 64, (int)si, 0);
+                    s.write((int64_t)BUF_L * s.stride + g0 + (int64_t)rb * 64 * s.ld + cb * 64, (int)si, 0);
+                    s.write((int64_t)BUF_S * s.stride + g0 + (int64_t)rb * 64 * s.ld + cb * 64, (int)si, 0);
+                }
+            if (numeric) {
+                const int info = leaf_compute(s, st.blk);
+                if (info) {
+                    snprintf(msg, msglen, "leaf %d: non-positive pivot %d (or NaN input)", st.blk, info);
+                    return -2;
+                }
+            }
+        } else if (st.kind == 1) {
+            const int n = st.count + (want_grad ? st.count_grad : 0);
+            const int64_t ba = (int64_t)st.a * s.stride, bb = (int64_t)st.b * s.stride, bc = (int64_t)st.c * s.stride;
+            const int64_t bc2 = st.c2 >= 0 ? (int64_t)st.c2 * s.stride : 0;
+            for (int k = 0; k < n; ++k) task_accesses(s, p.tasks[st.first + k], st.tile, ba, bb, bc, bc2, (int)si, k);
+            if (numeric)
+                for (int k = 0; k < n; ++k) task_compute(s, p.tasks[st.first + k], st.tile, ba, bb, bc, bc2);
+        }
+        if (st.rec_ev > 0) evclock[st.rec_ev] = vc[strm];
+        if (st.rec_ev_final > 0) evclock[st.rec_ev_final] = vc[strm];
+    }
+    // everything must be visible to the main stream at the end (solve / gradient kernels follow there)
+    for (size_t si = 0; si < p.steps.size(); ++si)
+        if (s.step_strm[si] == 1 && vc[0].t[1] < s.step_clock[si].t[1]) {
+            snprintf(msg, msglen, "bulk step %zu is not joined into the main stream at the end of the plan", si);
+            return -3;
+        }
+    if (want_grad && !p.kinv_streamed && numeric) {   // the stand-alone K^-1 launch
+        const Step& st = p.kinv_step;
+        for (int k = 0; k < st.count; ++k)
+            task_compute(s, p.tasks[st.first + k], st.tile, (int64_t)st.a * s.stride, (int64_t)st.b * s.stride,
+                         (int64_t)st.c * s.stride, 0);
+    }
+    report[4] = (double)s.races;
+    if (s.races && msg) snprintf(msg, msglen, "%d races; first: %s", s.races, s.first_race.c_str());
+    if (!numeric) return s.races ? 1 : 0;
+    // ---- numeric checks ----
+    const double* L = s.mem.data() + (int64_t)BUF_L * s.stride;
+    const double* S = s.mem.data() + (int64_t)BUF_S * s.stride;
+    const double* Ki = s.mem.data() + (int64_t)BUF_A * s.stride;
+    double num = 0.0, den = 0.0;
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j <= i; ++j) {
+            double v = 0.0;
+            for (int64_t k = 0; k <= j; ++k) v += L[i * s.ld + k] * L[j * s.ld + k];
+            const double d = v - A0[(size_t)i * N + j];
+            num += d * d;
+            den += A0[(size_t)i * N + j] * A0[(size_t)i * N + j];
+        }
+    report[0] = sqrt(num / den);
+    double e1 = 0.0, e2 = 0.0;
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j <= i; ++j) {
+            double v = 0.0;
+            for (int64_t k = j; k <= i; ++k) v += S[i * s.ld + k] * L[k * s.ld + j];   // X = lower part of S
+            e1 = std::max(e1, fabs(v - (i == j ? 1.0 : 0.0)));
+            e2 = std::max(e2, fabs(S[i * s.ld + j] - S[j * s.ld + i]));
+        }
+    report[1] = std::isnan(e1) ? 1e300 : e1;
+    report[2] = std::isnan(e2) ? 1e300 : e2;
+    for (int64_t i = 0; i < N && !std::isnan(report[1]); ++i)
+        for (int64_t j = 0; j <= i; ++j)
+            if (std::isnan(S[i * s.ld + j]) || std::isnan(L[i * s.ld + j])) report[1] = 1e300;
+    if (want_grad) {
+        double e3 = 0.0, mx = 0.0;
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j <= i; ++j) {
+                double v = 0.0;
+                for (int64_t k = i; k < N; ++k) v += S[k * s.ld + i] * S[k * s.ld + j];   // sum_k X[k][i] X[k][j]
+                const double got = Ki[i * s.ld + j];
+                e3 = std::isnan(got) ? 1e300 : std::max(e3, fabs(v - got));
+                mx = std::max(mx, fabs(v));
+            }
+        report[3] = e3 / mx;
+    }
+    return s.races ? 1 : 0;
+}
+
+// out[0..7] = main-stream launches, bulk launches, waits on the main stream, records on the main stream, waits on bulk,
+// records on bulk, tasks (without the stand-alone K^-1 launch), gradient-only tasks
+void plan_stats(int nblk, double* out) {
+    Plan p;
+    const int64_t ld = (int64_t)nblk * NB;
+    build_plan(p, nblk, ld, ld * ld);
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (const Step& st : p.steps) {
+        const int b = st.strm == 1;
+        if (st.kind != 2) out[b] += 1;
+        if (st.wait_ev > 0) out[b ? 4 : 2] += 1;
+        out[b ? 5 : 3] += (st.rec_ev > 0) + (st.rec_ev_final > 0);
+        if (st.kind == 1) { out[6] += st.count + st.count_grad; out[7] += st.count_grad; }
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""Multi-rank tests with the REAL HIP engine: two processes share GPU 0 of the one-GPU box.
+
+RCCL refuses two ranks on one device, so the two-process test moves the device data of the row-block layout through
+host memory (mfgp_rows_download / mfgp_rows_upload) and the small gathers over sharding.SocketComm; the RCCL calls
+themselves (mfgp_comm_init, mfgp_allgather_rows, mfgp_allgather_host) are exercised with a communicator of size 1.
+Covers e1 (predictive rows sharded), e2 (restarts sharded) and e3 (K row blocks + all-gather + prebuilt evaluation)."""
+import multiprocessing as mp
+import socket
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def hf(x):
+    return cases.hf_2d(x)[:, None]
+
+
+def lf(x):
+    return cases.lf_2d(x)[:, None]
+
+
+def _model_run(comm, conc):
+    import multifidelity_datafusion_gps_amd as mf
+
+    class Budget(mf.NARGP):
+        lf_max_iters = first_run_max_iters = restart_max_iters = 12
+        eval_cap = 12
+        restart_concurrency = conc
+
+    rng = np.random.default_rng(7)
+    X_lf = rng.uniform(size=(300, 2))
+    model = Budget(2, hf, None, lf_X=X_lf, lf_Y=lf(X_lf), seed=11, comm=comm)
+    model.fit(rng.uniform(size=(200, 2)))
+    mean, var = model.predict(rng.uniform(size=(333, 2)))
+    theta = np.array([p.value for p in model.hf_model.parameters()])
+    evals = model.hf_model.n_evals
+    model.close()
+    return dict(theta=theta, mean=mean, var=var, evals=evals)
+
+
+def _rowblock_run(comm):
+    from multifidelity_datafusion_gps_amd._lib import Engine
+    from multifidelity_datafusion_gps_amd.sharding import eval_rowblock_allgather
+    rng = np.random.default_rng(3)
+    X = rng.uniform(size=(700, 4))
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    e = Engine(0)
+    e.set_data(Xa, cases.hf_4d(X))
+    e.set_kernel(cases.composite(4, 1))
+    theta, noise = np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.02
+    fused = e.eval(theta, noise, 1e-8)
+    sharded = eval_rowblock_allgather(e, comm, theta, noise)      # 768 padded rows -> 2 x 384
+    e.close()
+    return fused, sharded
+
+
+def _worker(rank, world, port, q):
+    from multifidelity_datafusion_gps_amd.sharding import SocketComm
+    comm = SocketComm(rank, world, "127.0.0.1", port, timeout=120)
+    try:
+        q.put((rank, dict(seq=_model_run(comm, 1), conc=_model_run(comm, 2), rowblock=_rowblock_run(comm))))
+    finally:
+        comm.close()
+
+
+def test_two_processes_on_one_gpu_with_the_hip_engine():
+    from multifidelity_datafusion_gps_amd.sharding import LocalComm
+    ref = _model_run(LocalComm(), 1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        for key in ("seq", "conc"):
+            got = out[r][key]
+            # e2: the same restarts ran (seeded per restart), split over the ranks; the same winner everywhere
+            np.testing.assert_allclose(got["theta"], ref["theta"], rtol=1e-9)
+            # e1: row-sharded predictions, gathered: every rank holds the full result, equal to the single process
+            np.testing.assert_allclose(got["mean"], ref["mean"], rtol=0, atol=1e-7)
+            np.testing.assert_allclose(got["var"], ref["var"], rtol=0, atol=1e-7)
+            np.testing.assert_array_equal(got["mean"], out[0][key]["mean"])
+        assert out[r]["seq"]["evals"] < ref["evals"]
+        # e3: K built by two ranks' row blocks + gathered = the fused evaluation, bit for bit (same kernels, same order)
+        (f0, g0), (f1, g1) = out[r]["rowblock"]
+        assert f1 == f0 and np.array_equal(g1, g0)
+
+
+def test_rccl_calls_with_a_communicator_of_one(engine):
+    """mfgp_comm_unique_id / mfgp_comm_init / mfgp_allgather_rows / mfgp_allgather_host on the real RCCL, world size 1
+    (all a one-GPU box admits): the library loads librccl lazily, creates the communicator on the handle's device and
+    runs both collectives on the handle's stream."""
+    from multifidelity_datafusion_gps_amd.sharding import SocketComm, eval_rowblock_allgather
+    rng = np.random.default_rng(5)
+    X = rng.uniform(size=(500, 3))
+    Y = cases.hf_3d(X)
+    engine.set_data(X, Y)
+    engine.set_kernel(cases.single(cases.RBF, 3))
+    theta, noise = np.array([1.0, 0.3]), 0.01
+    f0, g0 = engine.eval(theta, noise, 1e-8)
+    comm = SocketComm(0, 1)
+    assert comm.attach_engine(engine) and comm.transport == "rccl" and engine.comm_size == 1
+    got = engine.allgather_host(np.arange(10.0))
+    assert got.shape == (1, 10) and np.array_equal(got[0], np.arange(10.0))
+    engine.kbuild_rows(theta, noise, 1e-8, 0, 512)
+    engine.allgather_rows()                                       # in place, one rank: the matrix is unchanged
+    f1, g1 = engine.eval_prebuilt(True)
+    assert f1 == f0 and np.array_equal(g1, g0)
+    f2, g2 = eval_rowblock_allgather(engine, comm, theta, noise)
+    assert f2 == f0 and np.array_equal(g2, g0)
+    engine.comm_destroy()

@@ -1,0 +1,86 @@
+"""CPU checks of the factorisation planner (multifidelity_datafusion_gps_amd/csrc/plan.cpp) -- no GPU needed.
+
+tests/host_plan/plan_sim.cpp compiles the planner itself with g++ and, for the plans it emits,
+  * executes every step in enqueue order with a plain-C restatement of the tile-GEMM task and of the leaf, on matrices
+    pre-filled with NaN wherever nothing has been written, and checks L L^T = A, X L = I, the mirrored storage of X and
+    K^-1 = X^T X;
+  * checks the two-stream schedule for data races (vector clocks over the streams, 64x64 cells, tasks of one launch
+    concurrent), that every event is recorded before it is waited for, and that the bulk stream is joined at the end.
+The checker checks itself on three mutated plans (a dropped wait must be reported)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = [os.path.join(ROOT, "tests", "host_plan", "plan_sim.cpp"),
+       os.path.join(ROOT, "multifidelity_datafusion_gps_amd", "csrc", "plan.cpp")]
+LIB = os.path.join(ROOT, "tests", "host_plan", "libplan_sim.so")
+
+_DRIVER = r"""
+import ctypes, json, sys
+lib = ctypes.CDLL(sys.argv[1])
+lib.plan_sim.restype = ctypes.c_int
+lib.plan_sim.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+out = []
+for spec in json.loads(sys.argv[2]):
+    rep = (ctypes.c_double * 8)()
+    msg = ctypes.create_string_buffer(512)
+    rc = lib.plan_sim(*spec, rep, msg, 512)
+    out.append([rc, list(rep), msg.value.decode()])
+print(json.dumps(out))
+"""
+
+
+@pytest.fixture(scope="module")
+def simlib():
+    deps = SRC + [os.path.join(ROOT, "multifidelity_datafusion_gps_amd", "csrc", "plan.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", LIB] + SRC, check=True)
+    return LIB
+
+
+def _run(lib, specs, env=None):
+    """the planner reads its switches from the environment when it plans: one subprocess per environment"""
+    import json
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", _DRIVER, lib, json.dumps(specs)], env=e, capture_output=True, text=True,
+                       check=True)
+    return json.loads(r.stdout)
+
+
+ENVS = [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}, {"MFGP_SHIFT": "0"}, {"MFGP_KINV_STREAM": "0"},
+        {"MFGP_T128_MIN": "10"}, {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "recursive"}]
+
+
+@pytest.mark.parametrize("env", ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_plans_factorise_invert_and_accumulate_kinv_without_races(simlib, env):
+    # (nblk, numeric, want_grad, slack rows of capacity, mutate)
+    specs = [(nb, 1, g, 128 if nb % 2 else 0, 0) for nb in (1, 2, 3, 5, 8, 9) for g in (0, 1)]
+    for (nb, _, g, _, _), (rc, rep, msg) in zip(specs, _run(simlib, specs, env)):
+        assert rc == 0, (nb, g, msg)
+        assert rep[0] < 1e-14 and rep[1] < 1e-12 and rep[2] == 0.0, (nb, g, rep)     # L L^T = A, X L = I, S mirrored
+        if g:
+            assert rep[3] < 1e-12, (nb, rep)                                            # K^-1 = X^T X
+        assert rep[4] == 0
+
+
+@pytest.mark.parametrize("env", [{}, {"MFGP_SHIFT": "1"}, {"MFGP_SHIFT": "0"}, {"MFGP_MACRO": "6"}, {"MFGP_PLAN": "levels"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_schedules_of_the_bench_sizes_are_race_free(simlib, env):
+    """race check only (no arithmetic) at the block counts of the BASELINE configurations: 32 (N = 4096), 47 / 48 / 49
+    (the slim-chain switch), 64 (N = 8192), 128 (N = 16384)"""
+    specs = [(nb, 0, 1, 0, 0) for nb in (16, 32, 47, 48, 49, 64, 128)]
+    for spec, (rc, rep, msg) in zip(specs, _run(simlib, specs, env)):
+        assert rc == 0 and rep[4] == 0, (spec, msg)
+
+
+def test_the_checker_catches_a_dropped_dependency(simlib):
+    ok, no_chain_wait, no_join, no_leaf_wait = _run(simlib, [(16, 0, 1, 0, m) for m in (0, 1, 2, 3)])
+    assert ok[0] == 0
+    assert no_chain_wait[0] == 1 and no_chain_wait[1][4] > 0 and "race" in no_chain_wait[2]
+    assert no_join[0] == -3 and "not joined" in no_join[2]
+    assert no_leaf_wait[0] == 1 and no_leaf_wait[1][4] > 0
