@@ -42,9 +42,11 @@ static void run_step(mfgp_handle* h, const Step& s, bool want_grad = true) {
         launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
         h->launches++;
     } else if (s.kind == 1) {
-        const int n = s.count + (want_grad ? s.count_grad : 0);   // the K^-1 accumulation rides along only for a gradient
+        // a launch that carries a chunk of the K^-1 accumulation has a second task list for gradient evaluations
+        const bool g = want_grad && s.gcount > 0;
+        const int n = g ? s.gcount : s.count;
         if (n > 0) {
-            launch_gemm(st, s.tile, h->dtasks + s.first, n, h->buf[s.a], h->buf[s.b], h->buf[s.c],
+            launch_gemm(st, s.tile, h->dtasks + (g ? s.gfirst : s.first), n, h->buf[s.a], h->buf[s.b], h->buf[s.c],
                         s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np, s.role);
             h->launches++;
         }

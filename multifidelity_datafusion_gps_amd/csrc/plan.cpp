@@ -13,11 +13,13 @@ namespace mfgp {
 // planner
 // ------------------------------------------------------------------------------------------------
 static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group);
+static int g_t128_min = 300;
 static int pick_tile(int ntiles128) {
     // 128-tiles run the MFMA pipe better, but a launch of few tiles is bound by its LONGEST tile (one tile per CU, 256
-    // CUs): below ~300 tiles four times as many 64-tiles balance better (top inverse level at N = 4096: 2 x 330 -> 2 x 220 us)
-    static const int t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : 300;
-    return ntiles128 >= t128_min ? 128 : 64;
+    // CUs): below ~300 tiles four times as many 64-tiles balance better (top inverse level at N = 4096: 2 x 330 -> 2 x 220 us).
+    // With macro panels of K >= 768 (N >= 7168) a 128-tile lasts >= 130 us and the threshold moves to 600 (N = 8192: the
+    // 364..448-tile column launches ran at 31 TFLOP/s as 128-tiles; whole evaluation 13.74 -> 13.36 ms).
+    return ntiles128 >= g_t128_min ? 128 : 64;
 }
 
 static void add_gemm(Plan& p, std::vector<Step>& plan, int tile, int first, int a, int b, int c, int c2) {
@@ -507,13 +509,25 @@ void plan_predv(Plan& p, int rows_p) {
 static void plan_sweep(Plan& p) {
     const int64_t ld = p.ld, bs = p.stride;
     const int nb = p.nblk;
-    int MB = 4;
+    // block columns per macro panel = K / 128 of the bulk trailing update.  Chain-bound sizes: 4 (a short in-macro chain);
+    // bulk-bound sizes: the longer K runs the matrix pipe better, but a 128-tile of K = 1024 holds its CU for 170 us and
+    // the leaf (which needs a whole CU) waits for one to retire (one evaluation alone, N = 6144: 6.66 / 6.91 / 7.37 ms at
+    // 4 / 6 / 8; N = 8192: 13.94 / 13.69 / 13.74 at 4 / 6 / 8; N = 16384: 96.8 / 94.1 / 93.1 ms at 8 / 12 / 16)
+    int MB = nb >= 96 ? 16 : (nb >= 56 ? 6 : 4);
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
-    int chain_role = nb >= 48 ? 3 : 0;   // slim chain workgroups co-resident with bulk workgroups
+    // slim (16 KB LDS) chain workgroups fit on a CU beside a 128 KB bulk workgroup; the 64 KB kernel would wait for one to
+    // retire (N = 4096: 3.27 -> 3.03 ms).  Below ~24 blocks the bulk launches are 64-tiles themselves: no difference.
+    int chain_role = nb >= 24 ? 3 : 0;
     if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
     p.kinv_streamed = !(getenv("MFGP_KINV_STREAM") && atoi(getenv("MFGP_KINV_STREAM")) == 0);
+    int bulk_every = 1;   // macro panels per bulk chunk of B / K^-1 (see "the rest" below; N = 8192, MB = 8: 14.1 / 14.6 ms at 1 / 2)
+    if (const char* e = getenv("MFGP_BULK_EVERY")) bulk_every = std::max(1, atoi(e));
+    int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
+    int far_done = 0;   // block columns < far_done have been applied to B's columns beyond the next macro panel
+    bool merge_xpanel = nb >= 48;   // bulk-bound sizes: fewer, fuller launches on the bulk stream
+    if (const char* e = getenv("MFGP_XPANEL_MERGE")) merge_xpanel = atoi(e) != 0;
     auto at = [&](int buf, int64_t row, int64_t col) { return (int64_t)buf * bs + row * ld + col; };
     auto push = [&](int64_t a, int64_t b, int64_t c, int64_t c2, int klen, int flags, double alpha, double beta) {
         GemmTask t{};
@@ -548,7 +562,7 @@ static void plan_sweep(Plan& p) {
     };
     // B[i,j] -= X^T[i, klo:khi] L[j, klo:khi]^T for block rows i in [ilo, ihi), block columns j in [jlo, jhi); a row that
     // lies inside [klo, khi) starts at its own diagonal block (X^T is upper triangular) and is the FIRST touch of its
-    // B tiles (beta = 0)
+    // B tiles (beta = 0).  Used K = 128 deep on the chain (inside the macro panel) and K = chunk deep on the bulk stream.
     auto b_update = [&](int T, int ilo, int ihi, int jlo, int jhi, int klo, int khi) {
         const int sc = NB / T;
         for (int i = ilo * sc; i < ihi * sc; ++i) {
@@ -644,42 +658,86 @@ static void plan_sweep(Plan& p) {
             if (st) main_wait(*st, ev_rest_prev);
             ev_col[M1] = 0;
         }
-        if (!last) {
-            // the other block columns of the next macro panel: ONE bulk launch (the next chain waits for its event once)
-            const int lo = M1 + 1, hi = shift ? std::min(M1 + MB, nb - 1) : M2 - 1;
-            if (lo <= hi) {
-                const int T = pick_tile(ntiles_cols(lo, hi + 1));
-                const int first = (int)p.tasks.size();
-                a_update(T, lo, hi + 1, M0, M1);
-                if (launch(T, first, 1, 0)) {
-                    bulk_steps.push_back(p.steps.size() - 1);
+        // the other block columns of the next macro panel (the next chain waits for their event once) and
+        // X^T[0:M0, M] = B[0:M0, M] X_MM^T (rows above the macro; the in-macro rows came with the chain).  Both need only
+        // chain(M); where the bulk stream is the bottleneck (merge_xpanel) they share ONE launch, where the chain is
+        // (small N) the column update goes first on its own so that the next chain is released as early as possible.
+        {
+            const int lo = M1 + 1, hi = last ? M1 : (shift ? std::min(M1 + MB, nb - 1) : M2 - 1);
+            const bool have_cols = !last && lo <= hi, have_x = M0 > 0;
+            const int n_cols = have_cols ? ntiles_cols(lo, hi + 1) : 0, n_x = have_x ? M0 * (M1 - M0) : 0;
+            auto cols_launch = [&](int T, int first) {
+                if (!launch(T, first, 1, 0)) return;
+                bulk_steps.push_back(p.steps.size() - 1);
+                if (have_cols) {
                     const int ev = bulk_event();
                     p.steps.back().rec_ev = ev;
                     for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
                 }
+            };
+            if (merge_xpanel && have_cols && have_x) {
+                const int T = pick_tile(n_cols + n_x);
+                const int first = (int)p.tasks.size();
+                a_update(T, lo, hi + 1, M0, M1);
+                for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
+                cols_launch(T, first);
+            } else {
+                if (have_cols) {
+                    const int T = pick_tile(n_cols);
+                    const int first = (int)p.tasks.size();
+                    a_update(T, lo, hi + 1, M0, M1);
+                    cols_launch(T, first);
+                }
+                if (have_x) {
+                    const int T = pick_tile(n_x);
+                    const int first = (int)p.tasks.size();
+                    for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
+                    if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
+                }
             }
         }
-        if (M0 > 0) {   // X^T[0:M0, M] = B[0:M0, M] X_MM^T   (rows above the macro; the in-macro rows came with the chain)
-            const int T = pick_tile(M0 * (M1 - M0));
-            const int first = (int)p.tasks.size();
-            for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
-            if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
-        }
-        {   // the rest: A's trailing update beyond the columns already done, B's update, and (gradient only) K^-1's
+        {   // the rest: A's trailing update beyond the columns already done; B: the NEXT macro's columns are brought up to
+            // date (they are consumed right after the next chain), the columns beyond in chunks of bulk_every macro panels;
+            // and -- gradient only -- K^-1 in the same chunks and after the last panel.  Chunks of K >= 2048 where the bulk
+            // stream is the bottleneck: long-K tasks run the matrix pipe ~10 % better than K = 512 ones and rewrite
+            // their output tile less often; one macro panel at a time where the chain is (the bulk stream has slack and
+            // the tail after the last leaf stays short).
             const int a_lo = last ? nb : (shift ? std::min(M1 + MB, nb - 1) + 1 : M2);
+            const bool chunk_now = last || (M1 - far_done) >= bulk_every * MB;
+            const bool kinv_now = p.kinv_streamed && chunk_now;
             const int n_a = a_lo < nb ? ntiles_cols(a_lo, nb) : 0;
-            const int n_b = last ? 0 : M1 * (nb - M1);
-            const int n_k = p.kinv_streamed ? M1 * (M1 + 1) / 2 : 0;
+            const int n_b = last ? 0 : M1 * ((chunk_now ? nb : M2) - M1);
+            const int n_k = kinv_now ? M1 * (M1 + 1) / 2 : 0;
             const int T = pick_tile(n_a + n_b + n_k);
+            auto by_length = [&](int first) {   // longest K first: the launch's tail is then made of its shortest tasks
+                std::stable_sort(p.tasks.begin() + first, p.tasks.end(),
+                                 [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+            };
+            auto common = [&]() {
+                if (!last) b_update(T, 0, M1, M1, M2, far_done, M1);                       // catch-up of the next macro's columns
+                if (!last && chunk_now && M2 < nb) b_update(T, 0, M1, M2, nb, far_done, M1);   // the columns beyond
+                if (a_lo < nb) a_update(T, a_lo, nb, M0, M1);
+            };
             const int first = (int)p.tasks.size();
-            if (a_lo < nb) a_update(T, a_lo, nb, M0, M1);
-            if (!last) b_update(T, 0, M1, M1, nb, M0, M1);
-            const int n_base = (int)p.tasks.size() - first;
-            if (p.kinv_streamed) kinv_update(T, M0, M1);
-            Step* st = launch(T, first, 1, 0);
-            if (st) {
-                st->count = n_base;
-                st->count_grad = (int)p.tasks.size() - first - n_base;
+            common();
+            by_length(first);
+            const int count = (int)p.tasks.size() - first;
+            int gfirst = 0, gcount = 0;
+            if (kinv_now) {   // the gradient variant of this launch: the same tasks + the K^-1 chunk, ordered as a whole
+                gfirst = (int)p.tasks.size();
+                kinv_update(T, kinv_lo, M1);
+                common();
+                by_length(gfirst);
+                gcount = (int)p.tasks.size() - gfirst;
+                kinv_lo = M1;
+            }
+            if (chunk_now) far_done = M1;
+            if (count > 0 || gcount > 0) {
+                Step st{};
+                st.kind = 1; st.tile = T; st.first = first; st.count = count; st.gfirst = gfirst; st.gcount = gcount;
+                st.a = st.b = st.c = st.c2 = BUF_A;
+                st.strm = 1;
+                p.steps.push_back(st);
                 bulk_steps.push_back(p.steps.size() - 1);
             }
         }
@@ -714,6 +772,7 @@ static void plan_sweep(Plan& p) {
 }
 
 void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride) {
+    g_t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : (nblk >= 56 ? 600 : 300);
     p = Plan{};
     p.nblk = nblk;
     p.ld = ld;

@@ -48,8 +48,8 @@ struct Step {
     int wait_ev, rec_ev;  // 1-based event indices (0 = none): wait before / record after the launch
     int blk;   // leaf block
     int tile, first, count, a, b, c, c2;  // gemm: tile edge, task range, operand / result buffers
-    int count_grad;     // further tasks [first + count, first + count + count_grad) that run only when the gradient is
-                        // wanted (the K^-1 accumulation streamed behind the chain)
+    int gfirst, gcount; // gcount > 0: the task range to run INSTEAD of [first, first + count) when the gradient is wanted
+                        // (the same tasks plus a chunk of the K^-1 accumulation, ordered longest first as a whole)
     int rec_ev_final;   // a second event recorded after the launch (the plan's final join), 0 = none
 };
 

@@ -270,12 +270,13 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
                 }
             }
         } else if (st.kind == 1) {
-            const int n = st.count + (want_grad ? st.count_grad : 0);
+            const bool g = want_grad && st.gcount > 0;
+            const int n = g ? st.gcount : st.count, first = g ? st.gfirst : st.first;
             const int64_t ba = (int64_t)st.a * s.stride, bb = (int64_t)st.b * s.stride, bc = (int64_t)st.c * s.stride;
             const int64_t bc2 = st.c2 >= 0 ? (int64_t)st.c2 * s.stride : 0;
-            for (int k = 0; k < n; ++k) task_accesses(s, p.tasks[st.first + k], st.tile, ba, bb, bc, bc2, (int)si, k);
+            for (int k = 0; k < n; ++k) task_accesses(s, p.tasks[first + k], st.tile, ba, bb, bc, bc2, (int)si, k);
             if (numeric)
-                for (int k = 0; k < n; ++k) task_compute(s, p.tasks[st.first + k], st.tile, ba, bb, bc, bc2);
+                for (int k = 0; k < n; ++k) task_compute(s, p.tasks[first + k], st.tile, ba, bb, bc, bc2);
         }
         if (st.rec_ev > 0) evclock[st.rec_ev] = vc[strm];
         if (st.rec_ev_final > 0) evclock[st.rec_ev_final] = vc[strm];
@@ -349,8 +350,34 @@ void plan_stats(int nblk, double* out) {
         if (st.kind != 2) out[b] += 1;
         if (st.wait_ev > 0) out[b ? 4 : 2] += 1;
         out[b ? 5 : 3] += (st.rec_ev > 0) + (st.rec_ev_final > 0);
-        if (st.kind == 1) { out[6] += st.count + st.count_grad; out[7] += st.count_grad; }
+        if (st.kind == 1) { out[6] += st.gcount > 0 ? st.gcount : st.count; out[7] += st.gcount > 0 ? st.gcount - st.count : 0; }
     }
+}
+
+// per-step table for tools/plan_flops.py: out[7*i + ..] = {stream, kind, tile, tasks (gradient variant), executed Gflop
+// (2 T^2 klen per task), longest klen, shortest klen}; returns the number of steps (at most max_steps are written)
+int plan_steps(int nblk, int want_grad, double* out, int max_steps) {
+    Plan p;
+    const int64_t ld = (int64_t)nblk * NB;
+    build_plan(p, nblk, ld, ld * ld);
+    int n = 0;
+    for (const Step& st : p.steps) {
+        if (n >= max_steps) break;
+        double* o = out + 7 * n++;
+        o[0] = st.strm; o[1] = st.kind; o[2] = st.tile; o[3] = o[4] = o[5] = o[6] = 0;
+        if (st.kind != 1) continue;
+        const bool g = want_grad && st.gcount > 0;
+        const int cnt = g ? st.gcount : st.count, first = g ? st.gfirst : st.first;
+        int kmax = 0, kmin = 1 << 30;
+        double fl = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const GemmTask& t = p.tasks[first + k];
+            fl += 2.0 * st.tile * st.tile * t.klen;
+            kmax = std::max(kmax, (int)t.klen); kmin = std::min(kmin, (int)t.klen);
+        }
+        o[3] = cnt; o[4] = fl * 1e-9; o[5] = kmax; o[6] = cnt ? kmin : 0;
+    }
+    return n;
 }
 
 }  // extern "C"

@@ -53,7 +53,9 @@ def _run(lib, specs, env=None):
 
 
 ENVS = [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}, {"MFGP_SHIFT": "0"}, {"MFGP_KINV_STREAM": "0"},
-        {"MFGP_T128_MIN": "10"}, {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "recursive"}]
+        {"MFGP_T128_MIN": "10"}, {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2"}, {"MFGP_MACRO": "1", "MFGP_BULK_EVERY": "3"},
+        {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2", "MFGP_XPANEL_MERGE": "1", "MFGP_SHIFT": "0"},
+        {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "recursive"}]
 
 
 @pytest.mark.parametrize("env", ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
