@@ -9,6 +9,7 @@
 //
 // Covariance structure (mfgp_kern_part): K = sum_terms prod_{f in term} var_f * shape_f(r_f / l_f),
 // r_f^2 over the factor's column range; factors with the same range share r^2 ("leader").
+#include <stdlib.h>
 #include "mfgp_internal.h"
 
 namespace mfgp {
@@ -233,16 +234,137 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const dou
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path for the two covariance structures the reference actually builds:
+//     one RBF over a column range:                 K = v1 exp(-cb r2_B)
+//     the NARGP composite k1(aug) k2(std) + k3(std): K = v1 exp(-(ca r2_A + cb r2_B)) + v2 exp(-cc r2_B)
+// with the two squared distances (augmentation columns A, input columns B) accumulated ONCE per pair -- k2 and k3 share
+// r2_B -- and every per-factor constant (v1 = s1 s2, ca = 1/2l1^2, ...) folded on the host.  The generic kernel above
+// re-accumulates r^2 per factor and carries the kernel description in registers: 216 VGPRs, 2 waves per SIMD.
+// ------------------------------------------------------------------------------------------------
+struct Rbf2Spec {
+    double v1, ca, cb, v2, cc, diag_add;
+    int32_t a0, a1, b0, b1, has2, D;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void mfgp_kbuild_rbf2_f64(Rbf2Spec sp, const double* __restrict__ Xr,
+                                                            const double* __restrict__ Xc, int N, int Np,
+                                                            double* __restrict__ out, int ld, int row_tile0) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sxi = smem;
+    double* sxj = smem + sp.D * XP;
+    int bi, bj;
+    if (MODE == MODE_TRI) {
+        const int b = blockIdx.x;
+        int i = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= b) ++i;
+        while (i * (i + 1) / 2 > b) --i;
+        bi = i;
+        bj = b - i * (i + 1) / 2;
+    } else {
+        bi = blockIdx.y + row_tile0;
+        bj = blockIdx.x;
+    }
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    stage_rows(Xr, (int64_t)bi * KT, sp.D, sxi);
+    stage_rows(Xc, (int64_t)bj * KT, sp.D, sxj);
+    __syncthreads();
+
+    double r2a[16], r2b[16];
+    pair_r2(sxi, sxj, ty, tx, sp.b0, sp.b1, r2b);
+    if (sp.a1 > sp.a0) {
+        pair_r2(sxi, sxj, ty, tx, sp.a0, sp.a1, r2a);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r2a[e] = 0.0;
+    }
+    double Kv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Kv[e] = sp.v1 * exp_nonpos(-__builtin_fma(sp.ca, r2a[e], sp.cb * r2b[e]));
+    if (sp.has2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Kv[e] = __builtin_fma(sp.v2, exp_nonpos(-sp.cc * r2b[e]), Kv[e]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = bi * KT + 4 * ty + r;
+        double v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int gj = bj * KT + col_of(tx, c);
+            double k = Kv[r * 4 + c];
+            if (MODE == MODE_TRI || MODE == MODE_ROWS) {
+                if (gi >= N || gj >= N) k = (gi == gj) ? 1.0 : 0.0;
+                else if (gi == gj) k += sp.diag_add;
+            } else if (MODE == MODE_PANEL) {
+                if (gj >= N) k = 0.0;
+            }
+            v[c] = k;
+        }
+        if (MODE == MODE_FULL) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int gj = bj * KT + col_of(tx, c);
+                if (gi < N && gj < N) out[(int64_t)gi * ld + gj] = v[c];
+            }
+        } else {
+            double* p = out + (int64_t)gi * ld + bj * KT;
+            *reinterpret_cast<d2_t*>(p + 2 * tx) = (d2_t){v[0], v[1]};
+            *reinterpret_cast<d2_t*>(p + 32 + 2 * tx) = (d2_t){v[2], v[3]};
+        }
+    }
+}
+
+// does the description match the fast path?  (host side; the generic kernel remains for everything else: Matern factors,
+// other products / sums)
+static bool rbf2_match(const KernSpecDev& s, Rbf2Spec& o) {
+    static const bool on = !(getenv("MFGP_KBUILD_FAST") && atoi(getenv("MFGP_KBUILD_FAST")) == 0);
+    if (!on) return false;
+    for (int f = 0; f < s.nf; ++f)
+        if (s.type[f] != MFGP_KERN_RBF) return false;
+    o = Rbf2Spec{};
+    o.D = s.D;
+    o.diag_add = s.theta[2 * s.nf] + s.theta[2 * s.nf + 1];
+    auto half_inv_l2 = [&](int f) { const double l = s.theta[2 * f + 1]; return 0.5 * (1.0 / (l * l)); };
+    if (s.nf == 1) {
+        o.b0 = s.c0[0]; o.b1 = s.c1[0];
+        o.v1 = s.theta[0]; o.cb = half_inv_l2(0);
+        return true;
+    }
+    if (s.nf == 3 && s.term[0] == s.term[1] && s.term[2] != s.term[1] && s.c0[1] == s.c0[2] && s.c1[1] == s.c1[2]) {
+        o.a0 = s.c0[0]; o.a1 = s.c1[0];
+        o.b0 = s.c0[1]; o.b1 = s.c1[1];
+        o.v1 = s.theta[0] * s.theta[2]; o.ca = half_inv_l2(0); o.cb = half_inv_l2(1);
+        o.v2 = s.theta[4]; o.cc = half_inv_l2(2); o.has2 = 1;
+        return true;
+    }
+    return false;
+}
+
 static size_t kb_lds(int D) { return (size_t)2 * D * XP * sizeof(double); }
 
 void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X,
                        int N, int Np, double* A, int ld) {
     const int nt = Np / KT;
+    Rbf2Spec f;
+    if (rbf2_match(spec, f)) {
+        hipLaunchKernelGGL((mfgp_kbuild_rbf2_f64<MODE_TRI>), dim3(nt * (nt + 1) / 2), dim3(256), kb_lds(spec.D), s, f, X, X,
+                           N, Np, A, ld, 0);
+        return;
+    }
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_TRI>), dim3(nt * (nt + 1) / 2), dim3(256), kb_lds(spec.D), s,
                        spec, X, X, N, Np, A, ld, 0);
 }
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
                          const double* X, int N, int Np, double* Kx, int ld) {
+    Rbf2Spec f;
+    if (rbf2_match(spec, f)) {
+        hipLaunchKernelGGL((mfgp_kbuild_rbf2_f64<MODE_PANEL>), dim3(Np / KT, Nsp / KT), dim3(256), kb_lds(spec.D), s, f, Xs, X,
+                           N, Np, Kx, ld, 0);
+        return;
+    }
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_PANEL>), dim3(Np / KT, Nsp / KT), dim3(256), kb_lds(spec.D), s,
                        spec, Xs, X, N, Np, Kx, ld, 0);
 }
@@ -253,6 +375,12 @@ void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
 }
 void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, int N, int Np,
                         double* A, int ld, int row_begin, int row_end) {
+    Rbf2Spec f;
+    if (rbf2_match(spec, f)) {
+        hipLaunchKernelGGL((mfgp_kbuild_rbf2_f64<MODE_ROWS>), dim3(Np / KT, (row_end - row_begin) / KT), dim3(256),
+                           kb_lds(spec.D), s, f, X, X, N, Np, A, ld, row_begin / KT);
+        return;
+    }
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_ROWS>), dim3(Np / KT, (row_end - row_begin) / KT), dim3(256), kb_lds(spec.D), s,
                        spec, X, X, N, Np, A, ld, row_begin / KT);
 }
@@ -385,6 +513,103 @@ __global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp,
     }
 }
 
+// Fast path of the gradient reduction for the same two structures as mfgp_kbuild_rbf2_f64: with K1 = v1 exp(-(ca r2_A + cb
+// r2_B)) and K2 = v2 exp(-cc r2_B) every sum the seven derivatives need is one of
+//     s1 = sum G K1,  s1a = sum G K1 r2_A,  s1b = sum G K1 r2_B,  s2 = sum G K2,  s2b = sum G K2 r2_B,  sn = sum_i G_ii
+// (dk/dl l/k = r^2/l^2 for an RBF factor; both factors of the product term share s1) -- ONE pass over the pairs instead of
+// the generic kernel's two passes per term with r^2 re-accumulated per factor.  Same partials layout as the generic kernel.
+__global__ __launch_bounds__(256) void mfgp_grad_rbf2_f64(Rbf2Spec sp, const double* __restrict__ X,
+                                                          const double* __restrict__ Kinv, int ld,
+                                                          const double* __restrict__ alpha, int N,
+                                                          double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sxi = smem;
+    double* sxj = smem + sp.D * XP;
+    double* red = smem + 2 * sp.D * XP;  // [6][256]
+    const int b = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+    while (bi * (bi + 1) / 2 > b) --bi;
+    const int bj = b - bi * (bi + 1) / 2;
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    stage_rows(X, (int64_t)bi * KT, sp.D, sxi);
+    stage_rows(X, (int64_t)bj * KT, sp.D, sxj);
+    __syncthreads();
+
+    const double w = (bi == bj) ? 1.0 : 2.0;   // off-diagonal tiles stand for their mirror image too
+    double G[16], sn = 0.0;
+    {
+        double aj[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) aj[c] = alpha[bj * KT + col_of(tx, c)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = bi * KT + 4 * ty + r;
+            const double ai = alpha[gi];
+            const double* kp = Kinv + (int64_t)gi * ld + bj * KT;
+            const d2_t k01 = *reinterpret_cast<const d2_t*>(kp + 2 * tx);
+            const d2_t k23 = *reinterpret_cast<const d2_t*>(kp + 32 + 2 * tx);
+            const double kin[4] = {k01.x, k01.y, k23.x, k23.y};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int gj = bj * KT + col_of(tx, c);
+                const double g = ((gi < N) && (gj < N)) ? w * (ai * aj[c] - kin[c]) : 0.0;
+                G[r * 4 + c] = g;
+                if (gi == gj) sn += g;
+            }
+        }
+    }
+    double r2a[16], r2b[16];
+    pair_r2(sxi, sxj, ty, tx, sp.b0, sp.b1, r2b);
+    if (sp.a1 > sp.a0) {
+        pair_r2(sxi, sxj, ty, tx, sp.a0, sp.a1, r2a);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r2a[e] = 0.0;
+    }
+    double s1 = 0.0, s1a = 0.0, s1b = 0.0, s2 = 0.0, s2b = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const double gk = G[e] * (sp.v1 * exp_nonpos(-__builtin_fma(sp.ca, r2a[e], sp.cb * r2b[e])));
+        s1 += gk;
+        s1a = __builtin_fma(gk, r2a[e], s1a);
+        s1b = __builtin_fma(gk, r2b[e], s1b);
+    }
+    if (sp.has2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double gk = G[e] * (sp.v2 * exp_nonpos(-sp.cc * r2b[e]));
+            s2 += gk;
+            s2b = __builtin_fma(gk, r2b[e], s2b);
+        }
+    }
+    red[0 * 256 + tid] = s1; red[1 * 256 + tid] = s1a; red[2 * 256 + tid] = s1b;
+    red[3 * 256 + tid] = s2; red[4 * 256 + tid] = s2b; red[5 * 256 + tid] = sn;
+    __syncthreads();
+    // fixed-order block reduction (bitwise reproducible), then scatter into the generic layout [2f] = Sv_f, [2f+1] = Sl_f
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < 6; i += 4) {
+        double v = (red[i * 256 + lane] + red[i * 256 + 64 + lane]) + (red[i * 256 + 128 + lane] + red[i * 256 + 192 + lane]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) {
+            double* out = partials + (int64_t)b * NSUM;
+            if (sp.has2) {   // factors: 0 = k1 (columns A), 1 = k2 (columns B), 2 = k3 (columns B)
+                if (i == 0) { out[0] = v; out[2] = v; }
+                if (i == 1) out[1] = v * (2.0 * sp.ca);
+                if (i == 2) out[3] = v * (2.0 * sp.cb);
+                if (i == 3) out[4] = v;
+                if (i == 4) out[5] = v * (2.0 * sp.cc);
+            } else {
+                if (i == 0) out[0] = v;
+                if (i == 2) out[1] = v * (2.0 * sp.cb);
+            }
+            if (i == 5) out[NSUM - 1] = v;
+        }
+    }
+}
+
 int grad_num_partials(int Np) {
     const int nt = Np / KT;
     return nt * (nt + 1) / 2;
@@ -395,8 +620,14 @@ void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
                  double* out) {
     const int nb = grad_num_partials(Np);
     const size_t lds = kb_lds(spec.D) + (size_t)256 * NSUM * sizeof(double);
-    hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, Kinv, ld, alpha, N,
-                       partials);
+    Rbf2Spec f;
+    if (rbf2_match(spec, f)) {
+        hipLaunchKernelGGL(mfgp_grad_rbf2_f64, dim3(nb), dim3(256), kb_lds(spec.D) + (size_t)256 * 6 * sizeof(double), s, f, X,
+                           Kinv, ld, alpha, N, partials);
+    } else {
+        hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, Kinv, ld, alpha, N,
+                           partials);
+    }
     hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(NSUM), dim3(256), 0, s, spec, partials, nb, out);
 }
 

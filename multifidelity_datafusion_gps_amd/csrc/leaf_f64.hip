@@ -15,6 +15,7 @@
 //     wave 0 factorises the next diagonal block WHILE waves 1-7 finish the rest of the update.
 // Phase 2 inverts in place: the eight 16x16 diagonal inverses are already there, the rest is assembled recursively
 // (X21 = -X22 (L21 X11) over 16 -> 32 -> 64 -> 128) on MFMA.
+#include <stdlib.h>
 #include <mutex>
 #include "mfgp_internal.h"
 
@@ -59,6 +60,7 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 // finished row j of Y enters row k's sum.  With the sums kept negated both lane groups execute the SAME instruction
 // v[k] -= v[j] * l_kj, so the inverse costs one add per pivot and no extra communication.
 // Branch-free inside the pivot loop: a failed pivot (d <= 0 or NaN) is replaced by 1 and its index kept.
+template <int YP = LP>
 __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lane, int* info, int pivot0) {
     const int i = lane & 15;
     const bool inv_lane = (lane & 16) != 0;
@@ -98,18 +100,19 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
         }
     } else if (lane < 32) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y_out[k * LP + i] = v[k];   // column i of Y_jj (zero above the diagonal)
+        for (int k = 0; k < 16; ++k) y_out[k * YP + i] = v[k];   // column i of Y_jj (zero above the diagonal)
     }
     if (fail != 0 && lane == 0 && *info == 0) *info = pivot0 + fail;
 }
 
 // rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
+template <int YP = LP>
 __device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
     d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const double av = sL[(ib * 16 + fr) * LP + jb * 16 + 4 * s + q];
-        const double bv = Y[fr * LP + 4 * s + q];   // B[k][n] = Y[n][k]
+        const double bv = Y[fr * YP + 4 * s + q];   // B[k][n] = Y[n][k]
         acc = mfma(av, bv, acc);
     }
 #pragma unroll
@@ -131,7 +134,7 @@ __device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb,
     for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + kb * 16 + fr] = acc[r];
 }
 
-__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const double* __restrict__ A,
+__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_v2_f64(const double* __restrict__ A,
                                                                          double* Lout, double* S, int ld, int blk,
                                                                          double* logdet_part, int* info,
                                                                          unsigned long long* stamps) {
@@ -289,18 +292,162 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
 #undef STAMP
 }
 
+// ---- leaf v3: the inverse rides on the factorisation --------------------------------------------------------------------
+// Same block-in-LDS, 16-column-panel factorisation as v2, but the inverse is no longer a second phase: it is produced by
+// the augmented system [A; I] INSIDE the panel loop, as idle-wave work in the shadow of wave 0's micro-Cholesky (which is
+// the leaf's critical path: 8 x ~5.7k cycles).  With B the running image of the identity, kept in the UPPER triangle of
+// the LDS block (the lower triangle holds A -> L; the upper part of the input is never used):
+//     X^T[I,jb] = B[I,jb] Y_jj^T            (I < jb:  the same product as the panel solve L[I,jb] = A[I,jb] Y_jj^T)
+//     B[I,J]   -= X^T[I,jb] L[J,jb]^T       (I <= jb < J; X^T[jb,jb] = Y_jj^T, first touch of row jb)
+// Per panel that is 7 solves (one per wave, as many as v2's worst case) and up to 16 extra rank-16 updates spread over the
+// seven waves that wait for the micro-Cholesky anyway; v2's phase 2 (17k of its 90k cycles) is gone.
+constexpr int YP16 = 18;                     // pitch of the eight 16x16 inverse diagonal factors Y_jj (own LDS area)
+constexpr int SY_SIZE = 8 * 16 * YP16;
+
+// first touch of row jb of B:  B[jb, J] = -Y_jj^T L[J, jb]^T
+__device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb, int J, int fr, int q) {
+    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double av = -Y[(4 * s + q) * YP16 + fr];                       // A[row fr][k] = Y^T[fr][k] = Y[k][fr]
+        const double bv = sL[(J * 16 + fr) * LP + jb * 16 + 4 * s + q];      // B[k][n = fr] = L[J*16 + fr][jb*16 + k]
+        acc = mfma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sL[(jb * 16 + q + 4 * r) * LP + J * 16 + fr] = acc[r];
+}
+
+__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const double* __restrict__ A,
+                                                                         double* Lout, double* S, int ld, int blk,
+                                                                         double* logdet_part, int* info,
+                                                                         unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sL = smem;                       // 128 x LP: lower = A -> L, strictly upper 16-blocks = B -> X^T
+    double* sY = smem + 128 * LP;            // 8 x (16 x YP16): Y_jj = L_jj^-1
+    double* sc = sY + SY_SIZE;               // scratch
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int fr = lane & 15;
+    const int q = lane >> 4;
+    const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;  // offset of the diagonal block
+#define STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
+    {   // load (16 B per lane, whole rows coalesced; 16 loads in flight per thread before the first LDS store)
+        constexpr int NLD = NB * NB / 2 / LEAF_THREADS;
+        d2_t v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = tid + u * LEAF_THREADS;
+            const int row = e >> 6, c2 = e & 63;
+            v[u] = *reinterpret_cast<const d2_t*>(A + g0 + (int64_t)row * ld + 2 * c2);
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = tid + u * LEAF_THREADS;
+            const int row = e >> 6, c2 = e & 63;
+            *reinterpret_cast<d2_t*>(sL + row * LP + 2 * c2) = v[u];
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+    if (wave == 0) micro_chol16<YP16>(sL, sY, lane, info, blk * NB);
+    __syncthreads();
+    STAMP(2);
+    for (int jb = 0; jb < 8; ++jb) {
+        const double* Yj = sY + jb * 16 * YP16;
+        // panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb]
+        if (wave != jb) solve_block<YP16>(sL, Yj, wave, jb, fr, q);
+        __syncthreads();
+        if (jb == 0) STAMP(3);
+        if (jb == 7) break;
+        {   // priority: block column jb+1 of A gets panel jb's update first (one block per wave)
+            const int ib = jb + 1 + wave;
+            if (ib < 8) update_block(sL, ib, jb + 1, jb, fr, q);
+        }
+        __syncthreads();
+        if (jb == 0) STAMP(4);
+        if (wave == 0) {
+            // the next diagonal block is factorised (and inverted) while waves 1-7 finish panel jb's updates
+            micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + (jb + 1) * 16 * YP16, lane, info,
+                               blk * NB + jb * 16 + 16);
+        } else {
+            const int m = 6 - jb;                    // A: block columns jb+2 .. 7, lower blocks
+            const int nA = m * (m + 1) / 2;
+            const int w = 7 - jb;                    // B: rows 0 .. jb, block columns jb+1 .. 7
+            const int nB = (jb + 1) * w;
+            for (int idx = wave - 1; idx < nA + nB; idx += 7) {
+                if (idx < nA) {
+                    int ii = 0, rem = idx;
+                    while (rem > ii) { rem -= ii + 1; ++ii; }
+                    update_block(sL, jb + 2 + ii, jb + 2 + rem, jb, fr, q);
+                } else {
+                    const int t = idx - nA;
+                    const int I = t / w, J = jb + 1 + t % w;
+                    if (I == jb) bfirst_block(sL, Yj, jb, J, fr, q);
+                    else update_block(sL, I, J, jb, fr, q);     // (I < jb: "L[I][jb]" read there is X^T[I,jb])
+                }
+            }
+        }
+        __syncthreads();
+        if (jb == 0) STAMP(5);
+    }
+    STAMP(6);
+    // ---- write L (zeros above the diagonal) and the half log-determinant ------------------------------
+    for (int e = tid; e < NB * NB / 2; e += LEAF_THREADS) {
+        const int row = e >> 6, c2 = e & 63;
+        d2_t v = *reinterpret_cast<const d2_t*>(sL + row * LP + 2 * c2);
+        if (2 * c2 > row) v.x = 0.0;
+        if (2 * c2 + 1 > row) v.y = 0.0;
+        *reinterpret_cast<d2_t*>(Lout + g0 + (int64_t)row * ld + 2 * c2) = v;
+    }
+    {
+        double v = (tid < NB) ? log(sL[tid * LP + tid]) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sc[SC_RED + wave] = v;
+        __syncthreads();
+        if (tid == 0) logdet_part[blk] = sc[SC_RED] + sc[SC_RED + 1];  // rows live in waves 0 and 1
+    }
+    STAMP(7);
+    STAMP(8);
+    STAMP(9);
+    // ---- write X mirrored: S[r][c] = X[max(r,c)][min(r,c)]; X[hi][lo] = X^T[lo][hi] sits in the UPPER part of sL, the
+    //      diagonal 16-blocks in sY
+    for (int e = tid; e < NB * NB; e += LEAF_THREADS) {
+        const int row = e >> 7, col = e & 127;
+        const int hi = row > col ? row : col, lo = row > col ? col : row;
+        double v;
+        if ((hi >> 4) == (lo >> 4)) v = sY[(hi >> 4) * 16 * YP16 + (hi & 15) * YP16 + (lo & 15)];
+        else v = sL[lo * LP + hi];
+        S[g0 + (int64_t)row * ld + col] = v;
+    }
+    __syncthreads();
+    STAMP(10);
+#undef STAMP
+}
+
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps) {
-    constexpr size_t lds = (size_t)(128 * LP + SC_SIZE) * sizeof(double);
+    constexpr size_t lds_v2 = (size_t)(128 * LP + SC_SIZE) * sizeof(double);
+    constexpr size_t lds_v3 = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
+    static const bool v2 = getenv("MFGP_LEAF") && atoi(getenv("MFGP_LEAF")) == 2;   // A/B: the two-phase leaf
     static std::once_flag attr_once[MFGP_MAX_DEVICES];   // per device, thread-safe (see launch_gemm)
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(attr_once[dev & (MFGP_MAX_DEVICES - 1)], [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_cholinv_v2_f64),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_cholinv_f64),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v3);
     });
-    hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(1), dim3(LEAF_THREADS), lds, s, A, Lout, S, ld, blk,
-                       logdet_part, info, stamps);
+    if (v2)
+        hipLaunchKernelGGL(mfgp_leaf_cholinv_v2_f64, dim3(1), dim3(LEAF_THREADS), lds_v2, s, A, Lout, S, ld, blk,
+                           logdet_part, info, stamps);
+    else
+        hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(1), dim3(LEAF_THREADS), lds_v3, s, A, Lout, S, ld, blk,
+                           logdet_part, info, stamps);
 }
 
 }  // namespace mfgp

@@ -297,6 +297,27 @@ def test_rank1_append_equals_fresh_factorisation(engine, engine_cls):
     fresh.close()
 
 
+@pytest.mark.parametrize("name", ["rbf_3d_n50", "nargp_4d_n64", "gpdfc_2d_n40", "matern52_mixed_n48"])
+def test_factorisation_input_matrix_matches_oracle(engine, name):
+    """The matrix the factorisation consumes (K + (noise + jitter) I on the padded grid, lower 64-tiles; built by the
+    single-RBF / NARGP-composite fast-path kernel or by the generic one) read back from the device against the oracle."""
+    c = cases.make_case(name)
+    X, Y, theta, noise = c["X"], c["Y"], np.array(c["theta"]), c["noise"]
+    n = len(X)
+    engine.set_data(X, Y)
+    engine.set_kernel(c["parts"])
+    _, npad = engine.dev_matrix()
+    engine.kbuild_rows(theta, noise, 1e-8, 0, npad)               # MODE_ROWS: full rows
+    Ky = engine.rows_download(0, npad)
+    want = orc.cov(c["parts"], theta, X) + (noise + 1e-8) * np.eye(n)
+    scale = max(theta[0::2]) * (1 + 1 / min(theta[1::2]) ** 2)
+    np.testing.assert_allclose(Ky[:n, :n], want, rtol=0, atol=2e-13 * scale)
+    assert np.array_equal(Ky[n:, n:], np.eye(npad - n)) and not Ky[:n, n:].any() and not Ky[n:, :n].any()   # identity padding
+    engine.eval(theta, noise, 1e-8, want_grad=False)              # MODE_TRI build + factorisation
+    L = engine.get_L()
+    assert np.linalg.norm(L @ L.T - want) / np.linalg.norm(want) <= 1e-14 * max(n, 16)
+
+
 def test_repeated_evaluations_are_bitwise_identical(engine):
     """The factorisation overlaps two streams (look-ahead); a missing cross-stream dependency would show up as
     run-to-run differences.  Same inputs -> bitwise the same NLML and gradient, 25 times, at a size with odd block
