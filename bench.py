@@ -245,7 +245,11 @@ def main():
         evals = tot["evals"]
         # The LF level's evaluations run ALONE on the GPU (its single L-BFGS-B run is sequential): "uncontended".  The
         # HF level's share the GPU with the concurrent restarts, which stretches every launch but shortens the job.
-        sweep_tf = _rate(tot["cholinv_flops"], tot["cholinv_ms"]) / 1e12
+        # Rate the GPU delivered on the sweeps over the timed region: several evaluations are in flight at once (the concurrent
+        # restarts), so per-launch event times overlap; the aggregate = all sweep flops / timed wall time (conservative: the
+        # wall time also holds the K builds, solves, gradient reductions and the predicts).
+        sweep_tf = tot["cholinv_flops"] / dt / 1e12
+        sweep_tf_launch = _rate(tot["cholinv_flops"], tot["cholinv_ms"]) / 1e12
         sweep_tf_alone = _rate(clf["cholinv_flops"], clf["cholinv_ms"]) / 1e12
         kb_gbs = _rate(tot["kbuild_bytes"], tot["kbuild_ms"]) / 1e9
         kb_gbs_alone = _rate(clf["kbuild_bytes"], clf["kbuild_ms"]) / 1e9
@@ -274,8 +278,13 @@ def main():
                          "frac": round(sweep_tf / FP64_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic("sweep", args.n), "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes over "
                          "tools/time_eval.py, committed; not measured by this run)",
-                         "launches": int(evals), "avg_launch_ms": round(tot["cholinv_ms"] / max(evals, 1), 4),
-                         "flops_per_launch": tot["cholinv_flops"] / max(evals, 1),
+                         "launches": int(evals), "flops_per_launch": tot["cholinv_flops"] / max(evals, 1),
+                         "achieved_is": "all sweep flops of the timed region / its wall time (%d evaluations in flight at once: "
+                                        "their launch intervals overlap)" % (1 + max(args.concurrency, 0) if args.concurrency > 1 else 1),
+                         "per_launch_overlapped": {"avg_launch_ms": round(tot["cholinv_ms"] / max(evals, 1), 4),
+                                                   "achieved": round(sweep_tf_launch, 2),
+                                                   "note": "HIP events around each sweep on its engine's stream; the interval "
+                                                           "includes waiting for CUs held by the other evaluations in flight"},
                          "uncontended": {"achieved": round(sweep_tf_alone, 2), "frac": round(sweep_tf_alone / FP64_PEAK_TFLOPS, 4),
                                          "launches": int(clf["evals"]), "avg_launch_ms": round(clf["cholinv_ms"] / max(clf["evals"], 1), 4),
                                          "note": "the LF level's evaluations only: they run alone on the GPU; the HF level's "

@@ -9,7 +9,7 @@ with open(files[0]) as f:
         rows.append((d['Kernel_Name'].split('(')[0].replace('mfgp::', '').replace('void ', ''), int(d['Start_Timestamp']),
                      int(d['End_Timestamp']), int(d['Grid_Size_X']) // int(d['Workgroup_Size_X']), d['Queue_Id']))
 rows.sort(key=lambda r: r[1])
-idx = [i for i, x in enumerate(rows) if 'kbuild_f64<0>' in x[0]]
+idx = [i for i, x in enumerate(rows) if ('kbuild_' in x[0] and '<0>' in x[0])]
 ev = rows[idx[-2]:idx[-1]]
 leaves = [i for i, x in enumerate(ev) if 'leaf' in x[0]]
 ev = ev[leaves[0]:leaves[-1] + 1]       # potrf phase: first leaf .. last leaf

@@ -34,9 +34,9 @@ for strm, kind, tile, cnt, gf, kmax, kmin in steps:
     if d:
         line += "  | %-26s blocks %5d  %8.1f us" % d
         if kind == 1 and d[2] > 0:
-            line += "  %5.1f TF" % (gf / d[2] * 1e3 * 1e-3)
+            line += "  %5.1f TF" % (gf / d[2] * 1e3)
             tot[s][0] += gf; tot[s][1] += d[2]
     print(line)
 for s in (0, 1):
     if tot[s][1] > 0:
-        print("%s gemm total: %.1f Gflop in %.1f us = %.1f TFLOP/s (executed flops incl. masked triangles)" % ("main" if s == 0 else "bulk", tot[s][0], tot[s][1], tot[s][0] / tot[s][1]))
+        print("%s gemm total: %.1f Gflop in %.1f us = %.1f TFLOP/s (executed flops incl. masked triangles)" % ("main" if s == 0 else "bulk", tot[s][0], tot[s][1], tot[s][0] / tot[s][1] * 1e3))

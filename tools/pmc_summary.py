@@ -1,46 +1,84 @@
-"""Summarise rocprofv3 --pmc counter_collection CSVs (one pass per counter) into per-kernel, per-launch HBM traffic.
+"""Summarise rocprofv3 --pmc counter_collection CSVs (one pass per counter) into HBM traffic per launch and per evaluation.
 usage: pmc_summary.py N out.json FETCH_SIZE=<csv> WRITE_SIZE=<csv>
-FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
-prescribes for wide coalesced reads on gfx950; the median over a kernel's launches is reported."""
+
+FETCH_SIZE / WRITE_SIZE are in KB.  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes
+for wide coalesced reads on gfx950; WRITE_SIZE is taken as is.  Per kernel: the median over its launches.  "sweep": the sum
+over every leaf / tile-GEMM dispatch of ONE evaluation (the dispatches between the last two K-build launches of the trace:
+tools/time_eval.py runs the same evaluation several times), i.e. the traffic of the Cholesky + inverse + K^-1 stage whose
+flops bench.py's `roofline` reports."""
 import csv, json, sys, statistics
 
-KERNELS = ["mfgp_kinv_syrk_f64", "mfgp_kbuild_f64<0>", "mfgp_predvar_f64", "mfgp_grad_tiles_f64", "mfgp_predv_skinny_f64"]
+KERNELS = ["mfgp_kbuild_rbf2_f64<0>", "mfgp_kbuild_f64<0>", "mfgp_predvar_f64", "mfgp_grad_rbf2_f64", "mfgp_grad_tiles_f64",
+           "mfgp_predv_skinny_f64", "mfgp_kinv_syrk_f64", "mfgp_gemm_nt_f64_t128", "mfgp_gemm_nt_f64_t64",
+           "mfgp_gemm_nt_f64_chain", "mfgp_leaf_cholinv_f64", "mfgp_rowdot_f64"]
+SWEEP = ("mfgp_gemm_nt_f64_t128", "mfgp_gemm_nt_f64_t64", "mfgp_gemm_nt_f64_chain", "mfgp_leaf_cholinv_f64")
 
 
-def per_kernel(path, counter):
-    acc = {}
+def which(name):
+    for k in KERNELS:
+        if k in name:
+            if k == "mfgp_predvar_f64" and "t64" in name:
+                continue
+            return k
+    return None
+
+
+def load(path, counter):
+    rows = []   # (dispatch id, kernel key, value) with the counter summed over its per-XCD rows
+    acc, order = {}, []
     with open(path) as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            name = row["Kernel_Name"]
-            for k in KERNELS:
-                if name.startswith(k) or ("mfgp::" + k) in name or k in name:
-                    if k == "mfgp_kinv_syrk_f64" and "t64" in name:
-                        continue
-                    acc.setdefault(k, {}).setdefault(row["Dispatch_Id"], 0.0)
-                    acc[k][row["Dispatch_Id"]] += float(row["Counter_Value"])
-                    break
-    return {k: statistics.median(v.values()) for k, v in acc.items()}
+            d = int(row["Dispatch_Id"])
+            if d not in acc:
+                acc[d] = [which(row["Kernel_Name"]), 0.0]
+                order.append(d)
+            acc[d][1] += float(row["Counter_Value"])
+    for d in sorted(order):
+        rows.append((d, acc[d][0], acc[d][1]))
+    return rows
+
+
+def per_kernel(rows):
+    by = {}
+    for _, k, v in rows:
+        if k:
+            by.setdefault(k, []).append(v)
+    return {k: statistics.median(v) for k, v in by.items()}
+
+
+def sweep_sum(rows):
+    kb = [i for i, (_, k, _) in enumerate(rows) if k and k.startswith("mfgp_kbuild")]
+    if len(kb) < 2:
+        return None
+    return sum(v for _, k, v in rows[kb[-2]:kb[-1]] if k in SWEEP)
 
 
 def main():
     n = int(sys.argv[1]); out = sys.argv[2]
     files = dict(a.split("=", 1) for a in sys.argv[3:])
-    fetch = per_kernel(files["FETCH_SIZE"], "FETCH_SIZE")
-    write = per_kernel(files["WRITE_SIZE"], "WRITE_SIZE")
+    fr, wr = load(files["FETCH_SIZE"], "FETCH_SIZE"), load(files["WRITE_SIZE"], "WRITE_SIZE")
+    fetch, write = per_kernel(fr), per_kernel(wr)
     Np = (n + 127) // 128 * 128
-    alg = {"mfgp_kinv_syrk_f64": 2 * 4 * Np * (Np + 128), "mfgp_kbuild_f64<0>": 4 * Np * (Np + 64) + 8 * n * 5}
+    alg = {"mfgp_kbuild_rbf2_f64<0>": 4 * Np * (Np + 64) + 8 * n * 5, "mfgp_kbuild_f64<0>": 4 * Np * (Np + 64) + 8 * n * 5,
+           "mfgp_predvar_f64": 8 * Np * Np + 4 * Np * Np + 8 * Np * Np}
     res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (with --kernel-trace only) over "
-                   "`python3 tools/time_eval.py %d`; values are per launch, median over the launches in the trace. FETCH_SIZE is "
-                   "doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on gfx950; WRITE_SIZE is "
-                   "taken as is." % n, "n": n}
+                   "`python3 tools/time_eval.py %d`; per kernel: per launch, median over the launches in the trace; 'sweep': sum over "
+                   "the leaf + tile-GEMM dispatches of one evaluation. FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) "
+                   "prescribes for wide coalesced reads on gfx950; WRITE_SIZE is taken as is." % n, "n": n}
     for k in KERNELS:
         if k in fetch or k in write:
             fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
             res[k] = {"fetch_kb_raw": round(fk), "write_kb": round(wk), "traffic_bytes": int((2 * fk + wk) * 1024)}
             if k in alg:
                 res[k]["algorithmic_bytes"] = alg[k]
+    sf, sw = sweep_sum(fr), sweep_sum(wr)
+    if sf is not None and sw is not None:
+        res["sweep"] = {"fetch_kb_raw": round(sf), "write_kb": round(sw), "traffic_bytes": int((2 * sf + sw) * 1024),
+                        "algorithmic_bytes": 3 * 4 * Np * (Np + 128),
+                        "note": "algorithmic = one read of the lower triangle of Ky and one write each of L, L^-1 (mirrored: full) ~ "
+                                "K^-1: 12 Np^2 B; the rest is operand panels re-read through L2 / Infinity Cache by the tile GEMMs"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

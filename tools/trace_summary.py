@@ -8,7 +8,7 @@ with open(files[0]) as f:
         rows.append((d['Kernel_Name'].split('(')[0].replace('mfgp::', '').replace('void ', ''), int(d['Start_Timestamp']),
                      int(d['End_Timestamp']), int(d['Grid_Size_X']) // int(d['Workgroup_Size_X'])))
 rows.sort(key=lambda r: r[1])
-idx = [i for i, x in enumerate(rows) if 'kbuild_f64<0>' in x[0]]
+idx = [i for i, x in enumerate(rows) if ('kbuild_' in x[0] and '<0>' in x[0])]
 s, e = idx[-2], idx[-1]
 ev = rows[s:e]
 print(len(ev), 'dispatches; span ms %.3f' % ((ev[-1][2] - ev[0][1]) / 1e6))
