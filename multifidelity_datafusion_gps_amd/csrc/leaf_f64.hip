@@ -334,27 +334,78 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;  // offset of the diagonal block
 #define STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
-    {   // load (16 B per lane, whole rows coalesced; 16 loads in flight per thread before the first LDS store)
-        constexpr int NLD = NB * NB / 2 / LEAF_THREADS;
+    // load: only the 16-blocks on and below the diagonal (the upper part of the input is never used: that triangle of the
+    // LDS block holds B).  Wave 0 takes the first diagonal tile alone and starts its micro-Cholesky at once, the other seven
+    // waves bring in the remaining 35 tiles meanwhile.
+    if (wave == 0) {
+        d2_t v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u;            // 16 rows x 8 pairs
+            v[u] = *reinterpret_cast<const d2_t*>(A + g0 + (int64_t)(e >> 3) * ld + 2 * (e & 7));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u;
+            *reinterpret_cast<d2_t*>(sL + (e >> 3) * LP + 2 * (e & 7)) = v[u];
+        }
+        STAMP(1);
+        micro_chol16<YP16>(sL, sY, lane, info, blk * NB);    // (same wave wrote the tile: LDS program order suffices)
+    } else {
+        // the 35 other tiles of the lower block triangle (tile tl = I(I+1)/2 + J, J <= I), 128 pairs of doubles each
+        constexpr int NLD = 10;   // ceil(35 * 128 / 448 lanes)
+        const int t7 = tid - 64;
         d2_t v[NLD];
+        int off[NLD];
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
-            const int e = tid + u * LEAF_THREADS;
-            const int row = e >> 6, c2 = e & 63;
-            v[u] = *reinterpret_cast<const d2_t*>(A + g0 + (int64_t)row * ld + 2 * c2);
+            const int g = t7 + u * 448;
+            off[u] = -1;
+            if (g < 35 * 128) {
+                const int tl = 1 + g / 128, pr = g % 128;             // tile 1..35 in row-major lower-triangle order
+                int I = 0, rem = tl;
+                while (rem > I) { rem -= I + 1; ++I; }                // tl = I(I+1)/2 + J
+                const int J = rem;
+                const int row = 16 * I + (pr >> 3), col = 16 * J + 2 * (pr & 7);
+                off[u] = row * LP + col;
+                v[u] = *reinterpret_cast<const d2_t*>(A + g0 + (int64_t)row * ld + col);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = tid + u * LEAF_THREADS;
-            const int row = e >> 6, c2 = e & 63;
-            *reinterpret_cast<d2_t*>(sL + row * LP + 2 * c2) = v[u];
-        }
+        for (int u = 0; u < NLD; ++u)
+            if (off[u] >= 0) *reinterpret_cast<d2_t*>(sL + off[u]) = v[u];
     }
     __syncthreads();
-    STAMP(1);
-    if (wave == 0) micro_chol16<YP16>(sL, sY, lane, info, blk * NB);
-    __syncthreads();
     STAMP(2);
+    // output of panel jb by `nthr` threads (t = 0 .. nthr-1): L[:, 16jb:16jb+16] with zeros above the diagonal, and the
+    // mirrored inverse S[r][c] = X[max(r,c)][min(r,c)] for max(r,c) in block jb: X[hi][lo] = X^T[lo][hi] sits in the UPPER part
+    // of sL, the diagonal 16-block in sY
+    auto write_panel = [&](int jb, int t, int nthr) {
+        for (int e = t; e < NB * 8; e += nthr) {
+            const int row = e >> 3, c2 = 8 * jb + (e & 7);
+            d2_t v = *reinterpret_cast<const d2_t*>(sL + row * LP + 2 * c2);
+            if (2 * c2 > row) v.x = 0.0;
+            if (2 * c2 + 1 > row) v.y = 0.0;
+            *reinterpret_cast<d2_t*>(Lout + g0 + (int64_t)row * ld + 2 * c2) = v;
+        }
+        const int w = 16 * jb + 16;                       // the strip: rows of block jb, columns 0 .. w (row-major writes)
+        const double* Yb = sY + jb * 16 * YP16;
+        for (int e = t; e < 16 * w; e += nthr) {
+            const int r = 16 * jb + e / w, c = e % w;
+            double v;
+            if (c >= 16 * jb) {                           // inside the diagonal block
+                const int a = r & 15, b = c & 15;
+                v = a >= b ? Yb[a * YP16 + b] : Yb[b * YP16 + a];
+            } else {
+                v = sL[c * LP + r];                       // X[r][c] = X^T[c][r]
+            }
+            S[g0 + (int64_t)r * ld + c] = v;
+        }
+        for (int e = t; e < 16 * 16 * jb; e += nthr) {    // its mirror image: rows above the block, 16 consecutive columns each
+            const int c = e >> 4, r = 16 * jb + (e & 15);
+            S[g0 + (int64_t)c * ld + r] = sL[c * LP + r];
+        }
+    };
     for (int jb = 0; jb < 8; ++jb) {
         const double* Yj = sY + jb * 16 * YP16;
         // panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb]
@@ -389,19 +440,16 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
                     else update_block(sL, I, J, jb, fr, q);     // (I < jb: "L[I][jb]" read there is X^T[I,jb])
                 }
             }
+            // Block column jb of L and row / column block jb of X are final since this panel's solves: write them out now,
+            // in the shadow of the micro-Cholesky, panel by panel (16 + <= 32 KB each) instead of 256 KB after the last one.
+            write_panel(jb, tid - 64, 448);
         }
         __syncthreads();
         if (jb == 0) STAMP(5);
     }
     STAMP(6);
-    // ---- write L (zeros above the diagonal) and the half log-determinant ------------------------------
-    for (int e = tid; e < NB * NB / 2; e += LEAF_THREADS) {
-        const int row = e >> 6, c2 = e & 63;
-        d2_t v = *reinterpret_cast<const d2_t*>(sL + row * LP + 2 * c2);
-        if (2 * c2 > row) v.x = 0.0;
-        if (2 * c2 + 1 > row) v.y = 0.0;
-        *reinterpret_cast<d2_t*>(Lout + g0 + (int64_t)row * ld + 2 * c2) = v;
-    }
+    // ---- the last panel's share of the output and the half log-determinant ----
+    write_panel(7, tid, LEAF_THREADS);
     {
         double v = (tid < NB) ? log(sL[tid * LP + tid]) : 0.0;
 #pragma unroll
@@ -413,16 +461,6 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     STAMP(7);
     STAMP(8);
     STAMP(9);
-    // ---- write X mirrored: S[r][c] = X[max(r,c)][min(r,c)]; X[hi][lo] = X^T[lo][hi] sits in the UPPER part of sL, the
-    //      diagonal 16-blocks in sY
-    for (int e = tid; e < NB * NB; e += LEAF_THREADS) {
-        const int row = e >> 7, col = e & 127;
-        const int hi = row > col ? row : col, lo = row > col ? col : row;
-        double v;
-        if ((hi >> 4) == (lo >> 4)) v = sY[(hi >> 4) * 16 * YP16 + (hi & 15) * YP16 + (lo & 15)];
-        else v = sL[lo * LP + hi];
-        S[g0 + (int64_t)row * ld + col] = v;
-    }
     __syncthreads();
     STAMP(10);
 #undef STAMP

@@ -522,6 +522,8 @@ static void plan_sweep(Plan& p) {
     int chain_role = nb >= 24 ? 3 : 0;
     if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
     p.kinv_streamed = !(getenv("MFGP_KINV_STREAM") && atoi(getenv("MFGP_KINV_STREAM")) == 0);
+    bool bulk_xcd = true;   // deal the super-blocks of a bulk launch to the 8 XCDs (workgroup p runs on XCD p mod 8)
+    if (const char* e = getenv("MFGP_BULK_XCD")) bulk_xcd = atoi(e) != 0;
     int bulk_every = 1;   // macro panels per bulk chunk of B / K^-1 (see "the rest" below; N = 8192, MB = 8: 14.1 / 14.6 ms at 1 / 2)
     if (const char* e = getenv("MFGP_BULK_EVERY")) bulk_every = std::max(1, atoi(e));
     int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
@@ -535,12 +537,25 @@ static void plan_sweep(Plan& p) {
         p.tasks.push_back(t);
     };
     // A[i,j] -= L[i,klo:khi] L[j,klo:khi]^T for block columns j in [jlo,jhi), rows i >= j
+    // Tiles are enumerated in SUPER-BLOCKS of bulk_bi x bulk_bj output tiles (bi row panels + bj column panels feed
+    // bi*bj tiles): after the XCD-aware deal below the workgroups that run side by side on one XCD (own L2) share their
+    // operand panels instead of each streaming its own pair from HBM / Infinity Cache.
+    int bulk_bi = 4, bulk_bj = 4;
+    if (const char* e = getenv("MFGP_BULK_BI")) bulk_bi = std::max(1, atoi(e));
+    if (const char* e = getenv("MFGP_BULK_BJ")) bulk_bj = std::max(1, atoi(e));
+    auto in_blocks = [&](int ilo, int ihi, int jlo, int jhi, auto&& fn) {   // fn(i, j) over [ilo,ihi) x [jlo,jhi)
+        for (int i0 = ilo; i0 < ihi; i0 += bulk_bi)
+            for (int j0 = jlo; j0 < jhi; j0 += bulk_bj)
+                for (int i = i0; i < std::min(ihi, i0 + bulk_bi); ++i)
+                    for (int j = j0; j < std::min(jhi, j0 + bulk_bj); ++j) fn(i, j);
+    };
     auto a_update = [&](int T, int jlo, int jhi, int klo, int khi) {
         const int sc = NB / T;
-        for (int j = jlo * sc; j < jhi * sc; ++j)
-            for (int i = j; i < nb * sc; ++i)
-                push(at(BUF_L, (int64_t)i * T, (int64_t)klo * NB), at(BUF_L, (int64_t)j * T, (int64_t)klo * NB),
-                     at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1, (khi - klo) * NB, 0, -1.0, 1.0);
+        in_blocks(jlo * sc, nb * sc, jlo * sc, jhi * sc, [&](int i, int j) {
+            if (i < j) return;
+            push(at(BUF_L, (int64_t)i * T, (int64_t)klo * NB), at(BUF_L, (int64_t)j * T, (int64_t)klo * NB),
+                 at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1, (khi - klo) * NB, 0, -1.0, 1.0);
+        });
     };
     // L[i,c] = A[i,c] X_cc^T, block rows i in (c, nb)
     auto l_panel = [&](int T, int c) {
@@ -565,25 +580,24 @@ static void plan_sweep(Plan& p) {
     // B tiles (beta = 0).  Used K = 128 deep on the chain (inside the macro panel) and K = chunk deep on the bulk stream.
     auto b_update = [&](int T, int ilo, int ihi, int jlo, int jhi, int klo, int khi) {
         const int sc = NB / T;
-        for (int i = ilo * sc; i < ihi * sc; ++i) {
+        in_blocks(ilo * sc, ihi * sc, jlo * sc, jhi * sc, [&](int i, int j) {
             const bool inside = (int64_t)i * T >= (int64_t)klo * NB;
             const int64_t k0 = inside ? (int64_t)i * T : (int64_t)klo * NB;
-            for (int j = jlo * sc; j < jhi * sc; ++j)
-                push(at(BUF_S, (int64_t)i * T, k0), at(BUF_L, (int64_t)j * T, k0), at(BUF_W, (int64_t)i * T, (int64_t)j * T), -1,
-                     (int)((int64_t)khi * NB - k0), inside ? TF_A_UPPER : 0, -1.0, inside ? 0.0 : 1.0);
-        }
+            push(at(BUF_S, (int64_t)i * T, k0), at(BUF_L, (int64_t)j * T, k0), at(BUF_W, (int64_t)i * T, (int64_t)j * T), -1,
+                 (int)((int64_t)khi * NB - k0), inside ? TF_A_UPPER : 0, -1.0, inside ? 0.0 : 1.0);
+        });
     };
     // K^-1[i,j] (+)= X^T[i, klo:khi] X^T[j, klo:khi]^T for block rows i < khi, j <= i (lower tiles, over the dead part of A)
     auto kinv_update = [&](int T, int klo, int khi) {
         const int sc = NB / T;
-        for (int i = 0; i < khi * sc; ++i) {
+        in_blocks(0, khi * sc, 0, khi * sc, [&](int i, int j) {
+            if (j > i) return;
             const bool inside = (int64_t)i * T >= (int64_t)klo * NB;
             const int64_t k0 = inside ? (int64_t)i * T : (int64_t)klo * NB;
-            for (int j = 0; j <= i; ++j)
-                push(at(BUF_S, (int64_t)i * T, k0), at(BUF_S, (int64_t)j * T, k0), at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1,
-                     (int)((int64_t)khi * NB - k0), inside ? (TF_A_UPPER | (i == j ? TF_B_UPPER : 0)) : 0, 1.0,
-                     inside ? 0.0 : 1.0);
-        }
+            push(at(BUF_S, (int64_t)i * T, k0), at(BUF_S, (int64_t)j * T, k0), at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1,
+                 (int)((int64_t)khi * NB - k0), inside ? (TF_A_UPPER | (i == j ? TF_B_UPPER : 0)) : 0, 1.0,
+                 inside ? 0.0 : 1.0);
+        });
     };
     auto launch = [&](int T, int first, int strm, int role) -> Step* {
         Step s{};
@@ -709,9 +723,10 @@ static void plan_sweep(Plan& p) {
             const int n_b = last ? 0 : M1 * ((chunk_now ? nb : M2) - M1);
             const int n_k = kinv_now ? M1 * (M1 + 1) / 2 : 0;
             const int T = pick_tile(n_a + n_b + n_k);
-            auto by_length = [&](int first) {   // longest K first: the launch's tail is then made of its shortest tasks
-                std::stable_sort(p.tasks.begin() + first, p.tasks.end(),
+            auto by_length = [&](int first) {   // longest K first: the launch's tail is then made of its shortest tasks;
+                std::stable_sort(p.tasks.begin() + first, p.tasks.end(),     // super-blocks stay together within a K class
                                  [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
+                if (bulk_xcd) xcd_interleave(p.tasks, first, bulk_bi * bulk_bj);
             };
             auto common = [&]() {
                 if (!last) b_update(T, 0, M1, M1, M2, far_done, M1);                       // catch-up of the next macro's columns
