@@ -293,7 +293,7 @@ def main():
                                  "achieved": round(pv_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(pv_tf / FP64_PEAK_TFLOPS, 4), "traffic": pmc_traffic("mfgp_predvar_f64", args.n),
                                  "launches": int(tot["predicts"]), "avg_launch_ms": round(tot["predict_var_ms"] / max(tot["predicts"], 1), 4)},
-            "roofline_kbuild": {"kernel": "mfgp_kbuild_f64<MODE_TRI> (K(X,X)+noise lower triangle, one launch per evaluation)",
+            "roofline_kbuild": {"kernel": "mfgp_kbuild_rbf2_f64<MODE_TRI> (K(X,X)+noise lower triangle, one launch per evaluation)",
                                 "bound": "hbm", "achieved": round(kb_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(kb_gbs / HBM_PEAK_GBS, 4),
                                 "traffic": pmc_traffic("mfgp_kbuild_f64<0>", args.n),
@@ -318,6 +318,9 @@ def main():
             out["config"]["gpu_over_cpu"] = round(cb["value"] / ms_per_step, 2)
         print(json.dumps(out), flush=True)
     comm.barrier()
+    if world > 1 and comm.transport == "rccl":
+        engines["hf"].comm_destroy()      # every rank still alive: destroy the communicator before anyone exits
+        comm.barrier()
     comm.close()
 
 
