@@ -301,8 +301,10 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_v2_f64(cons
 //     B[I,J]   -= X^T[I,jb] L[J,jb]^T       (I <= jb < J; X^T[jb,jb] = Y_jj^T, first touch of row jb)
 // Per panel that is 7 solves (one per wave, as many as v2's worst case) and up to 16 extra rank-16 updates spread over the
 // seven waves that wait for the micro-Cholesky anyway; v2's phase 2 (17k of its 90k cycles) is gone.
-constexpr int YP16 = 18;                     // pitch of the eight 16x16 inverse diagonal factors Y_jj (own LDS area)
-constexpr int SY_SIZE = 8 * 16 * YP16;
+constexpr int YP16 = 18;                     // pitch of a 16x16 inverse diagonal factor Y_jj
+constexpr int SY_SIZE = 2 * 16 * YP16;       // TWO of them (panel jb's, and the next one being produced beside it): Y_jb is dead once
+                                             // panel jb's solves, first touches and output are through -- 138 KB of LDS in all, so
+                                             // that a 16 KB chain workgroup of another evaluation still fits on the CU beside the leaf
 
 // first touch of row jb of B:  B[jb, J] = -Y_jj^T L[J, jb]^T
 __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb, int J, int fr, int q) {
@@ -317,13 +319,10 @@ __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb
     for (int r = 0; r < 4; ++r) sL[(jb * 16 + q + 4 * r) * LP + J * 16 + fr] = acc[r];
 }
 
-__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const double* __restrict__ A,
-                                                                         double* Lout, double* S, int ld, int blk,
-                                                                         double* logdet_part, int* info,
-                                                                         unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restrict__ A, double* Lout, double* S, int ld, int blk,
+                                             double* logdet_part, int* info, unsigned long long* stamps) {
     double* sL = smem;                       // 128 x LP: lower = A -> L, strictly upper 16-blocks = B -> X^T
-    double* sY = smem + 128 * LP;            // 8 x (16 x YP16): Y_jj = L_jj^-1
+    double* sY = smem + 128 * LP;            // 2 x (16 x YP16): Y_jj = L_jj^-1, slot jb & 1
     double* sc = sY + SY_SIZE;               // scratch
 
     const int tid = threadIdx.x;
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
             *reinterpret_cast<d2_t*>(Lout + g0 + (int64_t)row * ld + 2 * c2) = v;
         }
         const int w = 16 * jb + 16;                       // the strip: rows of block jb, columns 0 .. w (row-major writes)
-        const double* Yb = sY + jb * 16 * YP16;
+        const double* Yb = sY + (jb & 1) * 16 * YP16;
         for (int e = t; e < 16 * w; e += nthr) {
             const int r = 16 * jb + e / w, c = e % w;
             double v;
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
         }
     };
     for (int jb = 0; jb < 8; ++jb) {
-        const double* Yj = sY + jb * 16 * YP16;
+        const double* Yj = sY + (jb & 1) * 16 * YP16;
         // panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb]
         if (wave != jb) solve_block<YP16>(sL, Yj, wave, jb, fr, q);
         __syncthreads();
@@ -421,7 +420,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
         if (jb == 0) STAMP(4);
         if (wave == 0) {
             // the next diagonal block is factorised (and inverted) while waves 1-7 finish panel jb's updates
-            micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + (jb + 1) * 16 * YP16, lane, info,
+            micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + ((jb + 1) & 1) * 16 * YP16, lane, info,
                                blk * NB + jb * 16 + 16);
         } else {
             const int m = 6 - jb;                    // A: block columns jb+2 .. 7, lower blocks
@@ -466,6 +465,86 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
 #undef STAMP
 }
 
+__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const double* __restrict__ A,
+                                                                         double* Lout, double* S, int ld, int blk,
+                                                                         double* logdet_part, int* info,
+                                                                         unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    leaf_body_v3(smem, A, Lout, S, ld, blk, logdet_part, info, stamps);
+}
+
+// ---- leaf server ---------------------------------------------------------------------------------------------------------
+// A single-workgroup kernel that needs a whole CU (151 KB of LDS) is dispatched only when ONE specific bulk workgroup
+// retires: beside K = 512 tile tasks (86 us each) the leaf waits 10-16 us per block column, beside K >= 1024 ones 75 us --
+// which is what kept the macro panels short and the bulk GEMMs below their long-K rate.  The server is ONE persistent
+// workgroup per evaluation: it takes its CU once, at the start, and then factorises the diagonal blocks 0 .. nb-1 as they
+// are announced through a mailbox in device memory, so a leaf starts the moment its input is ready.
+//   main stream:  ... inner(c-1) | mfgp_leaf_post(req = c+1) | mfgp_leaf_wait(done >= c+1) | panel(c) ...
+//   server     :  poll req >= c+1 -> acquire -> leaf(c) -> every wave drains its stores -> barrier -> release -> done = c+1
+// Hand-off protocol of /opt/skills/guides (inter-workgroup visibility): relaxed agent-scope polls with s_sleep, ONE agent
+// acquire after the match, plain loads; producer stores -> s_waitcnt vmcnt(0) in every wave -> barrier -> lane-0 agent
+// release -> s_waitcnt vmcnt(0) -> relaxed agent flag store.  Every spin is bounded (timeout -> abort flag -> everybody exits
+// and the host reports an error): the grid always drains.
+struct LeafMail {
+    int req;   int pad0[31];    // blocks announced (written by mfgp_leaf_post)
+    int done;  int pad1[31];    // blocks finished  (written by the server)
+    int abort; int pad2[31];    // set by whoever times out; everybody exits
+};
+
+__device__ __forceinline__ bool mail_wait(int* flag, int want, int* abort_flag, long long timeout_cycles) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if ((long long)__builtin_amdgcn_s_memtime() - t0 > timeout_cycles) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_server_f64(const double* A, double* Lout, double* S, int ld,
+                                                                        int nblk, double* logdet_part, int* info,
+                                                                        LeafMail* mail, long long timeout_cycles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int go;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (threadIdx.x == 0) {
+            go = mail_wait(&mail->req, blk + 1, &mail->abort, timeout_cycles) ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!go) return;                                   // aborted / timed out: leave (the host sees the abort flag)
+        leaf_body_v3(smem, A, Lout, S, ld, blk, logdet_part, info, nullptr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores of L_cc / X_cc have left
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&mail->done, blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__global__ void mfgp_leaf_post(LeafMail* mail, int value) {
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (the previous kernels' results are visible at the kernel boundary)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&mail->req, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void mfgp_leaf_wait(LeafMail* mail, int value, int* info, long long timeout_cycles) {
+    if (threadIdx.x == 0) {
+        if (!mail_wait(&mail->done, value, &mail->abort, timeout_cycles)) {
+            if (*info == 0) *info = -77;                   // "leaf server did not answer": reported as an engine error
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps) {
     constexpr size_t lds_v2 = (size_t)(128 * LP + SC_SIZE) * sizeof(double);
@@ -486,6 +565,30 @@ void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld
     else
         hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(1), dim3(LEAF_THREADS), lds_v3, s, A, Lout, S, ld, blk,
                            logdet_part, info, stamps);
+}
+
+size_t leaf_mail_bytes() { return sizeof(LeafMail); }
+
+static constexpr long long LEAF_TIMEOUT_CYCLES = 4000000000LL;   // ~1.7 s of shader clock: bounds every spin
+
+void launch_leaf_server(hipStream_t s, const double* A, double* Lout, double* S, int ld, int nblk, double* logdet_part,
+                        int* info, void* mail) {
+    constexpr size_t lds_v3 = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
+    static std::once_flag attr_once[MFGP_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(attr_once[dev & (MFGP_MAX_DEVICES - 1)], [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_server_f64),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v3);
+    });
+    hipLaunchKernelGGL(mfgp_leaf_server_f64, dim3(1), dim3(LEAF_THREADS), lds_v3, s, A, Lout, S, ld, nblk, logdet_part, info,
+                       static_cast<LeafMail*>(mail), LEAF_TIMEOUT_CYCLES);
+}
+
+void launch_leaf_post_wait(hipStream_t s, void* mail, int value, int* info) {
+    hipLaunchKernelGGL(mfgp_leaf_post, dim3(1), dim3(64), 0, s, static_cast<LeafMail*>(mail), value);
+    hipLaunchKernelGGL(mfgp_leaf_wait, dim3(1), dim3(64), 0, s, static_cast<LeafMail*>(mail), value, info,
+                       LEAF_TIMEOUT_CYCLES);
 }
 
 }  // namespace mfgp

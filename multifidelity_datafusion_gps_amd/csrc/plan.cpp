@@ -13,13 +13,12 @@ namespace mfgp {
 // planner
 // ------------------------------------------------------------------------------------------------
 static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group);
-static int g_t128_min = 300;
-static int pick_tile(int ntiles128) {
+static int pick_tile(const Plan& p, int ntiles128) {
     // 128-tiles run the MFMA pipe better, but a launch of few tiles is bound by its LONGEST tile (one tile per CU, 256
     // CUs): below ~300 tiles four times as many 64-tiles balance better (top inverse level at N = 4096: 2 x 330 -> 2 x 220 us).
     // With macro panels of K >= 768 (N >= 7168) a 128-tile lasts >= 130 us and the threshold moves to 600 (N = 8192: the
     // 364..448-tile column launches ran at 31 TFLOP/s as 128-tiles; whole evaluation 13.74 -> 13.36 ms).
-    return ntiles128 >= g_t128_min ? 128 : 64;
+    return ntiles128 >= p.t128_min ? 128 : 64;
 }
 
 static void add_gemm(Plan& p, std::vector<Step>& plan, int tile, int first, int a, int b, int c, int c2) {
@@ -45,7 +44,7 @@ static void plan_cholinv(Plan& p, int b0, int b1) {
     const int bm = b0 + (b1 - b0 + 1) / 2;
     plan_cholinv(p, b0, bm);
     const int n1 = bm - b0, n2 = b1 - bm;
-    const int T = pick_tile(n1 * n2);
+    const int T = pick_tile(p, n1 * n2);
     const int sc = NB / T;
     const int64_t k0 = (int64_t)b0 * NB, km = (int64_t)bm * NB;
     // L21 = A21 * X11^T      (A: A, B: S lower rows j, C: L)
@@ -70,7 +69,7 @@ static void plan_cholinv(Plan& p, int b0, int b1) {
     }
     // A22 -= L21 L21^T       (A: L, B: L, C: A), lower tiles only
     {
-        const int T2 = pick_tile(n2 * (n2 + 1) / 2);
+        const int T2 = pick_tile(p, n2 * (n2 + 1) / 2);
         const int s2 = NB / T2;
         const int first = (int)p.tasks.size();
         for (int i = bm * s2; i < b1 * s2; ++i)
@@ -213,7 +212,7 @@ static void plan_potrf_rl(Plan& p) {
             if (rem == 0) break;
             const int64_t kc = (int64_t)c * NB;
             {   // panel: L[i,c] = A[i,c] * X_cc^T
-                const int T = pick_tile(rem);
+                const int T = pick_tile(p, rem);
                 const int sc = NB / T;
                 const int first = (int)p.tasks.size();
                 for (int i = (c + 1) * sc; i < nb * sc; ++i)
@@ -246,7 +245,7 @@ static void plan_potrf_rl(Plan& p) {
         if (M1 >= nb) break;
         if (!lookahead) {
             const int r = nb - M1;
-            const int T = pick_tile(r * (r + 1) / 2);
+            const int T = pick_tile(p, r * (r + 1) / 2);
             const int first = (int)p.tasks.size();
             syrk_tasks(T, M1, nb, M0, M1);
             add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
@@ -260,7 +259,7 @@ static void plan_potrf_rl(Plan& p) {
             // columns (M1, M1+MB] in one launch (the next chain waits for its event once) and everything beyond in another
             const int lo = M1 + 1, hi = std::min(M1 + MB, nb - 1);
             if (lo <= hi) {
-                const int T = pick_tile(ntiles_cols(lo, hi + 1));
+                const int T = pick_tile(p, ntiles_cols(lo, hi + 1));
                 const int first = (int)p.tasks.size();
                 syrk_tasks(T, lo, hi + 1, M0, M1);
                 add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
@@ -273,7 +272,7 @@ static void plan_potrf_rl(Plan& p) {
                 for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
             }
             if (hi + 1 < nb) {
-                const int T = pick_tile(ntiles_cols(hi + 1, nb));
+                const int T = pick_tile(p, ntiles_cols(hi + 1, nb));
                 const int first = (int)p.tasks.size();
                 syrk_tasks(T, hi + 1, nb, M0, M1);
                 add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
@@ -286,7 +285,7 @@ static void plan_potrf_rl(Plan& p) {
             // the column that gates the next leaf stays on the MAIN stream: no event round trip on the chain.
             // It must still come after the previous macro's rest-update, which covers this column too and
             // runs on the bulk stream (normally long finished: the wait is on an already signalled event).
-            const int T = pick_tile(nb - M1);
+            const int T = pick_tile(p, nb - M1);
             const int first = (int)p.tasks.size();
             syrk_tasks(T, M1, M1 + 1, M0, M1);
             add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
@@ -300,11 +299,11 @@ static void plan_potrf_rl(Plan& p) {
             // the other block columns of the next macro panel: ONE launch on the bulk stream (each is needed one chain
             // step later than the previous; a launch per column left the GPU at ~140 workgroups three times in a row)
             const int cols = M2 - (M1 + 1);
-            const int T = merge_cols ? pick_tile(cols * (nb - M1 - 1)) : 64;
+            const int T = merge_cols ? pick_tile(p, cols * (nb - M1 - 1)) : 64;
             for (int c = M1 + 1; c < M2; c += merge_cols ? cols : 1) {
                 const int first = (int)p.tasks.size();
-                syrk_tasks(merge_cols ? T : pick_tile(nb - c), c, merge_cols ? M2 : c + 1, M0, M1);
-                add_gemm(p, p.steps, merge_cols ? T : pick_tile(nb - c), first, BUF_L, BUF_L, BUF_A, -1);
+                syrk_tasks(merge_cols ? T : pick_tile(p, nb - c), c, merge_cols ? M2 : c + 1, M0, M1);
+                add_gemm(p, p.steps, merge_cols ? T : pick_tile(p, nb - c), first, BUF_L, BUF_L, BUF_A, -1);
                 Step& st = p.steps.back();
                 st.strm = 1;
                 if (first_bulk) st.wait_ev = ev_chain;
@@ -315,7 +314,7 @@ static void plan_potrf_rl(Plan& p) {
             }
         }
         if (M2 < nb) {   // the rest of the trailing matrix: overlaps the next macro panel's chain
-            const int T = pick_tile(ntiles_cols(M2, nb));
+            const int T = pick_tile(p, ntiles_cols(M2, nb));
             const int first = (int)p.tasks.size();
             syrk_tasks(T, M2, nb, M0, M1);
             add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
@@ -347,7 +346,7 @@ static void plan_trtri_levels(Plan& p) {
         int ntiles = 0;
         for (const TriNode& n : nodes)
             if (n.level == lev) ntiles += (n.bm - n.b0) * (n.b1 - n.bm);
-        const int T = pick_tile(ntiles);
+        const int T = pick_tile(p, ntiles);
         const int sc = NB / T;
         {   // P^T[j][i] = sum_{k>=j} X11^T[j][k] L21[i][k]
             const int first = (int)p.tasks.size();
@@ -458,7 +457,7 @@ void plan_predv(Plan& p, int rows_p) {
     p.tasks.resize(p.n_fixed_tasks);   // drop the product planned for another panel height, keep everything else
     const int64_t ld = p.ld;
     const int nb = p.nblk, rb = rows_p / NB;
-    const int T = pick_tile(nb * rb);
+    const int T = pick_tile(p, nb * rb);
     const int sc = NB / T;
     const int first = (int)p.tasks.size();
     const int BI = 8, BR = 4, ni = nb * sc, nr = rb * sc;   // super-blocks: BI rows of X  x  BR panel rows
@@ -522,6 +521,12 @@ static void plan_sweep(Plan& p) {
     int chain_role = nb >= 24 ? 3 : 0;
     if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
     p.kinv_streamed = !(getenv("MFGP_KINV_STREAM") && atoi(getenv("MFGP_KINV_STREAM")) == 0);
+    // leaf server (leaf_f64.hip): measured and NOT used by default -- one evaluation alone: N = 4096 2.94 -> 2.81 ms, but
+    // N = 8192 13.1 -> 14.3 (the post / wait launches and two flag hand-offs per block column cost more than the dispatch wait
+    // they remove), and with several evaluations in flight a server workgroup can starve for a whole CU behind the other
+    // evaluations' bulk workgroups (its bounded spins then report an engine error instead of hanging)
+    p.leaf_server = false;
+    if (const char* e = getenv("MFGP_LEAF_SERVER")) p.leaf_server = atoi(e) != 0;
     bool bulk_xcd = true;   // deal the super-blocks of a bulk launch to the 8 XCDs (workgroup p runs on XCD p mod 8)
     if (const char* e = getenv("MFGP_BULK_XCD")) bulk_xcd = atoi(e) != 0;
     int bulk_every = 1;   // macro panels per bulk chunk of B / K^-1 (see "the rest" below; N = 8192, MB = 8: 14.1 / 14.6 ms at 1 / 2)
@@ -641,7 +646,7 @@ static void plan_sweep(Plan& p) {
             {   // panel(c): the column of L below the diagonal and the in-macro part of the column of X^T above it
                 const int rows = (nb - 1 - c) + (c - M0);
                 if (rows > 0) {
-                    const int T = pick_tile(rows);
+                    const int T = pick_tile(p, rows);
                     const int first = (int)p.tasks.size();
                     l_panel(T, c);
                     x_panel(T, c, c, M0, c);
@@ -665,7 +670,7 @@ static void plan_sweep(Plan& p) {
         if (!last && !shift) {
             // the column that gates the next leaf stays on the MAIN stream (no event round trip on the chain); it must
             // still follow the previous macro's last bulk launch, whose A-rest part covers this column too
-            const int T = pick_tile(nb - M1);
+            const int T = pick_tile(p, nb - M1);
             const int first = (int)p.tasks.size();
             a_update(T, M1, M1 + 1, M0, M1);
             Step* st = launch(T, first, 0, T == 64 ? chain_role : 0);
@@ -690,20 +695,20 @@ static void plan_sweep(Plan& p) {
                 }
             };
             if (merge_xpanel && have_cols && have_x) {
-                const int T = pick_tile(n_cols + n_x);
+                const int T = pick_tile(p, n_cols + n_x);
                 const int first = (int)p.tasks.size();
                 a_update(T, lo, hi + 1, M0, M1);
                 for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
                 cols_launch(T, first);
             } else {
                 if (have_cols) {
-                    const int T = pick_tile(n_cols);
+                    const int T = pick_tile(p, n_cols);
                     const int first = (int)p.tasks.size();
                     a_update(T, lo, hi + 1, M0, M1);
                     cols_launch(T, first);
                 }
                 if (have_x) {
-                    const int T = pick_tile(n_x);
+                    const int T = pick_tile(p, n_x);
                     const int first = (int)p.tasks.size();
                     for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
                     if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
@@ -722,7 +727,7 @@ static void plan_sweep(Plan& p) {
             const int n_a = a_lo < nb ? ntiles_cols(a_lo, nb) : 0;
             const int n_b = last ? 0 : M1 * ((chunk_now ? nb : M2) - M1);
             const int n_k = kinv_now ? M1 * (M1 + 1) / 2 : 0;
-            const int T = pick_tile(n_a + n_b + n_k);
+            const int T = pick_tile(p, n_a + n_b + n_k);
             auto by_length = [&](int first) {   // longest K first: the launch's tail is then made of its shortest tasks;
                 std::stable_sort(p.tasks.begin() + first, p.tasks.end(),     // super-blocks stay together within a K class
                                  [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
@@ -787,8 +792,8 @@ static void plan_sweep(Plan& p) {
 }
 
 void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride) {
-    g_t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : (nblk >= 56 ? 600 : 300);
     p = Plan{};
+    p.t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : (nblk >= 56 ? 600 : 300);
     p.nblk = nblk;
     p.ld = ld;
     p.stride = stride;
