@@ -64,6 +64,56 @@ def test_two_rank_fit_predict_over_socket_comm_equals_single_process(conc):
     assert out[0]["evals"] < ref["evals"] and out[1]["evals"] < ref["evals"]
 
 
+class _FakeEngine:
+    """stands in for _lib.Engine in attach_engine: RCCL 'works' (the gather is emulated through a shared list) or fails"""
+
+    def __init__(self, fail_on_rank=None, rank=0):
+        self.fail = fail_on_rank == rank
+        self.comm_size = 1
+
+    def comm_unique_id(self):
+        return bytes(128)
+
+    def comm_init(self, uid, rank, size):
+        assert len(uid) == 128
+        if self.fail:
+            raise RuntimeError("ncclCommInitRank: unhandled system error (test)")
+        self.comm_size = size
+
+
+def _attach_worker(rank, world, port, q, fail_on_rank):
+    from multifidelity_datafusion_gps_amd.sharding import SocketComm
+    comm = SocketComm(rank, world, "127.0.0.1", port, timeout=60)
+    try:
+        ok = comm.attach_engine(_FakeEngine(fail_on_rank, rank))
+        # a failure on ANY rank keeps EVERY rank on TCP (a half-attached job would hang in its first collective)
+        g = comm.allgather_rows(np.full((2, 2), float(rank))) if not ok else None
+        q.put((rank, (ok, comm.transport, getattr(comm, "rccl_error", None), None if g is None else g[:, 0].tolist())))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("fail_on_rank", [None, 1])
+def test_attach_engine_is_all_or_nothing(fail_on_rank):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_attach_worker, args=(r, 2, port, q, fail_on_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        ok, transport, err, rows = out[r]
+        if fail_on_rank is None:
+            assert ok and transport == "rccl"
+        else:
+            assert not ok and transport == "tcp" and "ncclCommInitRank" in err
+            assert rows == [0.0, 0.0, 1.0, 1.0]
+
+
 def test_comm_from_env_single_process_is_local(monkeypatch):
     from multifidelity_datafusion_gps_amd import sharding
     monkeypatch.delenv("WORLD_SIZE", raising=False)
