@@ -26,11 +26,6 @@ constexpr int LEAF_THREADS = 512;
 constexpr int SC_RED = 0;      // scratch: 8 partial sums
 constexpr int SC_SIZE = 16;
 
-// where the inverted diagonal factor Y_jj = L_jj^-1 (16x16, pitch LP) waits for phase 2: in a block ABOVE the diagonal
-// of the LDS matrix -- that half only holds the symmetric copy of the input and is never read -- so that the leaf
-// stays at 133 KB of LDS (a slim chain workgroup of another evaluation still fits on the CU beside it)
-__device__ __forceinline__ int y_offset(int jb) { return jb < 7 ? (jb * 16) * LP + (jb + 1) * 16 : 7 * 16; }
-
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -132,164 +127,6 @@ __device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb,
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + kb * 16 + fr] = acc[r];
-}
-
-__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_v2_f64(const double* __restrict__ A,
-                                                                         double* Lout, double* S, int ld, int blk,
-                                                                         double* logdet_part, int* info,
-                                                                         unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sL = smem;             // 128 x LP
-    double* sc = smem + 128 * LP;  // scratch
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int fr = lane & 15;
-    const int q = lane >> 4;
-    const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;  // offset of the diagonal block
-#define STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-    STAMP(0);
-
-    // ---- load (16 B per lane, whole rows coalesced) ------------------------------------------------
-    {
-        constexpr int NLD = NB * NB / 2 / LEAF_THREADS;  // 16 loads in flight per thread before the first LDS store
-        d2_t v[NLD];
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = tid + u * LEAF_THREADS;
-            const int row = e >> 6, c2 = e & 63;
-            v[u] = *reinterpret_cast<const d2_t*>(A + g0 + (int64_t)row * ld + 2 * c2);
-        }
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = tid + u * LEAF_THREADS;
-            const int row = e >> 6, c2 = e & 63;
-            *reinterpret_cast<d2_t*>(sL + row * LP + 2 * c2) = v[u];
-        }
-    }
-    __syncthreads();
-
-    STAMP(1);
-    // ---- phase 1: blocked Cholesky with look-ahead ---------------------------------------------------
-    if (wave == 0) micro_chol16(sL, sL + y_offset(0), lane, info, blk * NB);
-    __syncthreads();
-    STAMP(2);
-    for (int jb = 0; jb < 8; ++jb) {
-        const int base = jb * 16;
-        // rows below the diagonal block: x L_jj^T = a, as the product with the inverted diagonal factor (one block per wave)
-        for (int ib = jb + 1 + wave; ib < 8; ib += 8) solve_block(sL, sL + y_offset(jb), ib, jb, fr, q);
-        __syncthreads();
-        if (jb == 0) STAMP(3);
-        if (jb == 7) break;
-        // priority: block column jb+1 gets panel jb's update first (one block per wave)
-        {
-            const int ib = jb + 1 + wave;
-            if (ib < 8) update_block(sL, ib, jb + 1, jb, fr, q);
-        }
-        __syncthreads();
-        if (jb == 0) STAMP(4);
-        // wave 0 factorises the next diagonal block while waves 1-7 finish the trailing update
-        if (wave == 0) {
-            micro_chol16(sL + (base + 16) * LP + base + 16, sL + y_offset(jb + 1), lane, info,
-                         blk * NB + base + 16);
-        } else {
-            const int m = 6 - jb;  // block columns jb+2 .. 7
-            const int nblk = m * (m + 1) / 2;
-            for (int idx = wave - 1; idx < nblk; idx += 7) {
-                int ii = 0, rem = idx;
-                while (rem > ii) { rem -= ii + 1; ++ii; }
-                update_block(sL, jb + 2 + ii, jb + 2 + rem, jb, fr, q);
-            }
-        }
-        __syncthreads();
-        if (jb == 0) STAMP(5);
-    }
-    STAMP(6);
-
-    // ---- write L (zeros above the diagonal) and the half log-determinant ------------------------------
-    for (int e = tid; e < NB * NB / 2; e += LEAF_THREADS) {
-        const int row = e >> 6, c2 = e & 63;
-        d2_t v = *reinterpret_cast<const d2_t*>(sL + row * LP + 2 * c2);
-        if (2 * c2 > row) v.x = 0.0;
-        if (2 * c2 + 1 > row) v.y = 0.0;
-        *reinterpret_cast<d2_t*>(Lout + g0 + (int64_t)row * ld + 2 * c2) = v;
-    }
-    {
-        double v = (tid < NB) ? log(sL[tid * LP + tid]) : 0.0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sc[SC_RED + wave] = v;
-        __syncthreads();
-        if (tid == 0) logdet_part[blk] = sc[SC_RED] + sc[SC_RED + 1];  // rows live in waves 0 and 1
-    }
-
-    STAMP(7);
-    // ---- phase 2: in-place inverse ---------------------------------------------------------------------
-    // (a) the eight 16x16 diagonal inverses were produced with the factors: copy them over the diagonal blocks
-    for (int e = tid; e < 8 * 256; e += LEAF_THREADS) {
-        const int b = e >> 8, i = (e >> 4) & 15, k = e & 15;
-        sL[(b * 16 + i) * LP + b * 16 + k] = sL[y_offset(b) + i * LP + k];
-    }
-    __syncthreads();
-    STAMP(8);
-    // (b) recursive assembly X21 = -X22 (L21 X11) over node half-sizes hs = 1, 2, 4 blocks; all nodes of a
-    //     level are independent; one or two 16x16 outputs per wave, accumulated in registers (the products
-    //     read blocks that other waves overwrite, so each half-step is compute | barrier | write | barrier)
-    for (int hs = 1; hs <= 4; hs <<= 1) {
-        const int nout = 4 * hs;  // (8 / (2 hs)) nodes x hs^2 outputs
-        for (int half = 0; half < 2; ++half) {
-            d4_t acc[2];
-            int oi[2], oj[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                acc[u] = (d4_t){0.0, 0.0, 0.0, 0.0};
-                const int o = wave + 8 * u;
-                oi[u] = -1;
-                oj[u] = 0;
-                if (o < nout) {
-                    const int node = o / (hs * hs), w = o % (hs * hs);
-                    const int b0 = 2 * hs * node;
-                    const int i = b0 + hs + w / hs, j = b0 + w % hs;
-                    oi[u] = i;
-                    oj[u] = j;
-                    // half 0: T[i][j]   = sum_{k=j}^{b0+hs-1} L[i][k] X[k][j]
-                    // half 1: X21[i][j] = - sum_{k=b0+hs}^{i} X[i][k] T[k][j]
-                    const int k0 = half == 0 ? j : b0 + hs;
-                    const int k1 = half == 0 ? b0 + hs - 1 : i;
-                    for (int k = k0; k <= k1; ++k) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            double a = sL[(i * 16 + fr) * LP + k * 16 + 4 * s4 + q];
-                            const double b = sL[(k * 16 + 4 * s4 + q) * LP + j * 16 + fr];
-                            if (half == 1) a = -a;
-                            acc[u] = mfma(a, b, acc[u]);
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (oi[u] >= 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sL[(oi[u] * 16 + q + 4 * r) * LP + oj[u] * 16 + fr] = acc[u][r];
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    STAMP(9);
-    // ---- write X mirrored: S[r][c] = X[max(r,c)][min(r,c)] -------------------------------------------
-    for (int e = tid; e < NB * NB; e += LEAF_THREADS) {
-        const int row = e >> 7, col = e & 127;
-        const int hi = row > col ? row : col, lo = row > col ? col : row;
-        S[g0 + (int64_t)row * ld + col] = sL[hi * LP + lo];
-    }
-    __syncthreads();
-    STAMP(10);
-#undef STAMP
 }
 
 // ---- leaf v3: the inverse rides on the factorisation --------------------------------------------------------------------
@@ -473,122 +310,18 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     leaf_body_v3(smem, A, Lout, S, ld, blk, logdet_part, info, stamps);
 }
 
-// ---- leaf server ---------------------------------------------------------------------------------------------------------
-// A single-workgroup kernel that needs a whole CU (151 KB of LDS) is dispatched only when ONE specific bulk workgroup
-// retires: beside K = 512 tile tasks (86 us each) the leaf waits 10-16 us per block column, beside K >= 1024 ones 75 us --
-// which is what kept the macro panels short and the bulk GEMMs below their long-K rate.  The server is ONE persistent
-// workgroup per evaluation: it takes its CU once, at the start, and then factorises the diagonal blocks 0 .. nb-1 as they
-// are announced through a mailbox in device memory, so a leaf starts the moment its input is ready.
-//   main stream:  ... inner(c-1) | mfgp_leaf_post(req = c+1) | mfgp_leaf_wait(done >= c+1) | panel(c) ...
-//   server     :  poll req >= c+1 -> acquire -> leaf(c) -> every wave drains its stores -> barrier -> release -> done = c+1
-// Hand-off protocol of /opt/skills/guides (inter-workgroup visibility): relaxed agent-scope polls with s_sleep, ONE agent
-// acquire after the match, plain loads; producer stores -> s_waitcnt vmcnt(0) in every wave -> barrier -> lane-0 agent
-// release -> s_waitcnt vmcnt(0) -> relaxed agent flag store.  Every spin is bounded (timeout -> abort flag -> everybody exits
-// and the host reports an error): the grid always drains.
-struct LeafMail {
-    int req;   int pad0[31];    // blocks announced (written by mfgp_leaf_post)
-    int done;  int pad1[31];    // blocks finished  (written by the server)
-    int abort; int pad2[31];    // set by whoever times out; everybody exits
-};
-
-__device__ __forceinline__ bool mail_wait(int* flag, int want, int* abort_flag, long long timeout_cycles) {
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if ((long long)__builtin_amdgcn_s_memtime() - t0 > timeout_cycles) {
-            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(4);
-    }
-    return true;
-}
-
-__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_server_f64(const double* A, double* Lout, double* S, int ld,
-                                                                        int nblk, double* logdet_part, int* info,
-                                                                        LeafMail* mail, long long timeout_cycles) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int go;
-    for (int blk = 0; blk < nblk; ++blk) {
-        if (threadIdx.x == 0) {
-            go = mail_wait(&mail->req, blk + 1, &mail->abort, timeout_cycles) ? 1 : 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (!go) return;                                   // aborted / timed out: leave (the host sees the abort flag)
-        leaf_body_v3(smem, A, Lout, S, ld, blk, logdet_part, info, nullptr);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores of L_cc / X_cc have left
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&mail->done, blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-__global__ void mfgp_leaf_post(LeafMail* mail, int value) {
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (the previous kernels' results are visible at the kernel boundary)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&mail->req, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__global__ void mfgp_leaf_wait(LeafMail* mail, int value, int* info, long long timeout_cycles) {
-    if (threadIdx.x == 0) {
-        if (!mail_wait(&mail->done, value, &mail->abort, timeout_cycles)) {
-            if (*info == 0) *info = -77;                   // "leaf server did not answer": reported as an engine error
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-}
-
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps) {
-    constexpr size_t lds_v2 = (size_t)(128 * LP + SC_SIZE) * sizeof(double);
-    constexpr size_t lds_v3 = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
-    static const bool v2 = getenv("MFGP_LEAF") && atoi(getenv("MFGP_LEAF")) == 2;   // A/B: the two-phase leaf
+    constexpr size_t lds = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
     static std::once_flag attr_once[MFGP_MAX_DEVICES];   // per device, thread-safe (see launch_gemm)
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(attr_once[dev & (MFGP_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_cholinv_v2_f64),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_cholinv_f64),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v3);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
-    if (v2)
-        hipLaunchKernelGGL(mfgp_leaf_cholinv_v2_f64, dim3(1), dim3(LEAF_THREADS), lds_v2, s, A, Lout, S, ld, blk,
-                           logdet_part, info, stamps);
-    else
-        hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(1), dim3(LEAF_THREADS), lds_v3, s, A, Lout, S, ld, blk,
-                           logdet_part, info, stamps);
-}
-
-size_t leaf_mail_bytes() { return sizeof(LeafMail); }
-
-static constexpr long long LEAF_TIMEOUT_CYCLES = 4000000000LL;   // ~1.7 s of shader clock: bounds every spin
-
-void launch_leaf_server(hipStream_t s, const double* A, double* Lout, double* S, int ld, int nblk, double* logdet_part,
-                        int* info, void* mail) {
-    constexpr size_t lds_v3 = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
-    static std::once_flag attr_once[MFGP_MAX_DEVICES];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::call_once(attr_once[dev & (MFGP_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_server_f64),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v3);
-    });
-    hipLaunchKernelGGL(mfgp_leaf_server_f64, dim3(1), dim3(LEAF_THREADS), lds_v3, s, A, Lout, S, ld, nblk, logdet_part, info,
-                       static_cast<LeafMail*>(mail), LEAF_TIMEOUT_CYCLES);
-}
-
-void launch_leaf_post_wait(hipStream_t s, void* mail, int value, int* info) {
-    hipLaunchKernelGGL(mfgp_leaf_post, dim3(1), dim3(64), 0, s, static_cast<LeafMail*>(mail), value);
-    hipLaunchKernelGGL(mfgp_leaf_wait, dim3(1), dim3(64), 0, s, static_cast<LeafMail*>(mail), value, info,
-                       LEAF_TIMEOUT_CYCLES);
+    hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(1), dim3(LEAF_THREADS), lds, s, A, Lout, S, ld, blk, logdet_part, info,
+                       stamps);
 }
 
 }  // namespace mfgp

@@ -39,8 +39,7 @@ static void run_step(mfgp_handle* h, const Step& s, bool want_grad = true) {
     hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
     if (s.wait_ev > 0) (void)hipStreamWaitEvent(st, h->evpool[s.wait_ev - 1], 0);
     if (s.kind == 0) {
-        if (h->leaf_server) launch_leaf_post_wait(st, h->dmail, s.blk + 1, h->dinfo);   // the resident server does block s.blk
-        else launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
+        launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
         h->launches++;
     } else if (s.kind == 1) {
         // a launch that carries a chunk of the K^-1 accumulation has a second task list for gradient evaluations
@@ -116,9 +115,6 @@ static int create_body(mfgp_handle* h, int device_id) {
             HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         }
     }
-    HIPCHK(h, hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
-    HIPCHK(h, hipMalloc(&h->dmail, leaf_mail_bytes()));
-    HIPCHK(h, hipMemset(h->dmail, 0, leaf_mail_bytes()));
     for (auto& ev : h->ev) HIPCHK(h, hipEventCreate(&ev));
     // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
     // pinned, device-mapped host memory: no copy kernel at the end of a call and no fill kernel for the status at its
@@ -153,7 +149,6 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->stream3) hipStreamSynchronize(h->stream3);
     free_mats(h);
     if (h->dXs) hipFree(h->dXs);
     if (h->dXc) hipFree(h->dXc);
@@ -166,8 +161,6 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->hres) hipHostFree(h->hres);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
-    if (h->dmail) hipFree(h->dmail);
-    if (h->stream3) hipStreamDestroy(h->stream3);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -176,9 +169,6 @@ int32_t mfgp_destroy(mfgp_handle* h) {
 
 static int build_plans(mfgp_handle* h) {
     build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap);
-    // bulk-bound sizes: the leaves run on a resident server workgroup (leaf_f64.hip) -- long-K bulk tasks would make a freshly
-    // dispatched leaf wait ~75 us for a CU; below, the two tiny post / wait launches per block column cost more than the wait
-    h->leaf_server = h->pl.leaf_server;
     while ((int)h->evpool.size() < h->pl.n_events) {
         hipEvent_t e;
         HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -303,16 +293,6 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     const bool stages = h->stage_timing;   // an event record costs 6-8 us of stream time: per-stage stamps only where that is noise
     if (stages) HIPCHK(h, hipEventRecord(h->ev[1], s));
     const bool stream_kinv = want_grad && h->pl.kinv_streamed;
-    if (h->leaf_server) {
-        // the mailbox is cleared in stream order BEFORE the K build (the previous evaluation's server has exited: both streams
-        // were synchronised at its end); the server takes its CU now and waits for block 0 to be announced
-        HIPCHK(h, hipMemsetAsync(h->dmail, 0, leaf_mail_bytes(), s));
-        HIPCHK(h, hipEventRecord(h->ev[9], s));
-        HIPCHK(h, hipStreamWaitEvent(h->stream3, h->ev[9], 0));
-        launch_leaf_server(h->stream3, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, h->nblk, h->dlogdet, h->dinfo,
-                           h->dmail);
-        h->launches++;
-    }
     for (const Step& st : h->pl.steps) run_step(h, st, stream_kinv);
     if (stages) HIPCHK(h, hipEventRecord(h->ev[2], s));
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dY, h->dz, (int)h->Np, (int)h->Np, 0);       // z = X y
@@ -334,7 +314,6 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
 
 static int finish_eval(mfgp_handle* h, bool want_grad) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->leaf_server) HIPCHK(h, hipStreamSynchronize(h->stream3));   // (the server left after its last block)
     HIPCHK(h, hipGetLastError());
     mfgp_timings& t = h->tm;
     memset(&t, 0, sizeof t);
@@ -373,10 +352,6 @@ static int finish_eval(mfgp_handle* h, bool want_grad) {
     if (want_grad)
         for (int i = 0; i < 2 * h->spec.nf + 1; ++i) h->grad[i] = h->hres[2 + i];
     const int info = *h->hinfo;
-    if (info == -77) {
-        h->factorized = h->kinv_valid = h->grad_valid = false;
-        return fail(h, -5, "leaf server timed out (internal error: a diagonal block was never announced or never finished)");
-    }
     if (info != 0) {
         h->factorized = false;
         h->kinv_valid = h->grad_valid = false;
@@ -886,8 +861,8 @@ int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xou
         HIPCHK(h, hipMemcpy(st, dst, sizeof st, hipMemcpyDeviceToHost));
         hipFree(dst);
         if (getenv("MFGP_LEAF_STAMPS")) {
-            static const char* names[] = {"load", "micro0", "trsm0", "prio0", "micro1||update0", "rest of phase1",
-                                          "writeL+logdet", "diag inverses", "phase2 columns", "write S"};
+            static const char* names[] = {"first tile load", "micro0 || block load", "solve0", "prio0",
+                                          "micro1 || update0 + output0", "panels 1-7", "output7 + logdet", "-", "-", "drain"};
             fprintf(stderr, "leaf stamps (shader cycles):");
             for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%llu", names[i], st[i + 1] - st[i]);
             fprintf(stderr, " total=%llu\n", st[10] - st[0]);

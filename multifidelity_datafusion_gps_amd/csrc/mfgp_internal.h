@@ -47,14 +47,6 @@ void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const doubl
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps = nullptr);
 
-// leaf server (leaf_f64.hip): one persistent workgroup per evaluation factorises the diagonal blocks 0 .. nblk-1 as the main
-// stream announces them through `mail` (leaf_mail_bytes() of zeroed device memory); post_wait = announce block value-1 and
-// hold the stream until it is done
-size_t leaf_mail_bytes();
-void launch_leaf_server(hipStream_t s, const double* A, double* Lout, double* S, int ld, int nblk, double* logdet_part,
-                        int* info, void* mail);
-void launch_leaf_post_wait(hipStream_t s, void* mail, int value, int* info);
-
 // covariance builders
 //   tri: lower-triangle 64x64 tiles of Ky = K + (noise+jitter) I over padded Np (identity padding)
 void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X,
@@ -135,9 +127,6 @@ struct mfgp_handle {
     mfgp_timings tm{};
     mfgp_counters cum{};
     int64_t launches = 0;
-    hipStream_t stream3 = nullptr;       // the leaf server's stream
-    void* dmail = nullptr;               // its mailbox (device memory)
-    bool leaf_server = false;            // this plan's leaves run on the server (bulk-bound sizes)
     // multi-GPU (comm_rccl.hip): one RCCL communicator per handle, created by mfgp_comm_init; opaque here
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 1;

@@ -521,12 +521,6 @@ static void plan_sweep(Plan& p) {
     int chain_role = nb >= 24 ? 3 : 0;
     if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
     p.kinv_streamed = !(getenv("MFGP_KINV_STREAM") && atoi(getenv("MFGP_KINV_STREAM")) == 0);
-    // leaf server (leaf_f64.hip): measured and NOT used by default -- one evaluation alone: N = 4096 2.94 -> 2.81 ms, but
-    // N = 8192 13.1 -> 14.3 (the post / wait launches and two flag hand-offs per block column cost more than the dispatch wait
-    // they remove), and with several evaluations in flight a server workgroup can starve for a whole CU behind the other
-    // evaluations' bulk workgroups (its bounded spins then report an engine error instead of hanging)
-    p.leaf_server = false;
-    if (const char* e = getenv("MFGP_LEAF_SERVER")) p.leaf_server = atoi(e) != 0;
     bool bulk_xcd = true;   // deal the super-blocks of a bulk launch to the 8 XCDs (workgroup p runs on XCD p mod 8)
     if (const char* e = getenv("MFGP_BULK_XCD")) bulk_xcd = atoi(e) != 0;
     int bulk_every = 1;   // macro panels per bulk chunk of B / K^-1 (see "the rest" below; N = 8192, MB = 8: 14.1 / 14.6 ms at 1 / 2)

@@ -66,7 +66,6 @@ struct Plan {
     int n_events = 0;               // events the steps refer to (1-based ids 1..n_events)
     int t128_min = 300;             // tiles per launch from which 128-tiles are used (64-tiles below)
     bool kinv_streamed = false;     // the steps accumulate K^-1 behind the chain
-    bool leaf_server = false;       // leaves are announced to a resident server workgroup instead of launched one by one
 };
 
 // environment-selected planner variants (read once per plan; defaults = the measured best, DESIGN.md "Planner switches")
