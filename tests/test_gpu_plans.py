@@ -1,0 +1,57 @@
+"""Every planner variant on the GPU against the oracle (the CPU plan checker of tests/test_plan_host.py proves the plans
+race-free and exact in exact-ish arithmetic; this runs the same switches through the real kernels).  The planner reads its
+switches from the environment when a handle plans, i.e. at the first mfgp_set_data of a fresh handle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as orc
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [{}, {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "recursive"}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"},
+            {"MFGP_KINV_STREAM": "0"}, {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2", "MFGP_XPANEL_MERGE": "1"},
+            {"MFGP_CHAIN_SLIM": "1", "MFGP_T128_MIN": "8"}, {"MFGP_BULK_XCD": "0", "MFGP_BULK_BI": "2", "MFGP_BULK_BJ": "3"}]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_planner_variant_matches_oracle(engine_cls, env):
+    rng = np.random.default_rng(19)
+    N = 1500                                                   # 12 leaf blocks: 3 macro panels of 4, 6 of 2
+    X = rng.uniform(size=(N, 4))
+    Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    st = orc.inference(parts, theta, noise, Xa, Y)
+    Xs = rng.uniform(size=(100, 4))
+    Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
+    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = engine_cls(0)
+        e.set_data(Xa, Y)                                       # plans here, under the variant's switches
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    e.set_kernel(parts)
+    nlml, grad = e.eval(theta, noise, 1e-8)
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    Kinv = e.get_Kinv()
+    assert np.abs(Kinv - st["Kinv"]).max() <= 1e-9 * np.abs(st["Kinv"]).max()
+    mean, v = e.predict(Xsa)
+    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
+    # the gradient-free factorisation + the lazy gradient (stand-alone K^-1 launch) give the same numbers
+    e.factorize(theta, noise, 1e-8)
+    assert e.nlml() == pytest.approx(st["nlml"], rel=1e-10)
+    np.testing.assert_allclose(e.nlml_grad(), st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    nlml2, grad2 = e.eval(theta, noise, 1e-8)
+    assert nlml2 == nlml and np.array_equal(grad2, grad)        # deterministic
+    e.close()
