@@ -511,8 +511,9 @@ static void plan_sweep(Plan& p) {
     // block columns per macro panel = K / 128 of the bulk trailing update.  Chain-bound sizes: 4 (a short in-macro chain);
     // bulk-bound sizes: the longer K runs the matrix pipe better, but a 128-tile of K = 1024 holds its CU for 170 us and
     // the leaf (which needs a whole CU) waits for one to retire (one evaluation alone, N = 6144: 6.66 / 6.91 / 7.37 ms at
-    // 4 / 6 / 8; N = 8192: 13.94 / 13.69 / 13.74 at 4 / 6 / 8; N = 16384: 96.8 / 94.1 / 93.1 ms at 8 / 12 / 16)
-    int MB = nb >= 96 ? 16 : (nb >= 56 ? 6 : 4);
+    // 4 / 6 / 8; N = 8192: 13.9 / 13.2 / 13.05 at 4 / 6 / 8 and, with three evaluations in flight (bench.py), 2074 / 2011 / 1999 /
+    // 2049 ms per fit+predict at 4 / 6 / 8 / 12; N = 16384: 96.8 / 94.1 / 93.1 ms at 8 / 12 / 16)
+    int MB = nb >= 96 ? 16 : (nb >= 56 ? 8 : 4);
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
