@@ -322,6 +322,9 @@ def main():
         engines["hf"].comm_destroy()      # every rank still alive: destroy the communicator before anyone exits
         comm.barrier()
     comm.close()
+    if "did not return" in str(getattr(comm, "rccl_error", "")):
+        sys.stdout.flush()
+        os._exit(0)       # an RCCL initialisation is still stuck in its watchdog thread: do not wait for it at interpreter exit
 
 
 if __name__ == "__main__":

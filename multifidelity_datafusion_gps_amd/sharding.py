@@ -137,9 +137,13 @@ class SocketComm:
     def barrier(self):
         self.allgather_object(None)
 
-    def attach_engine(self, engine):
+    def attach_engine(self, engine, init_timeout=120.0):
         """collective: create the RCCL communicator inside `engine`'s handle (unique id from rank 0 over TCP); from then
-        on the row gathers run as ncclAllGather on that engine's stream.  On failure every rank stays on TCP."""
+        on the row gathers run as ncclAllGather on that engine's stream.  All or nothing: if the initialisation fails --
+        or does not return within `init_timeout` seconds -- on ANY rank, every rank stays on TCP (a half-attached job
+        would hang in its first collective).  Only the ncclCommInitRank call itself runs under the watchdog; every TCP
+        exchange stays on the calling thread."""
+        import threading
         uid = None
         err = None
         if self.rank == 0:
@@ -149,10 +153,22 @@ class SocketComm:
                 err = repr(e)
         uid, err = self.bcast_object((uid, err))
         if uid is not None:
-            try:
-                engine.comm_init(uid, self.rank, self.size)
-            except Exception as e:  # noqa: BLE001
-                err = repr(e)
+            box = {}
+
+            def init():
+                try:
+                    engine.comm_init(uid, self.rank, self.size)
+                    box["ok"] = True
+                except Exception as e:  # noqa: BLE001
+                    box["err"] = repr(e)
+
+            t = threading.Thread(target=init, daemon=True)   # daemon: a hung initialisation must not keep the process alive
+            t.start()
+            t.join(init_timeout)
+            if t.is_alive():
+                err = "ncclCommInitRank did not return within %.0f s on rank %d" % (init_timeout, self.rank)
+            elif "err" in box:
+                err = box["err"]
         errs = [e for e in self.allgather_object(err) if e]
         if errs:
             self.rccl_error = errs[0]
