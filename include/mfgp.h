@@ -185,7 +185,7 @@ int32_t mfgp_device_synchronize(mfgp_handle* h);
 
 /* ---- kernel-level test hooks (tests/ only) -------------------------------------------------------- */
 /* C = alpha * A B^T + beta * C on Mp x Np x Kp host matrices (multiples of 128) through the MFMA
- * tile-GEMM kernel; tile = 128 or 64, or -64 for the serial-chain variant of the 64-tile kernel. */
+ * tile-GEMM kernel; tile = 128 or 64, -64 for the serial-chain variant of the 64-tile kernel, 32 for the 32x32 chain kernel. */
 int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, double* C, int32_t M,
                          int32_t N, int32_t K, double alpha, double beta, int32_t tile);
 /* Cholesky + inverse of one SPD 128x128 block through the leaf kernel: Lout, Xout are 128x128. */

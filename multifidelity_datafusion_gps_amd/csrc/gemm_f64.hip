@@ -210,6 +210,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_chain(const 
     __builtin_amdgcn_s_setprio(3);
     gemm_nt_tile<64, 64, GW_M, GW_N, 1, 16>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
+// 32x32 chain variant: 4 waves (2 x 2, one MFMA block each), 16 KB of LDS, K-steps of 32 -- the chain's panel / in-macro update
+// launches at chain-bound sizes (planner: MFGP_CHAIN_TILE).  Those launches are latency-bound (a 64x64x128 tile is 128 MFMAs
+// per SIMD behind eight serial K-steps); as 32x32 tiles the same work spreads over four times as many workgroups and four
+// K-steps: panel launch 12 -> 9.5 us, in-macro update 13-20 -> 10-17 us (N = 4096), one evaluation at N = 2048 1.20 -> 1.03 ms.
+// (Measured beside it: K-steps of 16, single- and double-buffered: 1.07 / 1.08 ms.)
+__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64_chain32(const GemmTask* __restrict__ tasks, const double* A,
+                                                          const double* B, double* C, double* C2, int ld) {
+    __builtin_amdgcn_s_setprio(3);
+    gemm_nt_tile<32, 32, 2, 2, 1, 32>(tasks[blockIdx.x], A, B, C, C2, ld);
+}
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_kinv_syrk_f64(const GemmTask* __restrict__ tasks, const double* A,
                                                              const double* B, double* C, double* C2, int ld) {
     gemm_nt_tile<128, 128, GW_M, GW_N>(tasks[blockIdx.x], A, B, C, C2, ld);
@@ -249,6 +259,11 @@ void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, con
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)gemm_lds_bytes(t == 0 ? 128 : 64));
     });
+    if (tile == 32) {                // chain step at chain-bound sizes: 32x32 tiles, 4 waves, 16 KB
+        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain32, dim3(ntasks), dim3(256), (size_t)(32 + 32) * 32 * sizeof(double), s, tasks, A, B,
+                           C, C2, ld);
+        return;
+    }
     if (role == 3 && tile == 64) {   // serial-chain step: slim workgroups that co-reside with the bulk update
         hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain, dim3(ntasks), dim3(GEMM_THREADS), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
                            C, C2, ld);

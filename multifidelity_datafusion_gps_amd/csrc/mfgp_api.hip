@@ -807,8 +807,8 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
     if (!h || !A || !B || !C) return fail(h, -1, "mfgp_dbg_gemm_nt: NULL");
     const bool chain = (tile == -64);   // -64: the serial-chain variant of the 64-tile kernel (mfgp_gemm_nt_f64_chain)
     if (chain) tile = 64;
-    if ((tile != 128 && tile != 64) || M % tile || N % tile || K % BK || K < BK)
-        return fail(h, -1, "mfgp_dbg_gemm_nt: M, N must be multiples of the tile and K of 32");
+    if ((tile != 128 && tile != 64 && tile != 32) || M % tile || N % tile || K % BK || K < BK)
+        return fail(h, -1, "mfgp_dbg_gemm_nt: M, N must be multiples of the tile (128, 64, 32) and K of 32");
     HIPCHK(h, hipSetDevice(h->device));
     // one common leading dimension
     const int ld = std::max(K, N);

@@ -521,6 +521,13 @@ static void plan_sweep(Plan& p) {
     // retire (N = 4096: 3.27 -> 3.03 ms).  Below ~24 blocks the bulk launches are 64-tiles themselves: no difference.
     int chain_role = nb >= 24 ? 3 : 0;
     if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
+    // tile edge of the chain's own launches (panel, inner).  They are latency-bound: a 64x64x128 tile is 128 dependent-ish
+    // MFMAs per SIMD (5.3 us) behind 8 serial K-steps; as 32x32 tiles (4 waves, 16 KB of LDS, four times the workgroups, four
+    // K-steps) the same work spreads over four times as many SIMDs (N = 1024 0.60 -> 0.53 ms, 2048 1.20 -> 1.03, 4096 2.93 -> 2.80).  Chain-bound sizes only: at N >= 6144 the chain hides behind the
+    // bulk stream and fewer, larger workgroups disturb it less.
+    int CT = nb < 48 ? 32 : 64;
+    if (const char* e = getenv("MFGP_CHAIN_TILE")) CT = atoi(e) == 32 ? 32 : 64;
+    const int chain_role_ct = CT == 32 ? 5 : chain_role;
     p.kinv_streamed = !(getenv("MFGP_KINV_STREAM") && atoi(getenv("MFGP_KINV_STREAM")) == 0);
     bool bulk_xcd = true;   // deal the super-blocks of a bulk launch to the 8 XCDs (workgroup p runs on XCD p mod 8)
     if (const char* e = getenv("MFGP_BULK_XCD")) bulk_xcd = atoi(e) != 0;
@@ -641,19 +648,19 @@ static void plan_sweep(Plan& p) {
             {   // panel(c): the column of L below the diagonal and the in-macro part of the column of X^T above it
                 const int rows = (nb - 1 - c) + (c - M0);
                 if (rows > 0) {
-                    const int T = pick_tile(p, rows);
+                    const int T = pick_tile(p, rows) == 128 ? 128 : CT;
                     const int first = (int)p.tasks.size();
                     l_panel(T, c);
                     x_panel(T, c, c, M0, c);
-                    launch(T, first, 0, T == 64 ? chain_role : 0);
+                    launch(T, first, 0, T == 128 ? 0 : chain_role_ct);
                 }
             }
             {   // inner(c): right-looking K = 128 updates inside the macro (A: also the next macro's first column if `shift`)
                 const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
                 const int first = (int)p.tasks.size();
-                if (c + 1 < inner_hi) a_update(64, c + 1, inner_hi, c, c + 1);
-                if (c + 1 < M1) b_update(64, M0, c + 1, c + 1, M1, c, c + 1);
-                Step* st = launch(64, first, 0, chain_role);
+                if (c + 1 < inner_hi) a_update(CT, c + 1, inner_hi, c, c + 1);
+                if (c + 1 < M1) b_update(CT, M0, c + 1, c + 1, M1, c, c + 1);
+                Step* st = launch(CT, first, 0, chain_role_ct);
                 if (st)   // the columns it touches were last written by the previous macro's bulk launches
                     for (int j = c + 1; j < inner_hi; ++j) main_wait(*st, ev_col[j]);
             }

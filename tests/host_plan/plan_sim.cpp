@@ -7,7 +7,7 @@
 //       the K build does not write -- so any read of data that no earlier step produced poisons the result --
 //       and checks  L L^T = A,  X L = I,  S mirrored,  K^-1 = X^T X;
 //   (2) checks the two-stream schedule for DATA RACES: every pair of conflicting accesses (write/write, write/read) to
-//       the same 64x64 cell of the same matrix must be ordered by stream order or by an event recorded before it is
+//       the same 32x32 cell of the same matrix must be ordered by stream order or by an event recorded before it is
 //       waited for (vector clocks over the two streams); tasks of one launch run concurrently and must not conflict.
 #include <math.h>
 #include <stdint.h>
@@ -22,6 +22,8 @@
 using namespace mfgp;
 
 namespace {
+
+constexpr int CELL = 32;   // granularity of the race check = the smallest tile edge the planner emits
 
 struct Clock { int t[2]; };
 
@@ -48,7 +50,7 @@ struct Sim {
     Cell& cell(int64_t off) {
         const int buf = (int)(off / stride);
         const int64_t r = (off % stride) / ld, c = off % ld;
-        return cells[(size_t)buf * cpr * cpr + (size_t)(r / 64) * cpr + (size_t)(c / 64)];
+        return cells[(size_t)buf * cpr * cpr + (size_t)(r / CELL) * cpr + (size_t)(c / CELL)];
     }
     void report(const char* kind, int64_t off, int s0, int t0, int s1, int t1) {
         ++races;
@@ -56,7 +58,7 @@ struct Sim {
             char tmp[256];
             const int buf = (int)(off / stride);
             snprintf(tmp, sizeof tmp, "%s on matrix %d cell (%lld,%lld): step %d task %d vs step %d task %d", kind, buf,
-                     (long long)((off % stride) / ld / 64), (long long)(off % ld / 64), s0, t0, s1, t1);
+                     (long long)((off % stride) / ld / CELL), (long long)(off % ld / CELL), s0, t0, s1, t1);
             first_race = tmp;
         }
     }
@@ -82,9 +84,9 @@ struct Sim {
     }
 };
 
-// operand window of a task: rows [0,T), k in [0,klen); cell (rb, kb) in 64-units; is it entirely masked (read as zero)?
+// operand window of a task: rows [0,T), k in [0,klen); cell (rb, kb) in CELL-units; is it entirely masked (read as zero)?
 bool operand_cell_masked(int T, int klen, bool lower, bool upper, int rb, int kb) {
-    const int r0 = rb * 64, r1 = r0 + 63, k0 = kb * 64, k1 = k0 + 63;
+    const int r0 = rb * CELL, r1 = r0 + CELL - 1, k0 = kb * CELL, k1 = k0 + CELL - 1;
     if (lower && k0 > r1 + (klen - T)) return true;   // zero where k > r + klen - T
     if (upper && k1 < r0) return true;                // zero where k < r
     return false;
@@ -93,17 +95,17 @@ bool operand_cell_masked(int T, int klen, bool lower, bool upper, int rb, int kb
 void task_accesses(Sim& s, const GemmTask& t, int T, int64_t base_a, int64_t base_b, int64_t base_c, int64_t base_c2, int step,
                    int task) {
     const bool a_lo = t.flags & TF_A_LOWER, a_up = t.flags & TF_A_UPPER, b_lo = t.flags & TF_B_LOWER, b_up = t.flags & TF_B_UPPER;
-    for (int rb = 0; rb < T / 64; ++rb)
-        for (int kb = 0; kb < (t.klen + 63) / 64; ++kb) {
-            if (!operand_cell_masked(T, t.klen, a_lo, a_up, rb, kb)) s.read(base_a + t.a_off + (int64_t)rb * 64 * s.ld + kb * 64, step, task);
-            if (!operand_cell_masked(T, t.klen, b_lo, b_up, rb, kb)) s.read(base_b + t.b_off + (int64_t)rb * 64 * s.ld + kb * 64, step, task);
+    for (int rb = 0; rb < T / CELL; ++rb)
+        for (int kb = 0; kb < (t.klen + CELL - 1) / CELL; ++kb) {
+            if (!operand_cell_masked(T, t.klen, a_lo, a_up, rb, kb)) s.read(base_a + t.a_off + (int64_t)rb * CELL * s.ld + kb * CELL, step, task);
+            if (!operand_cell_masked(T, t.klen, b_lo, b_up, rb, kb)) s.read(base_b + t.b_off + (int64_t)rb * CELL * s.ld + kb * CELL, step, task);
         }
-    for (int rb = 0; rb < T / 64; ++rb)
-        for (int cb = 0; cb < T / 64; ++cb) {
-            const int64_t off = base_c + t.c_off + (int64_t)rb * 64 * s.ld + cb * 64;
+    for (int rb = 0; rb < T / CELL; ++rb)
+        for (int cb = 0; cb < T / CELL; ++cb) {
+            const int64_t off = base_c + t.c_off + (int64_t)rb * CELL * s.ld + cb * CELL;
             if (t.beta != 0.0) s.read(off, step, task);
             s.write(off, step, task);
-            if (t.c2_off >= 0) s.write(base_c2 + t.c2_off + (int64_t)cb * 64 * s.ld + rb * 64, step, task);
+            if (t.c2_off >= 0) s.write(base_c2 + t.c2_off + (int64_t)cb * CELL * s.ld + rb * CELL, step, task);
         }
 }
 
@@ -209,7 +211,7 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
             if (st.strm == 0 && st.wait_ev > 0 && st.kind != 2 && ++seen == 1) { st.wait_ev = 0; break; }
     }
     const Plan& p = s.p;
-    s.cpr = (int)(s.ld / 64);
+    s.cpr = (int)(s.ld / CELL);
     s.cells.assign((size_t)4 * s.cpr * s.cpr, Cell());
     for (int i = 0; i < 8; ++i) report[i] = 0.0;
     report[5] = (double)p.steps.size();
@@ -256,11 +258,12 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
         s.step_strm[si] = strm;
         if (st.kind == 0) {
             const int64_t g0 = (int64_t)st.blk * NB * s.ld + (int64_t)st.blk * NB;
-            for (int rb = 0; rb < 2; ++rb)
-                for (int cb = 0; cb < 2; ++cb) {
-                    if (cb <= rb) s.read((int64_t)BUF_A * s.stride + g0 + (int64_t)rb * 64 * s.ld + cb * 64, (int)si, 0);
-                    s.write((int64_t)BUF_L * s.stride + g0 + (int64_t)rb * 64 * s.ld + cb * 64, (int)si, 0);
-                    s.write((int64_t)BUF_S * s.stride + g0 + (int64_t)rb * 64 * s.ld + cb * 64, (int)si, 0);
+            for (int rb = 0; rb < NB / CELL; ++rb)
+                for (int cb = 0; cb < NB / CELL; ++cb) {
+                    // the leaf reads the 16-blocks on and below the diagonal: every CELL that holds one
+                    if (cb <= rb) s.read((int64_t)BUF_A * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
+                    s.write((int64_t)BUF_L * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
+                    s.write((int64_t)BUF_S * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
                 }
             if (numeric) {
                 const int info = leaf_compute(s, st.blk);
