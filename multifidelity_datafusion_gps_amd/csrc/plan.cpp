@@ -513,7 +513,10 @@ static void plan_sweep(Plan& p) {
     // the leaf (which needs a whole CU) waits for one to retire (one evaluation alone, N = 6144: 6.66 / 6.91 / 7.37 ms at
     // 4 / 6 / 8; N = 8192: 13.9 / 13.2 / 13.05 at 4 / 6 / 8 and, with three evaluations in flight (bench.py), 2074 / 2011 / 1999 /
     // 2049 ms per fit+predict at 4 / 6 / 8 / 12; N = 16384: 96.8 / 94.1 / 93.1 ms at 8 / 12 / 16)
-    int MB = nb >= 96 ? 16 : (nb >= 56 ? 8 : 4);
+    // Chain-bound sizes (one evaluation alone, ms at MB = 2 / 3 / 4): N = 2048 0.94 / 0.97 / 1.02, 3072 1.63 / 1.72 / 1.84; with the
+    // X^T rows sharing the column launch: 4096 2.63 / 2.79 / 2.84, 5120 4.82 / 4.21 / 4.31, 5632 5.80 / 5.46 / 5.36.
+    // Up to 8 block columns ONE macro panel (and then one stream, see the end): N = 1024 0.527 -> 0.469.
+    int MB = nb >= 96 ? 16 : (nb >= 56 ? 8 : (nb > 40 ? 4 : (nb > 32 ? 3 : (nb > 8 ? 2 : nb))));
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
@@ -535,7 +538,7 @@ static void plan_sweep(Plan& p) {
     if (const char* e = getenv("MFGP_BULK_EVERY")) bulk_every = std::max(1, atoi(e));
     int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
     int far_done = 0;   // block columns < far_done have been applied to B's columns beyond the next macro panel
-    bool merge_xpanel = nb >= 48;   // bulk-bound sizes: fewer, fuller launches on the bulk stream
+    bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
     if (const char* e = getenv("MFGP_XPANEL_MERGE")) merge_xpanel = atoi(e) != 0;
     auto at = [&](int buf, int64_t row, int64_t col) { return (int64_t)buf * bs + row * ld + col; };
     auto push = [&](int64_t a, int64_t b, int64_t c, int64_t c2, int klen, int flags, double alpha, double beta) {
@@ -777,6 +780,12 @@ static void plan_sweep(Plan& p) {
         } else if (!last) {
             ev_rest_prev = 0;
         }
+    }
+    if (nb <= MB) {
+        // a single macro panel: its bulk work depends on the whole chain and nothing runs beside it -- keep it on the main
+        // stream and save the two event hops (chain -> bulk, bulk -> join: ~6 us each; N = 128: 85 -> 71 us per evaluation)
+        for (Step& st : p.steps) { st.strm = 0; st.wait_ev = st.rec_ev = st.rec_ev_final = 0; }
+        bulk_used = false;
     }
     if (bulk_used) {   // join: whatever follows on the main stream (solve, gradient) needs the bulk stream's results
         const int ev = new_event(p);
