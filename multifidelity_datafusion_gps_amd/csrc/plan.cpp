@@ -540,6 +540,10 @@ static void plan_sweep(Plan& p) {
     int far_done = 0;   // block columns < far_done have been applied to B's columns beyond the next macro panel
     bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
     if (const char* e = getenv("MFGP_XPANEL_MERGE")) merge_xpanel = atoi(e) != 0;
+    // One macro panel (nothing runs beside the chain): K^-1 is accumulated column by column in the chain's own K = 128 launches
+    // instead of one long-K launch at the end (N = 1024: 136 64-tiles of K <= 1024, 58 us on 136 CUs)
+    bool kinv_on_chain = p.kinv_streamed && nb <= MB;
+    if (const char* e = getenv("MFGP_KINV_ON_CHAIN")) kinv_on_chain = kinv_on_chain && atoi(e) != 0;
     auto at = [&](int buf, int64_t row, int64_t col) { return (int64_t)buf * bs + row * ld + col; };
     auto push = [&](int64_t a, int64_t b, int64_t c, int64_t c2, int klen, int flags, double alpha, double beta) {
         GemmTask t{};
@@ -604,7 +608,11 @@ static void plan_sweep(Plan& p) {
             if (j > i) return;
             const bool inside = (int64_t)i * T >= (int64_t)klo * NB;
             const int64_t k0 = inside ? (int64_t)i * T : (int64_t)klo * NB;
-            push(at(BUF_S, (int64_t)i * T, k0), at(BUF_S, (int64_t)j * T, k0), at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1,
+            // the gradient reduction reads K^-1 in 64x64 tiles and the diagonal ones in full: a 32-tile below the diagonal of
+            // such a block also writes its mirror image
+            const bool mirror = T < 64 && i != j && ((int64_t)i * T) / 64 == ((int64_t)j * T) / 64;
+            push(at(BUF_S, (int64_t)i * T, k0), at(BUF_S, (int64_t)j * T, k0), at(BUF_A, (int64_t)i * T, (int64_t)j * T),
+                 mirror ? at(BUF_A, (int64_t)j * T, (int64_t)i * T) : -1,
                  (int)((int64_t)khi * NB - k0), inside ? (TF_A_UPPER | (i == j ? TF_B_UPPER : 0)) : 0, 1.0,
                  inside ? 0.0 : 1.0);
         });
@@ -660,12 +668,30 @@ static void plan_sweep(Plan& p) {
             }
             {   // inner(c): right-looking K = 128 updates inside the macro (A: also the next macro's first column if `shift`)
                 const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
+                auto updates = [&]() {
+                    if (c + 1 < inner_hi) a_update(CT, c + 1, inner_hi, c, c + 1);
+                    if (c + 1 < M1) b_update(CT, M0, c + 1, c + 1, M1, c, c + 1);
+                };
                 const int first = (int)p.tasks.size();
-                if (c + 1 < inner_hi) a_update(CT, c + 1, inner_hi, c, c + 1);
-                if (c + 1 < M1) b_update(CT, M0, c + 1, c + 1, M1, c, c + 1);
-                Step* st = launch(CT, first, 0, chain_role_ct);
-                if (st)   // the columns it touches were last written by the previous macro's bulk launches
-                    for (int j = c + 1; j < inner_hi; ++j) main_wait(*st, ev_col[j]);
+                updates();
+                const int count = (int)p.tasks.size() - first;
+                int gfirst = 0, gcount = 0;
+                if (kinv_on_chain) {   // gradient variant: column c's contribution to K^-1[0:c+1, 0:c+1] rides along
+                    gfirst = (int)p.tasks.size();
+                    kinv_update(CT, c, c + 1);
+                    updates();
+                    gcount = (int)p.tasks.size() - gfirst;
+                    kinv_lo = c + 1;
+                }
+                if (count > 0 || gcount > 0) {
+                    Step st{};
+                    st.kind = 1; st.tile = CT; st.first = first; st.count = count; st.gfirst = gfirst; st.gcount = gcount;
+                    st.a = st.b = st.c = st.c2 = BUF_A;
+                    st.strm = 0; st.role = chain_role_ct;
+                    // the columns it touches were last written by the previous macro's bulk launches
+                    for (int j = c + 1; j < inner_hi; ++j) main_wait(st, ev_col[j]);
+                    p.steps.push_back(st);
+                }
             }
         }
         // ---- bulk work released by this chain ----
@@ -728,7 +754,7 @@ static void plan_sweep(Plan& p) {
             // the tail after the last leaf stays short).
             const int a_lo = last ? nb : (shift ? std::min(M1 + MB, nb - 1) + 1 : M2);
             const bool chunk_now = last || (M1 - far_done) >= bulk_every * MB;
-            const bool kinv_now = p.kinv_streamed && chunk_now;
+            const bool kinv_now = p.kinv_streamed && chunk_now && kinv_lo < M1;
             const int n_a = a_lo < nb ? ntiles_cols(a_lo, nb) : 0;
             const int n_b = last ? 0 : M1 * ((chunk_now ? nb : M2) - M1);
             const int n_k = kinv_now ? M1 * (M1 + 1) / 2 : 0;

@@ -335,6 +335,10 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
                 const double got = Ki[i * s.ld + j];
                 e3 = std::isnan(got) ? 1e300 : std::max(e3, fabs(v - got));
                 mx = std::max(mx, fabs(v));
+                if (i / 64 == j / 64) {   // the gradient reduction reads the diagonal 64x64 tiles of K^-1 in full
+                    const double up = Ki[j * s.ld + i];
+                    e3 = std::isnan(up) ? 1e300 : std::max(e3, fabs(v - up));
+                }
             }
         report[3] = e3 / mx;
     }
