@@ -1,11 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$GRAFT_REPO_ROOT/gpurun_out/${1:-ab}; mkdir -p $out
-run() { printf "%-44s" "$1"; env $2 timeout -k 10 200 python tools/time_eval.py $3 2>&1 | awk '{printf "  %s %s", $1, $3}' ; echo; }
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; tail -4 $out/tests.log
-{
-S="128 256 384 512 640 768 896 1024"
-run "default" "A=1" "$S"
-run "KINV_ON_CHAIN=0" "MFGP_KINV_ON_CHAIN=0" "$S"
-} | tee $out/plan_ab2.txt
-python tools/small_n_latency.py 2>&1 | tail -8
+export TMPDIR=/tmp
+cd /tmp
+for n in 2048 4096; do
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace_$n -- python3 $GRAFT_REPO_ROOT/tools/time_eval.py $n > $out/trace_$n.log 2>&1
+(cd $GRAFT_REPO_ROOT && python tools/trace_timeline.py $out/trace_$n 0 400 > $out/timeline_$n.txt 2>&1; python tools/chain_account.py $out/trace_$n > $out/chain_account_$n.txt 2>&1)
+cat $out/chain_account_$n.txt
+done
