@@ -157,10 +157,12 @@ def test_refit_with_new_sizes_reuses_handle(engine):
         np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
 
 
-def test_medium_size_all_tile_paths(engine):
-    """N = 2500 (Np = 2560, 20 leaf blocks: odd splits, both tile sizes) against the oracle."""
-    rng = np.random.default_rng(11)
-    N = 2500
+@pytest.mark.parametrize("N", [1000, 1100, 2500, 3100, 4200, 5200])
+def test_medium_size_all_tile_paths(engine, N):
+    """One size inside every regime of the planner's defaults, against the oracle: 8 leaf blocks (one macro panel on one
+    stream, K^-1 on the chain), 9 (two-column macro panels), 20 (odd splits, both tile sizes), 25 (merged column launch),
+    33 (three-column panels), 41 (four-column panels); 32, 49 and 64 blocks have their own tests below."""
+    rng = np.random.default_rng(11 + N)
     X = rng.uniform(size=(N, 4))
     Y = cases.hf_4d(X)
     Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
@@ -170,7 +172,7 @@ def test_medium_size_all_tile_paths(engine):
     Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
     mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
     nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
-    print("N=2500 timings:", engine.timings())
+    print("N=%d timings:" % N, engine.timings())
     assert nlml == pytest.approx(st["nlml"], rel=1e-10)
     np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
     np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
