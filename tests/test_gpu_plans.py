@@ -55,3 +55,42 @@ def test_planner_variant_matches_oracle(engine_cls, env):
     nlml2, grad2 = e.eval(theta, noise, 1e-8)
     assert nlml2 == nlml and np.array_equal(grad2, grad)        # deterministic
     e.close()
+
+
+def test_beyond_the_baseline_sizes_n32768(engine_cls):
+    """N = 32768 (256 leaf blocks, a 34 GB slab: four times the elements of the largest BASELINE configuration -- the absolute
+    task offsets pass 2^32): the sweep plan and round 1's `levels` plan run different launches over the same arithmetic, so
+    their NLML and gradient must agree to rounding, and alpha must solve the system on a sample of rows of Ky built on the
+    host.  No O(N^3) host run."""
+    rng = np.random.default_rng(32768)
+    N = 32768
+    X = rng.uniform(size=(N, 4))
+    Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    got = []
+    for env in ({}, {"MFGP_PLAN": "levels"}):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            e = engine_cls(0)
+            e.set_data(Xa, Y)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        e.set_kernel(parts)
+        nlml, grad = e.eval(theta, noise, 1e-8)
+        if not env:
+            alpha = e.get_alpha()
+            rows = rng.choice(N, size=64, replace=False)
+            Krows = orc.cov(parts, theta, Xa[rows], Xa)
+            Krows[np.arange(64), rows] += noise + 1e-8
+            assert np.abs(Krows @ alpha - Y[rows]).max() <= 1e-10 * np.abs(Y).max()
+        got.append((nlml, grad))
+        e.close()
+    (n0, g0), (n1, g1) = got
+    assert np.isfinite(n0) and n0 == pytest.approx(n1, rel=1e-12)
+    np.testing.assert_allclose(g0, g1, rtol=0, atol=1e-10 * np.abs(g1).max())
