@@ -185,7 +185,15 @@ def main():
     from multifidelity_datafusion_gps_amd import sharding
     from multifidelity_datafusion_gps_amd._lib import Engine
     comm = sharding.comm_from_env()
-    engines = {"lf": Engine(local_rank), "hf": Engine(local_rank)}
+    try:
+        first = Engine(local_rank)
+    except RuntimeError as ex:
+        # a launcher that narrows the visible devices per rank (HIP_VISIBLE_DEVICES = one GPU each) leaves only device 0
+        if local_rank == 0 or "bad device id" not in str(ex):
+            raise
+        local_rank = 0
+        first = Engine(0)
+    engines = {"lf": first, "hf": Engine(local_rank)}
     for j in range(1, args.concurrency + 1 if args.concurrency > 1 else 1):
         engines["hf#%d" % j] = Engine(local_rank)
     collectives = "none (1 rank)"
