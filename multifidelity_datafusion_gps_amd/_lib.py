@@ -142,10 +142,15 @@ class Engine:
 
     def __init__(self, device=None):
         self._lib = load_library()
-        if device is None:
+        implicit = device is None
+        if implicit:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         self._h = ctypes.c_void_p()
         rc = self._lib.mfgp_create(int(device), ctypes.byref(self._h))
+        if rc != 0 and implicit and device != 0 and b"bad device id" in self._lib.mfgp_last_error(None):
+            # one process per GPU under a launcher that narrows the visible devices per rank: the only device is 0
+            device = 0
+            rc = self._lib.mfgp_create(0, ctypes.byref(self._h))
         if rc != 0:
             msg = self._lib.mfgp_last_error(None).decode()
             self._h = None
