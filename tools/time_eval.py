@@ -1,5 +1,5 @@
 """quick per-stage timing of one objective+gradient evaluation and one predict (GPU box)"""
-import sys, os, json
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from multifidelity_datafusion_gps_amd._lib import Engine
