@@ -515,8 +515,9 @@ static void plan_sweep(Plan& p) {
     // 2049 ms per fit+predict at 4 / 6 / 8 / 12; N = 16384: 96.8 / 94.1 / 93.1 ms at 8 / 12 / 16)
     // Chain-bound sizes (one evaluation alone, ms at MB = 2 / 3 / 4): N = 2048 0.94 / 0.97 / 1.02, 3072 1.63 / 1.72 / 1.84; with the
     // X^T rows sharing the column launch: 4096 2.63 / 2.79 / 2.84, 5120 4.82 / 4.21 / 4.31, 5632 5.80 / 5.46 / 5.36.
-    // Up to 8 block columns ONE macro panel (and then one stream, see the end): N = 1024 0.527 -> 0.469.
-    int MB = nb >= 96 ? 16 : (nb >= 56 ? 8 : (nb > 40 ? 4 : (nb > 32 ? 3 : (nb > 8 ? 2 : nb))));
+    // Up to 13 block columns ONE macro panel (and then one stream and K^-1 on the chain, see the end): N = 1024 0.527 -> 0.42,
+    // 1280 0.60 -> 0.55, 1536 0.72 -> 0.68 (1792: 0.825 either way, 2048: 0.94 / 0.99 in favour of two-column panels).
+    int MB = nb >= 96 ? 16 : (nb >= 56 ? 8 : (nb > 40 ? 4 : (nb > 32 ? 3 : (nb > 13 ? 2 : nb))));
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;

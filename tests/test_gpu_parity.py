@@ -157,10 +157,10 @@ def test_refit_with_new_sizes_reuses_handle(engine):
         np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
 
 
-@pytest.mark.parametrize("N", [1000, 1100, 2500, 3100, 4200, 5200])
+@pytest.mark.parametrize("N", [1000, 1600, 1700, 2500, 3100, 4200, 5200])
 def test_medium_size_all_tile_paths(engine, N):
     """One size inside every regime of the planner's defaults, against the oracle: 8 leaf blocks (one macro panel on one
-    stream, K^-1 on the chain), 9 (two-column macro panels), 20 (odd splits, both tile sizes), 25 (merged column launch),
+    stream, K^-1 on the chain), 13 (the largest such plan), 14 (two-column macro panels), 20 (odd splits, both tile sizes), 25 (merged column launch),
     33 (three-column panels), 41 (four-column panels); 32, 49 and 64 blocks have their own tests below."""
     rng = np.random.default_rng(11 + N)
     X = rng.uniform(size=(N, 4))

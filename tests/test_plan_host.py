@@ -62,6 +62,8 @@ ENVS = [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}, {"MFGP_
 def test_plans_factorise_invert_and_accumulate_kinv_without_races(simlib, env):
     # (nblk, numeric, want_grad, slack rows of capacity, mutate)
     specs = [(nb, 1, g, 128 if nb % 2 else 0, 0) for nb in (1, 2, 3, 5, 8, 9) for g in (0, 1)]
+    if not env:   # the largest single-macro plan of the defaults (13 block columns, K^-1 on the chain)
+        specs += [(13, 1, g, 0, 0) for g in (0, 1)]
     for (nb, _, g, _, _), (rc, rep, msg) in zip(specs, _run(simlib, specs, env)):
         assert rc == 0, (nb, g, msg)
         assert rep[0] < 1e-14 and rep[1] < 1e-12 and rep[2] == 0.0, (nb, g, rep)     # L L^T = A, X L = I, S mirrored
@@ -76,7 +78,7 @@ def test_schedules_of_the_bench_sizes_are_race_free(simlib, env):
     """race check only (no arithmetic) at the block counts of the BASELINE configurations: 32 (N = 4096), 47 / 48 / 49
     (the slim-chain switch), 64 (N = 8192), 128 (N = 16384), and either side of every size at which the planner's defaults
     change (macro panel length, merged column launch, tile sizes)"""
-    specs = [(nb, 0, 1, 0, 0) for nb in (8, 9, 16, 24, 25, 32, 33, 40, 41, 47, 48, 49, 55, 56, 64, 128)]
+    specs = [(nb, 0, 1, 0, 0) for nb in (8, 9, 13, 14, 16, 24, 25, 32, 33, 40, 41, 47, 48, 49, 55, 56, 64, 128)]
     for spec, (rc, rep, msg) in zip(specs, _run(simlib, specs, env)):
         assert rc == 0 and rep[4] == 0, (spec, msg)
 

@@ -1,10 +1,9 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$GRAFT_REPO_ROOT/gpurun_out/${1:-ab}; mkdir -p $out
-export TMPDIR=/tmp
-cd /tmp
-for n in 2048 4096; do
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace_$n -- python3 $GRAFT_REPO_ROOT/tools/time_eval.py $n > $out/trace_$n.log 2>&1
-(cd $GRAFT_REPO_ROOT && python tools/trace_timeline.py $out/trace_$n 0 400 > $out/timeline_$n.txt 2>&1; python tools/chain_account.py $out/trace_$n > $out/chain_account_$n.txt 2>&1)
-cat $out/chain_account_$n.txt
-done
+run() { printf "%-44s" "$1"; env $2 timeout -k 10 200 python tools/time_eval.py $3 2>&1 | awk '{printf "  %s %s", $1, $3}' ; echo; }
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; tail -3 $out/tests.log
+{
+S="1024 1152 1280 1536 1664 1792 2048"
+run "default" "A=1" "$S"
+} | tee $out/plan_ab2.txt
