@@ -36,15 +36,15 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) to full double precision: hardware seed + two Newton steps (short dependent chain:
-// this sits on the pivot-to-pivot critical path 128 times per leaf)
+// 1/sqrt(d) to full double precision: hardware seed y0 (>= 20 good bits) and ONE third-order correction
+//   e = 1 - d y0^2 ,   1/sqrt(d) = y0 (1 - e)^-1/2 = y0 (1 + e/2 + 3e^2/8 + O(e^3)) ,   |e|^3 < 2^-60
+// -- four dependent operations behind the seed instead of the six of two Newton steps: this chain sits on the pivot-to-pivot
+// critical path 128 times per leaf.
 __device__ __forceinline__ double fast_rsqrt(double d) {
-    double y = __builtin_amdgcn_rsq(d);
-    double e = __builtin_fma(-d * y, y, 1.0);
-    y = __builtin_fma(0.5 * y, e, y);
-    e = __builtin_fma(-d * y, y, 1.0);
-    y = __builtin_fma(0.5 * y, e, y);
-    return y;
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = __builtin_fma(-d * y0, y0, 1.0);
+    const double p = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y0 * e, p, y0);
 }
 
 // 16x16 Cholesky AND the inverse of the factor in the registers of one wave.  blk -> element (0,0) of the diagonal

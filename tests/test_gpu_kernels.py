@@ -61,6 +61,23 @@ def test_leaf_cholesky_and_inverse(engine, cond):
     assert np.abs(X @ L - np.eye(128)).max() < 1e-13 * np.sqrt(cond) * 128
 
 
+def test_leaf_pivots_over_a_wide_range_of_magnitudes(engine):
+    """D A D with D = diag(10^[-8, 8]): pivots from 1e-16 to 1e16 (the reciprocal square root of a pivot is a hardware seed
+    plus one third-order correction: its accuracy must not depend on the magnitude); checked in the scaled-back metric."""
+    rng = np.random.default_rng(77)
+    A = _spd(128, rng, 1e3)
+    d = 10.0 ** rng.uniform(-8, 8, size=128)
+    As = A * d[:, None] * d[None, :]
+    L, S, half_logdet, info = engine.dbg_leaf(np.tril(As))
+    assert info == 0
+    Lref = np.linalg.cholesky(A) * d[:, None]          # chol(D A D) = D chol(A)
+    assert np.abs((L @ L.T - As) / (d[:, None] * d[None, :])).max() / np.abs(A).max() < 1e-14 * 128
+    assert np.abs((L - Lref) / d[:, None]).max() / np.abs(Lref / d[:, None]).max() < 1e-11
+    assert half_logdet == pytest.approx(np.log(np.diag(Lref)).sum(), rel=1e-12, abs=1e-10)
+    X = np.tril(S)
+    assert np.abs(X @ L - np.eye(128)).max() < 1e-9       # rows / columns scaled 1e+-8 apart: absolute identity error
+
+
 def test_leaf_reports_non_positive_pivot(engine):
     A = np.eye(128)
     A[40, 40] = -1.0
