@@ -24,7 +24,7 @@ namespace mfgp {
 constexpr int LP = 130;       // LDS pitch (doubles)
 constexpr int LEAF_THREADS = 512;
 constexpr int SC_RED = 0;      // scratch: 8 partial sums
-constexpr int SC_SIZE = 16;
+constexpr int SC_SIZE = 48;     // 8 partial sums (+ 8 spare), then the micro-Cholesky's 2 x 16 column broadcast slots
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -49,41 +49,71 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 
 // 16x16 Cholesky AND the inverse of the factor in the registers of one wave.  blk -> element (0,0) of the diagonal
 // block in LDS.  Lanes 0-15: lane i holds row i of the block, v[k] = A[i][k] -> L[i][k].  Lanes 16-31: lane 16+c holds
-// column c of the inverse Y = L^-1, v[k] = -(sum_{m<k} l_km Y[m][c]) until pivot k, then Y[k][c].
+// column c of the inverse Y = L^-1, v[k] = delta_kc - sum_{m<k} l_km Y[m][c] until pivot k, then Y[k][c].
 // The inverse rides on the factorisation's own broadcasts: row j of Y is Y[j][:] = (e_j - sum_{m<j} l_jm Y[m][:]) / l_jj,
 // and l_kj -- broadcast at pivot j to eliminate column j from row k -- is exactly the coefficient with which the
-// finished row j of Y enters row k's sum.  With the sums kept negated both lane groups execute the SAME instruction
-// v[k] -= v[j] * l_kj, so the inverse costs one add per pivot and no extra communication.
-// Branch-free inside the pivot loop: a failed pivot (d <= 0 or NaN) is replaced by 1 and its index kept.
+// finished row j of Y enters row k's sum.  Both lane groups execute the SAME instructions (v[j] *= y_j, v[k] -= v[j] * l_kj):
+// the inverse costs nothing per pivot and no extra communication.
 template <int YP = LP>
-__device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lane, int* info, int pivot0) {
+__device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lane, int* info, int pivot0, double* col_buf) {
     const int i = lane & 15;
     const bool inv_lane = (lane & 16) != 0;
     double v[16];
 #pragma unroll
-    for (int k = 0; k < 16; k += 2) {
+    for (int k = 0; k < 16; k += 2) {   // inverse lanes start from the identity: column c of I
         const d2_t t = *reinterpret_cast<const d2_t*>(blk + i * LP + k);
-        v[k] = inv_lane ? 0.0 : t.x;
-        v[k + 1] = inv_lane ? 0.0 : t.y;
+        v[k] = inv_lane ? (k == i ? 1.0 : 0.0) : t.x;
+        v[k + 1] = inv_lane ? (k + 1 == i ? 1.0 : 0.0) : t.y;
     }
-    int fail = 0;  // 1-based index of the first non-positive pivot inside this block (wave-uniform)
+    // Nothing in the pivot loop looks at the sign of a pivot (the loop is bound by instruction issue: every instruction per
+    // pivot counts 128 times per leaf): a pivot d <= 0 or NaN makes its own diagonal entry NaN (rsq(d < 0) = NaN, 0 * inf = NaN)
+    // and everything after it, so the first non-positive diagonal entry of the result IS the first failed pivot.
+    //
+    // Column j reaches the other lanes two ways.  The ONE entry the next pivot waits for (l_{j+1,j}) is broadcast with
+    // v_readlane (two instructions + the FMA, no memory latency).  The other 14 - j entries go through LDS: the factor
+    // lanes store their l_ij (one ds_write), every lane reads them back two at a time from the same address (broadcast
+    // reads), so an update costs half a read + one FMA instead of two v_readlane + one FMA -- a third of the loop's
+    // instructions.  The reads are issued before the next pivot's reciprocal-square-root chain and consumed after it.
+    double* const col = col_buf;          // 2 x 16 doubles, slot j & 1
+    double r[16];                         // pivot j's entries l_kj for the columns k >= j + 2, in flight
+    double y = fast_rsqrt(readlane_f64(v[0], 0));
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        double d = readlane_f64(v[j], j);
-        const bool ok = d > 0.0;
-        fail = (!ok && fail == 0) ? j + 1 : fail;
-        d = ok ? d : 1.0;
-        const double y = fast_rsqrt(d);
-        const double e = (inv_lane && i == j) ? 1.0 : 0.0;
-        v[j] = (v[j] + e) * y;          // factor lanes: l_ij (row j itself: sqrt(d)); inverse lanes: Y[j][c]
-        v[j] = (!inv_lane && i == j && !ok) ? 1.0 : v[j];
+        if (j >= 1) {   // pivot j-1's remaining updates (columns j+1 .. 15; column j was the readlane path)
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-            const double lkj = readlane_f64(v[j], k);   // from factor lane k
-            v[k] = __builtin_fma(-v[j], lkj, v[k]);     // factor lanes: meaningful for rows i >= k
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 broadcasts in flight (SGPR pressure)
+            for (int k = j + 1; k < 16; ++k) v[k] = __builtin_fma(-v[j - 1], r[k], v[k]);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        v[j] *= y;                      // factor lanes: l_ij (row j itself: sqrt(d)); inverse lanes: Y[j][c]
+        if (j < 15) {
+            const double l = readlane_f64(v[j], j + 1);
+            v[j + 1] = __builtin_fma(-v[j], l, v[j + 1]);
+            const double dn = readlane_f64(v[j + 1], j + 1);
+            const double y0 = __builtin_amdgcn_rsq(dn);
+            if (j < 14) {
+                if (lane < 16) col[(j & 1) * 16 + i] = v[j];
+                // lanes exchange data through memory here: without a (wavefront-scope, instruction-free) fence the compiler
+                // treats the reads below as private to each lane and forwards older values to the lanes that did not store
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double* const cj = col + (j & 1) * 16;
+                const int k0 = (j + 2) | 1;               // first odd column index >= j + 2 ...
+                if (((j + 2) & 1) == 0) {                 // ... reached through one aligned pair, or directly
+                    const d2_t t = *reinterpret_cast<const d2_t*>(cj + j + 2);
+                    r[j + 2] = t.x; r[j + 3] = t.y;
+                } else {
+                    r[j + 2] = cj[j + 2];
+                }
+#pragma unroll
+                for (int k = k0 + 1; k < 16; k += 2) {    // aligned pairs (k even, k + 1 <= 15)
+                    const d2_t t = *reinterpret_cast<const d2_t*>(cj + k);
+                    r[k] = t.x; r[k + 1] = t.y;
+                }
+            }
+            const double en = __builtin_fma(-dn * y0, y0, 1.0);
+            const double p = __builtin_fma(0.375, en, 0.5);
+            y = __builtin_fma(y0 * en, p, y0);
+        }
     }
     if (lane < 16) {
 #pragma unroll
@@ -97,7 +127,10 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
 #pragma unroll
         for (int k = 0; k < 16; ++k) y_out[k * YP + i] = v[k];   // column i of Y_jj (zero above the diagonal)
     }
-    if (fail != 0 && lane == 0 && *info == 0) *info = pivot0 + fail;
+    // first failed pivot, if any: the first diagonal entry that is not a positive number (read back: same wave, LDS is in order)
+    const double dg = blk[i * LP + i];
+    const unsigned long long bad = __ballot(lane < 16 && !(dg > 0.0));
+    if (bad != 0 && lane == 0 && *info == 0) *info = pivot0 + __ffsll((long long)bad);
 }
 
 // rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
@@ -186,7 +219,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             *reinterpret_cast<d2_t*>(sL + (e >> 3) * LP + 2 * (e & 7)) = v[u];
         }
         STAMP(1);
-        micro_chol16<YP16>(sL, sY, lane, info, blk * NB);    // (same wave wrote the tile: LDS program order suffices)
+        micro_chol16<YP16>(sL, sY, lane, info, blk * NB, sc + 16);    // (same wave wrote the tile: LDS program order suffices)
     } else {
         // the 35 other tiles of the lower block triangle (tile tl = I(I+1)/2 + J, J <= I), 128 pairs of doubles each
         constexpr int NLD = 10;   // ceil(35 * 128 / 448 lanes)
@@ -258,7 +291,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         if (wave == 0) {
             // the next diagonal block is factorised (and inverted) while waves 1-7 finish panel jb's updates
             micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + ((jb + 1) & 1) * 16 * YP16, lane, info,
-                               blk * NB + jb * 16 + 16);
+                               blk * NB + jb * 16 + 16, sc + 16);
         } else {
             const int m = 6 - jb;                    // A: block columns jb+2 .. 7, lower blocks
             const int nA = m * (m + 1) / 2;
