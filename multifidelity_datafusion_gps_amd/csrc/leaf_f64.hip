@@ -24,7 +24,7 @@ namespace mfgp {
 constexpr int LP = 130;       // LDS pitch (doubles)
 constexpr int LEAF_THREADS = 512;
 constexpr int SC_RED = 0;      // scratch: 8 partial sums
-constexpr int SC_SIZE = 48;     // 8 partial sums (+ 8 spare), then the micro-Cholesky's 2 x 16 column broadcast slots
+constexpr int SC_SIZE = 144;    // 8 partial sums (+ 8 spare), then the micro-Cholesky's 2 x 64 column broadcast slots
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -74,7 +74,12 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
     // lanes store their l_ij (one ds_write), every lane reads them back two at a time from the same address (broadcast
     // reads), so an update costs half a read + one FMA instead of two v_readlane + one FMA -- a third of the loop's
     // instructions.  The reads are issued before the next pivot's reciprocal-square-root chain and consumed after it.
-    double* const col = col_buf;          // 2 x 16 doubles, slot j & 1
+    // col_buf: 2 slots (j & 1) of 64 doubles.  EVERY lane stores (entry = its lane index; only entries 0-15, the factor lanes,
+    // are read): no exec masking around the store.  The slot base goes through an opaque per-lane zero, or the compiler
+    // materialises every read's absolute LDS address in a VGPR of its own (s_add + v_mov per read) instead of base + offset.
+    int zero = 0;
+    __asm__ volatile("" : "+v"(zero));
+    double* const col = col_buf + zero;
     double r[16];                         // pivot j's entries l_kj for the columns k >= j + 2, in flight
     double y = fast_rsqrt(readlane_f64(v[0], 0));
 #pragma unroll
@@ -90,13 +95,13 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
             const double dn = readlane_f64(v[j + 1], j + 1);
             const double y0 = __builtin_amdgcn_rsq(dn);
             if (j < 14) {
-                if (lane < 16) col[(j & 1) * 16 + i] = v[j];
+                col[(j & 1) * 64 + lane] = v[j];
                 // lanes exchange data through memory here: without a (wavefront-scope, instruction-free) fence the compiler
                 // treats the reads below as private to each lane and forwards older values to the lanes that did not store
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                double* const cj = col + (j & 1) * 16;
+                double* const cj = col + (j & 1) * 64;
                 const int k0 = (j + 2) | 1;               // first odd column index >= j + 2 ...
                 if (((j + 2) & 1) == 0) {                 // ... reached through one aligned pair, or directly
                     const d2_t t = *reinterpret_cast<const d2_t*>(cj + j + 2);
@@ -110,6 +115,9 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
                     r[k] = t.x; r[k + 1] = t.y;
                 }
             }
+            // (the reads must be ISSUED here, a whole reciprocal-square-root chain ahead of their first use: left to itself the
+            // compiler sinks them next to that use and puts the LDS latency on the pivot-to-pivot path)
+            __builtin_amdgcn_sched_barrier(0);
             const double en = __builtin_fma(-dn * y0, y0, 1.0);
             const double p = __builtin_fma(0.375, en, 0.5);
             y = __builtin_fma(y0 * en, p, y0);
