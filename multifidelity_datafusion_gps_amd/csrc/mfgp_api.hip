@@ -171,7 +171,12 @@ static int build_plans(mfgp_handle* h) {
     build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap);
     while ((int)h->evpool.size() < h->pl.n_events) {
         hipEvent_t e;
-        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // the plan's events order kernels of ONE device across the handle's two streams: no system-scope fence (cache
+        // write-back / invalidate for the host and for other devices) when they are recorded -- ~2 % of an evaluation at
+        // N = 3072 .. 6144 (MFGP_EVENT_SYSTEM_FENCE=1 restores it); results reach the host behind hipStreamSynchronize
+        unsigned flags = hipEventDisableTiming;
+        if (!(getenv("MFGP_EVENT_SYSTEM_FENCE") && atoi(getenv("MFGP_EVENT_SYSTEM_FENCE")) != 0)) flags |= hipEventDisableSystemFence;
+        HIPCHK(h, hipEventCreateWithFlags(&e, flags));
         h->evpool.push_back(e);
     }
     return upload_tasks(h);
