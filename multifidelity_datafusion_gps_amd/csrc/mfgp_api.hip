@@ -115,7 +115,8 @@ static int create_body(mfgp_handle* h, int device_id) {
             HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         }
     }
-    for (auto& ev : h->ev) HIPCHK(h, hipEventCreate(&ev));
+    // timing events: no system-scope fence at the record either (more precise stamps, and cheaper: see build_plans)
+    for (auto& ev : h->ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
     // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
     // pinned, device-mapped host memory: no copy kernel at the end of a call and no fill kernel for the status at its
     // start (each costs ~5 us plus a gap; an evaluation at N <= 128 is ~75 us of GPU time in all)
@@ -210,7 +211,7 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
     }
     const bool replan = (Np != h->Np) || realloc_;   // (the plan's offsets depend on the slab stride = cap^2)
     h->N = N; h->Np = Np; h->D = D; h->nblk = (int)(Np / NB);
-    h->stage_timing = Np >= 1024;
+    h->stage_timing = Np >= 4096;   // four more event records per evaluation: ~20 us, 5 % of an evaluation at N = 1024
     if (const char* e = getenv("MFGP_STAGE_TIMING")) h->stage_timing = atoi(e) != 0;
     HIPCHK(h, hipMemsetAsync(h->dX, 0, (size_t)Np * D * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->dY, 0, (size_t)Np * sizeof(double), h->stream));

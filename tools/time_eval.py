@@ -26,7 +26,7 @@ def main():
         m, v = e.predict(Xa[: min(N, 8192)])
         tp = e.timings()
         Np = (N + 127) // 128 * 128
-        for k in ("kbuild_ms", "cholinv_ms", "kinv_ms"):   # per-stage stamps are off below Np = 1024 (MFGP_STAGE_TIMING=1 forces them)
+        for k in ("kbuild_ms", "cholinv_ms", "kinv_ms"):   # per-stage stamps are off below Np = 4096 (MFGP_STAGE_TIMING=1 forces them)
             acc[k] = max(acc[k], 1e-9)
         print("N=%d  total %.3f ms | kbuild %.3f (%.0f GB/s) cholinv %.3f (%.1f TF) solve %.3f kinv %.3f (%.1f TF) grad %.3f | launches %d | predict panel %.3f var %.3f (%.1f TF)" % (
             N, acc["total_ms"], acc["kbuild_ms"], acc["kbuild_bytes"] / acc["kbuild_ms"] / 1e6, acc["cholinv_ms"],
