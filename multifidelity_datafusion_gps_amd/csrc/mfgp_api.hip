@@ -213,6 +213,10 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
     h->N = N; h->Np = Np; h->D = D; h->nblk = (int)(Np / NB);
     h->stage_timing = Np >= 4096;   // four more event records per evaluation: ~20 us, 5 % of an evaluation at N = 1024
     if (const char* e = getenv("MFGP_STAGE_TIMING")) h->stage_timing = atoi(e) != 0;
+    // no timing events at all below that size unless asked for (MFGP_TIMING=1: start / end stamps only): an optimiser never
+    // reads them, and the two records of an evaluation (three of a predict) are ~7 us of the ~56 (~80) us a small one takes
+    h->timing = h->stage_timing;
+    if (const char* e = getenv("MFGP_TIMING")) h->timing = h->timing || atoi(e) != 0;
     HIPCHK(h, hipMemsetAsync(h->dX, 0, (size_t)Np * D * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->dY, 0, (size_t)Np * sizeof(double), h->stream));
     HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -291,7 +295,7 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
         if (rc_) return rc_;
     }
     *h->hinfo = 0;   // (the previous call synchronised the stream)
-    HIPCHK(h, hipEventRecord(h->ev[0], s));
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], s));
     if (!prebuilt) {
         launch_kbuild_tri(s, h->spec, h->dX, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
         h->launches++;
@@ -305,14 +309,14 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dz, h->dalpha, (int)h->Np, (int)h->Np, 1);   // alpha = X^T z
     launch_finish_solve(s, h->dz, (int)h->Np, h->dlogdet, h->nblk, h->dres);
     h->launches += 3;
-    if (stages || !want_grad) HIPCHK(h, hipEventRecord(h->ev[3], s));
+    if (stages || (!want_grad && h->timing)) HIPCHK(h, hipEventRecord(h->ev[3], s));
     if (want_grad) {
         if (!stream_kinv) run_step(h, h->pl.kinv_step);   // (streamed plans have accumulated K^-1 behind the chain already)
         if (stages) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
         h->launches += 2;
-        HIPCHK(h, hipEventRecord(h->ev[5], s));
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -332,7 +336,7 @@ static int finish_eval(mfgp_handle* h, bool want_grad) {
             t.grad_ms = ev_ms(h->ev[4], h->ev[5]);
         }
     }
-    t.total_ms = ev_ms(h->ev[0], h->ev[want_grad ? 5 : 3]);
+    if (h->timing) t.total_ms = ev_ms(h->ev[0], h->ev[want_grad ? 5 : 3]);
     const double np = (double)h->Np;
     t.kbuild_bytes = 4.0 * np * (np + 64.0);
     // a streamed plan accumulates K^-1 inside the sweep (between the cholinv stamps): its N^3/3 flops are counted there
@@ -495,16 +499,16 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->grad_valid) {
         hipStream_t s = h->stream;
-        HIPCHK(h, hipEventRecord(h->ev[3], s));
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], s));
         run_step(h, h->pl.kinv_step);
-        HIPCHK(h, hipEventRecord(h->ev[4], s));
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 2);
-        HIPCHK(h, hipEventRecord(h->ev[5], s));
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
         HIPCHK(h, hipStreamSynchronize(s));
         HIPCHK(h, hipGetLastError());
-        h->tm.kinv_ms = ev_ms(h->ev[3], h->ev[4]);
-        h->tm.grad_ms = ev_ms(h->ev[4], h->ev[5]);
+        h->tm.kinv_ms = h->timing ? ev_ms(h->ev[3], h->ev[4]) : 0.f;
+        h->tm.grad_ms = h->timing ? ev_ms(h->ev[4], h->ev[5]) : 0.f;
         for (int i = 0; i < 2 * h->spec.nf + 1; ++i) h->grad[i] = h->hres[2 + i];
         h->kinv_valid = h->grad_valid = true;
         h->cum.grad_evals += 1;
@@ -547,11 +551,11 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         rc = upload_tasks(h);
         if (rc) return rc;
     }
-    HIPCHK(h, hipEventRecord(h->ev[6], s));
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[6], s));
     launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
     launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, h->dvec, rows_p, (int)Np, 2);
     h->launches += 2;
-    HIPCHK(h, hipEventRecord(h->ev[7], s));
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
     HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
     if (want_var) {
         h->kinv_valid = false;  // V overwrites the K^-1 storage
@@ -561,13 +565,15 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
         launch_finish_var(s, h->spec, h->dvec2, h->dvec2, vrows, include_noise ? h->noise : 0.0);
         h->launches += 2;
-        HIPCHK(h, hipEventRecord(h->ev[8], s));
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[8], s));
         HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
-    *pan_ms += ev_ms(h->ev[6], h->ev[7]);
-    if (want_var) *var_ms += ev_ms(h->ev[7], h->ev[8]);
+    if (h->timing) {
+        *pan_ms += ev_ms(h->ev[6], h->ev[7]);
+        if (want_var) *var_ms += ev_ms(h->ev[7], h->ev[8]);
+    }
     return 0;
 }
 

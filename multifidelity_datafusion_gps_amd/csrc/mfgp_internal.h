@@ -115,6 +115,7 @@ struct mfgp_handle {
     double* hres = nullptr;  // pinned
     int* hinfo = nullptr;    // pinned
     bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 1024 unless MFGP_STAGE_TIMING=1)
+    bool timing = true;          // any timing events at all (start / end of an evaluation, of a predict)
     mfgp::Plan pl;                  // factorisation / inverse / K^-1 / predictive-variance launch lists (plan.cpp)
     mfgp::KernSpecDev spec{};
     bool have_kernel = false, have_data = false, factorized = false, kinv_valid = false, grad_valid = false,

@@ -1,6 +1,7 @@
 """Latency of one two-level predict (low-fidelity mean on the stencil -> augmented rows -> high-fidelity mean+variance):
 host hand-over (two engine calls + numpy concatenation) against mfgp_predict_chained."""
 import sys, os, time
+import os as _os; _os.environ.setdefault("MFGP_TIMING", "1")   # start / end stamps of a call at every size (off by default below Np = 4096)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from multifidelity_datafusion_gps_amd._lib import Engine

@@ -1,6 +1,7 @@
 """Latency of one predict call (mean + variance) against the number of test rows; MFGP_SKINNY=0 disables the skinny
 variance product for N* <= 64 (then every batch is padded to a 128-row tile GEMM)."""
 import sys, os, time
+import os as _os; _os.environ.setdefault("MFGP_TIMING", "1")   # start / end stamps of a call at every size (off by default below Np = 4096)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from multifidelity_datafusion_gps_amd._lib import Engine

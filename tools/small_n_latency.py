@@ -1,6 +1,7 @@
 """Per-evaluation latency at the reference's own problem sizes (N = 10 .. 512): engine call alone vs the whole
 host path (transform + ctypes + engine + gradient chain rule) that L-BFGS-B sees."""
 import sys, os, time
+import os as _os; _os.environ.setdefault("MFGP_TIMING", "1")   # start / end stamps of a call at every size (off by default below Np = 4096)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from multifidelity_datafusion_gps_amd import engine as gp

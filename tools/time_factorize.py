@@ -1,5 +1,6 @@
 """gradient-free factorisation (mfgp_factorize: K build + Cholesky + inverse, no K^-1) of a single-RBF 3-D GP: ms per size"""
 import sys, os
+import os as _os; _os.environ.setdefault("MFGP_TIMING", "1")   # start / end stamps of a call at every size (off by default below Np = 4096)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from multifidelity_datafusion_gps_amd._lib import Engine
