@@ -123,6 +123,8 @@ static int create_body(mfgp_handle* h, int device_id) {
     HIPCHK(h, hipHostMalloc(&h->hres, 64 * sizeof(double), hipHostMallocMapped));
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dres), h->hres, 0));
     memset(h->hres, 0, 64 * sizeof(double));
+    HIPCHK(h, hipHostMalloc(&h->hio, (size_t)(mfgp_handle::IO_IN + 2 * mfgp_handle::IO_OUT) * sizeof(double), hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dio), h->hio, 0));
     h->dinfo = reinterpret_cast<int*>(h->dres + 30);   // the pivot status lives beside the results
     h->hinfo = reinterpret_cast<int*>(h->hres + 30);
     hipDeviceProp_t prop;
@@ -160,6 +162,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     comm_release(h);
     if (h->dstage) hipFree(h->dstage);
     if (h->hres) hipHostFree(h->hres);
+    if (h->hio) hipHostFree(h->hio);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
     if (h->stream2) hipStreamDestroy(h->stream2);
@@ -536,9 +539,13 @@ static int ensure_xs(mfgp_handle* h, int rows_p) {
 }
 
 // mean (and variance) of the `rows` test rows already resident (zero padded to rows_p) in h->dXs, in stream order
+// `pinned`: the results are written by the kernels straight into the handle's device-mapped pinned memory and copied to
+// mean / var by the host after the synchronisation (no device-to-host copy commands)
 static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean, double* var, int want_var,
-                         int include_noise, double* pan_ms, double* var_ms) {
+                         int include_noise, double* pan_ms, double* var_ms, bool pinned = false) {
     hipStream_t s = h->stream;
+    double* const mean_dev = pinned ? h->dio + mfgp_handle::IO_IN : h->dvec;
+    double* const var_dev = pinned ? h->dio + mfgp_handle::IO_IN + mfgp_handle::IO_OUT : h->dvec2;
     const int64_t Np = h->Np;
     int rc;
     // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound skinny product instead of a padded tile GEMM
@@ -553,23 +560,27 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     }
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[6], s));
     launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
-    launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, h->dvec, rows_p, (int)Np, 2);
+    launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, mean_dev, rows_p, (int)Np, 2);
     h->launches += 2;
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
-    HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (!pinned) HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
     if (want_var) {
         h->kinv_valid = false;  // V overwrites the K^-1 storage
         const int vrows = skinny ? 16 * rows16 : rows_p;
         if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
         else run_step(h, h->pl.predv_step);
         launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
-        launch_finish_var(s, h->spec, h->dvec2, h->dvec2, vrows, include_noise ? h->noise : 0.0);
+        launch_finish_var(s, h->spec, h->dvec2, var_dev, vrows, include_noise ? h->noise : 0.0);
         h->launches += 2;
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[8], s));
-        HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (!pinned) HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
+    if (pinned) {
+        memcpy(mean, h->hio + mfgp_handle::IO_IN, (size_t)rows * sizeof(double));
+        if (want_var) memcpy(var, h->hio + mfgp_handle::IO_IN + mfgp_handle::IO_OUT, (size_t)rows * sizeof(double));
+    }
     if (h->timing) {
         *pan_ms += ev_ms(h->ev[6], h->ev[7]);
         if (want_var) *var_ms += ev_ms(h->ev[7], h->ev[8]);
@@ -607,10 +618,18 @@ int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double*
         const int rows_p = (int)((rows + NB - 1) / NB * NB);
         rc = ensure_xs(h, rows_p);
         if (rc) return rc;
-        HIPCHK(h, hipMemsetAsync(h->dXs, 0, (size_t)rows_p * D * sizeof(double), s));
-        HIPCHK(h, hipMemcpyAsync(h->dXs, Xstar + r0 * D, (size_t)rows * D * sizeof(double), hipMemcpyHostToDevice, s));
+        // vrows of the skinny variance path can exceed rows (16 / 32 / 64): the output slots hold rows_p
+        const bool pinned = (int64_t)rows_p * D <= mfgp_handle::IO_IN && rows_p <= mfgp_handle::IO_OUT;
+        if (pinned) {   // zero-padded rows assembled in pinned memory by the host, ONE asynchronous copy command
+            memcpy(h->hio, Xstar + r0 * D, (size_t)rows * D * sizeof(double));
+            memset(h->hio + rows * D, 0, (size_t)(rows_p - rows) * D * sizeof(double));
+            HIPCHK(h, hipMemcpyAsync(h->dXs, h->hio, (size_t)rows_p * D * sizeof(double), hipMemcpyHostToDevice, s));
+        } else {
+            HIPCHK(h, hipMemsetAsync(h->dXs, 0, (size_t)rows_p * D * sizeof(double), s));
+            HIPCHK(h, hipMemcpyAsync(h->dXs, Xstar + r0 * D, (size_t)rows * D * sizeof(double), hipMemcpyHostToDevice, s));
+        }
         rc = predict_chunk(h, rows, rows_p, mean + r0, want_var ? var + r0 : nullptr, want_var, include_noise, &pan_ms,
-                           &var_ms);
+                           &var_ms, pinned);
         if (rc) return rc;
     }
     predict_account(h, Nstar, pan_ms, var_ms);

@@ -113,6 +113,12 @@ struct mfgp_handle {
     int64_t ch_rows = 0;
     int ch_c = 0, ch_D = 0;             // the chain scratch is sized for (ch_rows, ch_c) at input width ch_D
     double* hres = nullptr;  // pinned
+    // small predictive batches (the DIRECT callback, acquisition batches, single-point serving) travel through pinned,
+    // device-mapped memory instead of pageable copies: [IO_IN doubles of test rows | IO_OUT means | IO_OUT variances].
+    // A hipMemcpyAsync to / from pageable memory is staged and blocks the calling thread (~15-20 us each, three per call).
+    static constexpr int IO_IN = 32768, IO_OUT = 8192;
+    double* hio = nullptr;   // host view
+    double* dio = nullptr;   // device view
     int* hinfo = nullptr;    // pinned
     bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 1024 unless MFGP_STAGE_TIMING=1)
     bool timing = true;          // any timing events at all (start / end of an evaluation, of a predict)
