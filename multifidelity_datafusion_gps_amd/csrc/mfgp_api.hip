@@ -659,8 +659,9 @@ static int ensure_chain(mfgp_handle* lf, int64_t rows, int c) {
 
 // On lf->stream: upload `rows` base points, push the (rows*c, d) stencil stack through the low-fidelity posterior
 // mean.  Leaves the base points in lf->dXc and the means, (rows, c) row-major, in lf->dm.  No host synchronisation.
-static int chain_lf_means(mfgp_handle* lf, const double* Xhost, int64_t rows, const double* offs_host, int c) {
-    hipStream_t s = lf->stream;
+// `s`: the stream everything is enqueued on -- lf's own, or the consuming level's (mfgp_predict_chained: one stream for both
+// levels, no cross-stream hop; nothing else runs on lf meanwhile, every API call ends synchronised).
+static int chain_lf_means(mfgp_handle* lf, const double* Xhost, int64_t rows, const double* offs_host, int c, hipStream_t s) {
     const int d = lf->D;
     const int64_t Np = lf->Np;
     int rc = ensure_chain(lf, rows, c);
@@ -668,8 +669,15 @@ static int chain_lf_means(mfgp_handle* lf, const double* Xhost, int64_t rows, co
     const int64_t T = rows * c;
     rc = ensure_xs(lf, (int)std::min<int64_t>(Np, (T + NB - 1) / NB * NB));
     if (rc) return rc;
-    HIPCHK(lf, hipMemcpyAsync(lf->doffs, offs_host, (size_t)c * d * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(lf, hipMemcpyAsync(lf->dXc, Xhost, (size_t)rows * d * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rows + c) * d <= mfgp_handle::IO_IN) {   // small batch: through pinned memory (see mfgp_predict), copies stay asynchronous
+        memcpy(lf->hio, Xhost, (size_t)rows * d * sizeof(double));
+        memcpy(lf->hio + rows * d, offs_host, (size_t)c * d * sizeof(double));
+        HIPCHK(lf, hipMemcpyAsync(lf->dXc, lf->hio, (size_t)rows * d * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(lf, hipMemcpyAsync(lf->doffs, lf->hio + rows * d, (size_t)c * d * sizeof(double), hipMemcpyHostToDevice, s));
+    } else {
+        HIPCHK(lf, hipMemcpyAsync(lf->doffs, offs_host, (size_t)c * d * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(lf, hipMemcpyAsync(lf->dXc, Xhost, (size_t)rows * d * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     for (int64_t t0 = 0; t0 < T; t0 += Np) {
         const int n = (int)std::min(Np, T - t0);
         const int n_p = (n + NB - 1) / NB * NB;
@@ -702,7 +710,7 @@ int32_t mfgp_augment(mfgp_handle* lf, const double* X, int64_t N, const double* 
     lf->launches = 0;
     for (int64_t r0 = 0; r0 < N; r0 += chunk) {
         const int64_t rows = std::min(chunk, N - r0);
-        rc = chain_lf_means(lf, X + r0 * d, rows, offsets, c);
+        rc = chain_lf_means(lf, X + r0 * d, rows, offsets, c, lf->stream);
         if (rc) return rc;
         launch_assemble_aug(lf->stream, lf->dXc, lf->dm, (int)rows, (int)rows, d, c, lf->dAug, w);
         HIPCHK(lf, hipMemcpyAsync(out + r0 * w, lf->dAug, (size_t)rows * w * sizeof(double), hipMemcpyDeviceToHost,
@@ -737,21 +745,19 @@ int32_t mfgp_predict_chained(mfgp_handle* h, mfgp_handle* lf, const double* Xsta
         const int rows_p = (int)((rows + NB - 1) / NB * NB);
         rc = ensure_xs(h, rows_p);
         if (rc) return rc;
-        rc = chain_lf_means(lf, Xstar + r0 * d, rows, offsets, c);
+        // both levels on THIS level's stream: the low-fidelity means, the augmented rows (straight into this level's panel
+        // input) and this level's predict follow each other in stream order -- no event, no cross-stream hop (~12 us)
+        rc = chain_lf_means(lf, Xstar + r0 * d, rows, offsets, c, h->stream);
         if (rc) return fail(h, rc, std::string("mfgp_predict_chained: low-fidelity level: ") + lf->err);
-        // the augmented rows go straight into this level's panel input; this level's stream waits for them
-        launch_assemble_aug(lf->stream, lf->dXc, lf->dm, (int)rows, rows_p, d, c, h->dXs, D);
+        launch_assemble_aug(h->stream, lf->dXc, lf->dm, (int)rows, rows_p, d, c, h->dXs, D);
         if (aug_out)
             HIPCHK(h, hipMemcpyAsync(aug_out + r0 * D, h->dXs, (size_t)rows * D * sizeof(double), hipMemcpyDeviceToHost,
-                                     lf->stream));
-        HIPCHK(h, hipEventRecord(lf->ev[9], lf->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->stream, lf->ev[9], 0));
+                                     h->stream));
         h->launches += lf->launches + 1;
         lf->launches = 0;
         rc = predict_chunk(h, rows, rows_p, mean + r0, want_var ? var + r0 : nullptr, want_var, include_noise, &pan_ms,
-                           &var_ms);
+                           &var_ms, rows_p <= mfgp_handle::IO_OUT);
         if (rc) return rc;
-        if (aug_out) HIPCHK(h, hipStreamSynchronize(lf->stream));
     }
     predict_account(h, Nstar, pan_ms, var_ms);
     return 0;
