@@ -116,7 +116,7 @@ struct mfgp_handle {
     // small predictive batches (the DIRECT callback, acquisition batches, single-point serving) travel through pinned,
     // device-mapped memory instead of pageable copies: [IO_IN doubles of test rows | IO_OUT means | IO_OUT variances].
     // A hipMemcpyAsync to / from pageable memory is staged and blocks the calling thread (~15-20 us each, three per call).
-    static constexpr int IO_IN = 32768, IO_OUT = 8192;
+    static constexpr int IO_IN = 65536, IO_OUT = 8192;
     double* hio = nullptr;   // host view
     double* dio = nullptr;   // device view
     int* hinfo = nullptr;    // pinned
