@@ -455,8 +455,9 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
         h->xs_cap_D = D;
         HIPCHK(h, hipMalloc(&h->dXs, (size_t)h->xs_cap_rows * D * sizeof(double)));
     }
-    HIPCHK(h, hipMemsetAsync(h->dXs, 0, (size_t)128 * D * sizeof(double), s));
-    HIPCHK(h, hipMemcpyAsync(h->dXs, x_new, (size_t)D * sizeof(double), hipMemcpyHostToDevice, s));
+    memset(h->hio, 0, (size_t)128 * D * sizeof(double));      // (pinned staging: one asynchronous copy, see mfgp_predict)
+    memcpy(h->hio, x_new, (size_t)D * sizeof(double));
+    HIPCHK(h, hipMemcpyAsync(h->dXs, h->hio, (size_t)128 * D * sizeof(double), hipMemcpyHostToDevice, s));
     // k = K(x_new, X[0:n]) -> row 0 of W ; l = X k ; w = X^T l
     launch_kbuild_panel(s, h->spec, h->dXs, 128, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np);
     HIPCHK(h, hipMemsetAsync(h->dvec, 0, (size_t)Np * sizeof(double), s));
