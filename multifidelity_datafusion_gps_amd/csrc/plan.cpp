@@ -517,7 +517,8 @@ static void plan_sweep(Plan& p) {
     // X^T rows sharing the column launch: 4096 2.63 / 2.79 / 2.84, 5120 4.82 / 4.21 / 4.31, 5632 5.80 / 5.46 / 5.36.
     // Up to 13 block columns ONE macro panel (and then one stream and K^-1 on the chain, see the end): N = 1024 0.527 -> 0.42,
     // 1280 0.60 -> 0.55, 1536 0.72 -> 0.68 (1792: 0.825 either way, 2048: 0.94 / 0.99 in favour of two-column panels).
-    int MB = nb >= 96 ? 16 : (nb >= 56 ? 8 : (nb > 40 ? 4 : (nb > 32 ? 3 : (nb > 13 ? 2 : nb))));
+    // Between: 6 for 52 .. 63 block columns (N = 6656 7.96 -> 7.81 ms, 7040 9.35 -> 8.95, 7680 11.3 -> 11.0 against 4 / 8).
+    int MB = nb >= 96 ? 16 : (nb >= 64 ? 8 : (nb >= 52 ? 6 : (nb > 40 ? 4 : (nb > 32 ? 3 : (nb > 13 ? 2 : nb)))));
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;

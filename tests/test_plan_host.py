@@ -78,7 +78,7 @@ def test_schedules_of_the_bench_sizes_are_race_free(simlib, env):
     """race check only (no arithmetic) at the block counts of the BASELINE configurations: 32 (N = 4096), 47 / 48 / 49
     (the slim-chain switch), 64 (N = 8192), 128 (N = 16384), and either side of every size at which the planner's defaults
     change (macro panel length, merged column launch, tile sizes)"""
-    specs = [(nb, 0, 1, 0, 0) for nb in (8, 9, 13, 14, 16, 24, 25, 32, 33, 40, 41, 47, 48, 49, 55, 56, 64, 128)]
+    specs = [(nb, 0, 1, 0, 0) for nb in (8, 9, 13, 14, 16, 24, 25, 32, 33, 40, 41, 47, 48, 49, 51, 52, 55, 56, 63, 64, 128)]
     for spec, (rc, rep, msg) in zip(specs, _run(simlib, specs, env)):
         assert rc == 0 and rep[4] == 0, (spec, msg)
 
