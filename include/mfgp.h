@@ -177,6 +177,8 @@ int32_t mfgp_get_L(mfgp_handle* h, double* out);      /* lower Cholesky factor o
 int32_t mfgp_get_Linv(mfgp_handle* h, double* out);   /* L^-1 lower                                       */
 int32_t mfgp_get_Kinv(mfgp_handle* h, double* out);   /* Ky^-1 full symmetric (valid after a gradient)    */
 int32_t mfgp_get_alpha(mfgp_handle* h, double* out);  /* alpha (N)                                        */
+/* HIP-event times of the last call.  Event records cost stream time, so below N = 4096 none are taken (all times 0) unless
+ * the environment asks at mfgp_set_data: MFGP_TIMING=1 (start / end of a call), MFGP_STAGE_TIMING=1 (stages inside an evaluation). */
 int32_t mfgp_get_timings(mfgp_handle* h, mfgp_timings* out);
 int32_t mfgp_get_counters(mfgp_handle* h, mfgp_counters* out, int32_t reset);
 /* hipDeviceSynchronize on the handle's device: what a benchmark brackets its timed region with (every stream of
