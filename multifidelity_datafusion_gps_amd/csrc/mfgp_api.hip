@@ -309,9 +309,8 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     for (const Step& st : h->pl.steps) run_step(h, st, stream_kinv);
     if (stages) HIPCHK(h, hipEventRecord(h->ev[2], s));
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dY, h->dz, (int)h->Np, (int)h->Np, 0);       // z = X y
-    launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dz, h->dalpha, (int)h->Np, (int)h->Np, 1);   // alpha = X^T z
-    launch_finish_solve(s, h->dz, (int)h->Np, h->dlogdet, h->nblk, h->dres);
-    h->launches += 3;
+    launch_alpha_finish(s, h->buf[BUF_S], (int)h->Np, h->dz, h->dalpha, (int)h->Np, h->dlogdet, h->nblk, h->dres);   // alpha = X^T z; z^T z, log-det
+    h->launches += 2;
     if (stages || (!want_grad && h->timing)) HIPCHK(h, hipEventRecord(h->ev[3], s));
     if (want_grad) {
         if (!stream_kinv) run_step(h, h->pl.kinv_step);   // (streamed plans have accumulated K^-1 behind the chain already)

@@ -70,6 +70,8 @@ void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, co
 //   rowsumsq[i] = sum_{k < ncols} M[i][k]^2
 void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols);
 //   scalars[0] = sum z^2 ; scalars[1] = 2*sum logdet_part ; (single small block)
+void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z, double* alpha, int Np,
+                         const double* logdet_part, int nblk, double* scalars);   // alpha = X^T z + the scalars, one launch
 void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* logdet_part, int nblk,
                          double* scalars);
 //   gradient: partial sums over lower-triangle 64x64 tiles; out[2*nf+1] (natural-parameter gradient of NLML)
