@@ -12,11 +12,18 @@ objective+gradient evaluation budget (--evals, default 20; SURVEY.md 8(d) "fixed
 (`eval_cap`): with scipy's `maxfun` alone a run overshoots by up to a line search, and the total then moves by
 +-8 % with the last bits of the arithmetic (173 vs 188 evaluations between two versions of one kernel).
 
-  python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 is one process per GPU.  Under a launcher (torch.distributed.run exports RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_*) this process IS one rank.  Started as a plain process with --gpus N > 1 it is the launcher: before anything
+touches HIP it starts N copies of itself, one per GPU, with that environment (and a per-job token for the
+rendezvous), waits for them, and exits non-zero if any rank did.  A rank whose RCCL communicator does not come up
+prints the reason and exits non-zero -- an N-GPU line is never produced by a job that fell back to TCP
+(`--single-device` is the explicit rehearsal of the N-rank code path on one GPU; its line says n_gpus = 1).
 
 N > 1 is STRONG scaling of the same job: the randomized restarts and the N* predictive rows are sharded over the
 ranks (sharding.py: rendezvous + tiny object gathers over TCP, device collectives = RCCL inside libmfgp_hip.so; no
-PyTorch anywhere); the LF run is replicated; rank 0 alone runs the sequential first HF run -> restart 0.
+PyTorch anywhere); rank 0 alone runs the sequential first HF run -> restart 0.
 Prints ONE JSON line on rank 0.  `value` = milliseconds per fit+predict (lower is better).
 The CPU comparator (`cpu_baseline`) is the numpy/LAPACK oracle timed on the host cores of the same box
 on a bounded sample (one objective+gradient evaluation per level + the predict products), scaled by the
@@ -161,6 +168,48 @@ def _rate(num, ms):
     return num / (ms * 1e-3) if ms > 0 else 0.0
 
 
+def launch_ranks(n_ranks, argv, script=None):
+    """the --gpus N > 1 job started as a plain process: N child processes of this script, one rank per GPU.  Runs BEFORE
+    this process imports the engine or touches HIP (it never does).  Children inherit stdout / stderr, so rank 0's JSON
+    line is this job's line; returns the exit code of the job (the first non-zero child code, else 0)."""
+    import secrets
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    if port + 1000 >= 65536:
+        port -= 2000
+    base = dict(os.environ)
+    base.update({"WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                 "MFGP_COMM_TOKEN": secrets.token_hex(16)})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
+    procs = []
+    for r in range(n_ranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (procs.index(p), code))
+                for q in live:          # exactly the processes started above: they would wait for ever in a collective
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,8 +226,13 @@ def main():
                     help="rehearsal only: every rank uses GPU 0 (collectives over TCP: RCCL refuses two ranks on one device)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))     # nothing below runs in the launcher; no HIP call was made
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != max(args.gpus, 1):
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        sys.exit(2)
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     # No PyTorch: the host side needs a rendezvous and a few tiny object gathers (sharding.SocketComm, TCP on
     # MASTER_ADDR), the device collectives are RCCL inside libmfgp_hip.so on the engine's own stream.
@@ -197,11 +251,18 @@ def main():
     for j in range(1, args.concurrency + 1 if args.concurrency > 1 else 1):
         engines["hf#%d" % j] = Engine(local_rank)
     collectives = "none (1 rank)"
-    if world > 1:
-        if not args.single_device and comm.attach_engine(engines["hf"]):
-            collectives = "rccl (ncclAllGather on the engine stream; rendezvous + object gathers over tcp)"
-        else:
-            collectives = "tcp (%s)" % getattr(comm, "rccl_error", "single-device rehearsal")
+    if world > 1 and args.single_device:
+        collectives = "tcp (single-device rehearsal: RCCL refuses two ranks on one device)"
+    elif world > 1:
+        try:
+            comm.attach_engine(engines["hf"], required=True)
+        except sharding.RcclInitError as ex:
+            # agreed by every rank over TCP: all of them end here.  No fall-back to TCP: a line that says n_gpus = N
+            # must come from N ranks on RCCL.  os._exit: where the initialisation hangs, its thread never returns.
+            sys.stderr.write("bench.py: rank %d: the RCCL communicator of %d ranks was not created: %s\n" % (rank, world, ex))
+            sys.stderr.flush()
+            os._exit(3)
+        collectives = "rccl (ncclAllGather on the engine stream; rendezvous + object gathers over tcp)"
 
     def barrier():
         engines["hf"].device_synchronize()
@@ -265,7 +326,8 @@ def main():
         kinv_tf = _rate(tot["kinv_flops"], tot["kinv_ms"]) / 1e12
         streamed = tot["kinv_flops"] == 0
         out = {
-            "metric": "gp_fit_predict_wall_ms", "value": round(ms_per_step, 2), "unit": "ms", "n_gpus": world,
+            "metric": "gp_fit_predict_wall_ms", "value": round(ms_per_step, 2), "unit": "ms",
+            "n_gpus": 1 if args.single_device else world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
@@ -277,6 +339,7 @@ def main():
                        "gpu_ms_per_evaluation": round(tot["total_ms"] / max(evals, 1), 3),
                        "wall_ms_per_evaluation": round(ms_per_step * args.steps / max(evals, 1), 3),
                        "restart_concurrency": args.concurrency, "collectives": collectives,
+                       "ranks": world, "rccl_ranks": int(engines["hf"].comm_size),
                        "sharding": "randomized restarts + predictive rows over ranks; LF run replicated; first HF run -> restart 0 on rank 0 only"},
             # the dominant work: ONE sweep per evaluation = Cholesky + triangular inverse%s, timed with HIP events on the
             # engine's main stream around the sweep (the bulk stream joins before the closing event)
@@ -330,9 +393,6 @@ def main():
         engines["hf"].comm_destroy()      # every rank still alive: destroy the communicator before anyone exits
         comm.barrier()
     comm.close()
-    if "did not return" in str(getattr(comm, "rccl_error", "")):
-        sys.stdout.flush()
-        os._exit(0)       # an RCCL initialisation is still stuck in its watchdog thread: do not wait for it at interpreter exit
 
 
 if __name__ == "__main__":

@@ -145,26 +145,43 @@ class Engine:
         implicit = device is None
         if implicit:
             device = int(os.environ.get("LOCAL_RANK", "0"))
-        self._h = ctypes.c_void_p()
-        rc = self._lib.mfgp_create(int(device), ctypes.byref(self._h))
+        self._poisoned = None
+        h = ctypes.c_void_p()
+        rc = self._lib.mfgp_create(int(device), ctypes.byref(h))
         if rc != 0 and implicit and device != 0 and b"bad device id" in self._lib.mfgp_last_error(None):
             # one process per GPU under a launcher that narrows the visible devices per rank: the only device is 0
             device = 0
-            rc = self._lib.mfgp_create(0, ctypes.byref(self._h))
+            rc = self._lib.mfgp_create(0, ctypes.byref(h))
         if rc != 0:
             msg = self._lib.mfgp_last_error(None).decode()
-            self._h = None
+            self._handle = None
             raise EngineUnavailable("mfgp_create(device=%d) failed (%d): %s" % (device, rc, msg))
+        self._handle = h
         self.device = device
         self.n = 0
         self.n_parts = 0
         self.comm_rank, self.comm_size = 0, 1
 
     # -- plumbing -------------------------------------------------------------------------------
+    @property
+    def _h(self):
+        """the C handle; unusable once poisoned (see poison())"""
+        if self._poisoned is not None:
+            raise RuntimeError("engine handle abandoned: " + self._poisoned)
+        return self._handle
+
+    def poison(self, why):
+        """give the handle up without destroying it: another thread is stuck inside a library call on it (an RCCL
+        initialisation that never returned) and the handle is not thread-safe, so no further call may reach it --
+        every method raises from here on, close() leaves it alone, and the process is expected to end."""
+        self._poisoned = str(why)
+
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.mfgp_destroy(self._h)
-            self._h = None
+        if getattr(self, "_poisoned", None) is not None:
+            return
+        if getattr(self, "_handle", None):
+            self._lib.mfgp_destroy(self._handle)
+            self._handle = None
 
     def __del__(self):
         try:

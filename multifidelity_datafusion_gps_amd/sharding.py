@@ -13,14 +13,148 @@ mfgp_allgather_host), on the engine's own stream.  The HOST side needs only a re
 gathers; `SocketComm` does that over plain TCP on 127.0.0.1 (rank 0 is the hub) -- no PyTorch anywhere on the
 product's multi-GPU path.  `TorchComm` remains as the gloo communicator of the CPU tests
 (tests/test_sharding_gloo.py) and is the only place in the package that imports torch.
+
+Wire safety (round 3).  Nothing received from a socket is ever unpickled: frames carry a closed, non-executable
+encoding (`wire_encode` / `wire_decode`: None, bool, int, float, str, bytes, list, tuple, str-keyed dict, numpy
+arrays of plain numeric dtypes).  A connection is admitted to the rendezvous only after a mutual HMAC-SHA256
+challenge-response on a per-job token (MFGP_COMM_TOKEN; without it, a 0600 token file under a 0700 per-user
+directory, single node only), and the hub binds loopback unless a multi-node address is explicitly requested.
 """
+import hashlib
+import hmac
 import os
-import pickle
+import secrets
 import socket
 import struct
 import time
 
 import numpy as np
+
+
+# ---- wire format: a closed set of plain data types, nothing executable ----------------------------------------
+_WIRE_DTYPES = ("<f8", "<f4", "<i8", "<i4", "<u8", "<u4", "|u1", "|b1")
+_WIRE_MAX_FRAME = 1 << 32     # 4 GiB: row blocks of the one-GPU rehearsal travel through here; matrices never do
+
+
+def _enc(obj, out):
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)):
+        out.append(b"i" + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"d" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, str):
+        b = obj.encode("utf-8")
+        out.append(b"s" + struct.pack("<Q", len(b)) + b)
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b"b" + struct.pack("<Q", len(obj)) + bytes(obj))
+    elif isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj)
+        dt = a.dtype.newbyteorder("<").str if a.dtype.byteorder == ">" else a.dtype.str
+        if dt not in _WIRE_DTYPES:
+            raise TypeError("array dtype %s is not part of the wire format" % a.dtype)
+        a = a.astype(np.dtype(dt), copy=False)
+        out.append(b"a" + struct.pack("<BB", _WIRE_DTYPES.index(dt), a.ndim) + struct.pack("<%dQ" % a.ndim, *a.shape))
+        out.append(a.tobytes())
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"l" if isinstance(obj, list) else b"t") + struct.pack("<Q", len(obj)))
+        for v in obj:
+            _enc(v, out)
+    elif isinstance(obj, dict):
+        out.append(b"m" + struct.pack("<Q", len(obj)))
+        for k, v in obj.items():
+            if not isinstance(k, str):
+                raise TypeError("only str keys travel (got %r)" % type(k))
+            _enc(k, out)
+            _enc(v, out)
+    else:
+        raise TypeError("%r is not part of the wire format (plain data only)" % type(obj))
+
+
+def wire_encode(obj):
+    out = []
+    _enc(obj, out)
+    return b"".join(out)
+
+
+def _dec(buf, pos):
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag == b"T":
+        return True, pos
+    if tag == b"F":
+        return False, pos
+    if tag == b"i":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"d":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"s", b"b"):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("truncated frame")
+        raw = bytes(buf[pos:pos + n])
+        return (raw.decode("utf-8") if tag == b"s" else raw), pos + n
+    if tag == b"a":
+        di, nd = struct.unpack_from("<BB", buf, pos)
+        pos += 2
+        if di >= len(_WIRE_DTYPES) or nd > 8:
+            raise ValueError("bad array header")
+        shape = struct.unpack_from("<%dQ" % nd, buf, pos)
+        pos += 8 * nd
+        dt = np.dtype(_WIRE_DTYPES[di])
+        count = 1
+        for v in shape:
+            count *= v
+        nbytes = count * dt.itemsize
+        if nbytes > len(buf) - pos:
+            raise ValueError("truncated frame")
+        a = np.frombuffer(buf, dtype=dt, count=count, offset=pos).reshape(shape).copy()
+        return a, pos + nbytes
+    if tag in (b"l", b"t"):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf) - pos:      # every element takes at least one byte
+            raise ValueError("truncated frame")
+        items = []
+        for _ in range(n):
+            v, pos = _dec(buf, pos)
+            items.append(v)
+        return (items if tag == b"l" else tuple(items)), pos
+    if tag == b"m":
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("truncated frame")
+        d = {}
+        for _ in range(n):
+            k, pos = _dec(buf, pos)
+            if not isinstance(k, str):
+                raise ValueError("bad map key")
+            d[k], pos = _dec(buf, pos)
+        return d, pos
+    raise ValueError("unknown wire tag %r" % tag)
+
+
+def wire_decode(blob):
+    obj, pos = _dec(memoryview(blob), 0)
+    if pos != len(blob):
+        raise ValueError("trailing bytes in frame")
+    return obj
+
+
+class RcclInitError(RuntimeError):
+    """the RCCL communicator could not be created on every rank.  `.hung` says that this rank's ncclCommInitRank never
+    returned: the engine handle is then still in use by the stuck thread and must not be touched again -- the only
+    safe continuation is to end the process (a launcher starts fresh ones)."""
+
+    def __init__(self, msg, hung=False):
+        super().__init__(msg)
+        self.hung = hung
 
 
 class LocalComm:
@@ -61,7 +195,7 @@ class SocketComm:
     counts, timing scalars and the 128-byte RCCL unique id -- never matrices.  With `attach_engine` the row gathers of
     the data path go through RCCL on the engine's stream instead (`transport` says which one is in use)."""
 
-    def __init__(self, rank, size, addr="127.0.0.1", port=29650, timeout=120.0):
+    def __init__(self, rank, size, addr="127.0.0.1", port=29650, timeout=120.0, token=None):
         self.rank, self.size = int(rank), int(size)
         self.transport = "tcp"
         self._engine = None
@@ -69,55 +203,103 @@ class SocketComm:
         self._hub = None       # spoke: socket to rank 0
         if self.size == 1:
             return
+        loopback = addr in ("127.0.0.1", "localhost", "::1")
         if self.rank == 0:
+            key = _job_token(token, port, create=True, loopback=loopback)
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, int(port)))
+            # loopback unless a multi-node address was asked for explicitly (then that interface, never 0.0.0.0)
+            srv.bind(("127.0.0.1" if loopback else addr, int(port)))
             srv.listen(self.size)
-            srv.settimeout(timeout)
+            deadline = time.time() + timeout
             got = {}
             while len(got) < self.size - 1:
-                conn, _ = srv.accept()
+                srv.settimeout(max(deadline - time.time(), 0.01))
+                conn, _ = srv.accept()      # socket.timeout ends a rendezvous that never completes
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(10.0)
+                try:
+                    peer = self._admit(conn, key)
+                except (OSError, ValueError, ConnectionError):
+                    peer = None
+                if peer is None or not (0 < peer < self.size) or peer in got:
+                    conn.close()            # not one of ours (or a duplicate): dropped before anything is decoded
+                    continue
                 conn.settimeout(None)
-                peer = self._recv(conn)
-                got[int(peer)] = conn
+                got[peer] = conn
             srv.close()
             self._peers = [got[r] for r in range(1, self.size)]
         else:
             deadline = time.time() + timeout
             while True:
+                s = None
                 try:
+                    key = _job_token(token, port, create=False, loopback=loopback)
                     s = socket.create_connection((addr, int(port)), timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.settimeout(10.0)
+                    self._introduce(s, key, self.rank)
                     break
-                except OSError:
+                except (OSError, ValueError, ConnectionError):
+                    # hub not up yet, token file not written yet, or a stale token of an earlier job: try again
+                    if s is not None:
+                        s.close()
                     if time.time() > deadline:
                         raise
                     time.sleep(0.05)
-            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(None)
-            self._send(s, self.rank)
             self._hub = s
+
+    # ---- admission: mutual HMAC-SHA256 challenge-response on the job token, fixed-size fields only ----------------
+    @staticmethod
+    def _exactly(sock, n):
+        chunks, left = [], n
+        while left:
+            c = sock.recv(min(left, 1 << 20))
+            if not c:
+                raise ConnectionError("peer closed the connection")
+            chunks.append(c)
+            left -= len(c)
+        return b"".join(chunks)
+
+    @classmethod
+    def _admit(cls, conn, key):
+        """hub side -> the peer's rank, or None when it does not hold the token"""
+        nonce = secrets.token_bytes(16)
+        conn.sendall(b"MFGP1" + nonce)
+        msg = cls._exactly(conn, 4 + 16 + 32)
+        rank = struct.unpack("<I", msg[:4])[0]
+        peer_nonce, mac = msg[4:20], msg[20:]
+        want = hmac.new(key, b"spoke" + nonce + msg[:4] + peer_nonce, hashlib.sha256).digest()
+        if not hmac.compare_digest(mac, want):
+            return None
+        conn.sendall(hmac.new(key, b"hub" + peer_nonce + msg[:4], hashlib.sha256).digest())
+        return rank
+
+    @classmethod
+    def _introduce(cls, sock, key, rank):
+        hello = cls._exactly(sock, 5 + 16)
+        if hello[:5] != b"MFGP1":
+            raise ValueError("not an mfgp rendezvous")
+        mine = secrets.token_bytes(16)
+        r = struct.pack("<I", rank)
+        sock.sendall(r + mine + hmac.new(key, b"spoke" + hello[5:] + r + mine, hashlib.sha256).digest())
+        proof = cls._exactly(sock, 32)      # the hub holds the token too (or the connection is closed on us)
+        if not hmac.compare_digest(proof, hmac.new(key, b"hub" + mine + r, hashlib.sha256).digest()):
+            raise ValueError("the rendezvous hub does not hold the job token")
 
     # ---- framing -----------------------------------------------------------------------------------------
     @staticmethod
     def _send(sock, obj):
-        blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+        blob = wire_encode(obj)
         sock.sendall(struct.pack("<Q", len(blob)) + blob)
 
-    @staticmethod
-    def _recv(sock):
-        def exactly(n):
-            chunks, left = [], n
-            while left:
-                c = sock.recv(min(left, 1 << 20))
-                if not c:
-                    raise ConnectionError("peer closed the connection")
-                chunks.append(c)
-                left -= len(c)
-            return b"".join(chunks)
-        (n,) = struct.unpack("<Q", exactly(8))
-        return pickle.loads(exactly(n))
+    @classmethod
+    def _recv(cls, sock):
+        (n,) = struct.unpack("<Q", cls._exactly(sock, 8))
+        if n > _WIRE_MAX_FRAME:
+            raise ValueError("frame of %d bytes refused" % n)
+        return wire_decode(cls._exactly(sock, n))
 
     # ---- collectives -------------------------------------------------------------------------------------
     def allgather_object(self, obj):
@@ -137,15 +319,21 @@ class SocketComm:
     def barrier(self):
         self.allgather_object(None)
 
-    def attach_engine(self, engine, init_timeout=120.0):
+    def attach_engine(self, engine, init_timeout=120.0, required=False):
         """collective: create the RCCL communicator inside `engine`'s handle (unique id from rank 0 over TCP); from then
-        on the row gathers run as ncclAllGather on that engine's stream.  All or nothing: if the initialisation fails --
-        or does not return within `init_timeout` seconds -- on ANY rank, every rank stays on TCP (a half-attached job
-        would hang in its first collective).  Only the ncclCommInitRank call itself runs under the watchdog; every TCP
-        exchange stays on the calling thread."""
+        on the row gathers run as ncclAllGather on that engine's stream.  All or nothing, agreed over TCP:
+          * every rank's ncclCommInitRank returned and one of them reported an error -> every rank destroys what it
+            created and stays on TCP: returns False (`rccl_error` holds the first reason), or raises RcclInitError when
+            `required` (a benchmark of N GPUs must not quietly become a TCP job);
+          * some rank's initialisation did not return within `init_timeout` seconds -> RcclInitError on EVERY rank, with
+            `.hung` set where the call is still stuck.  There the engine handle stays in use by the stuck thread (the
+            handle is not thread-safe; the thread may write its communicator at any later moment), so it is poisoned
+            -- every further call on it raises -- and the caller must end the process rather than continue on TCP.
+        Only the ncclCommInitRank call itself runs under the watchdog; every TCP exchange stays on the calling thread."""
         import threading
         uid = None
         err = None
+        hung = False
         if self.rank == 0:
             try:
                 uid = engine.comm_unique_id()
@@ -166,16 +354,29 @@ class SocketComm:
             t.start()
             t.join(init_timeout)
             if t.is_alive():
+                hung = True
                 err = "ncclCommInitRank did not return within %.0f s on rank %d" % (init_timeout, self.rank)
+                if hasattr(engine, "poison"):
+                    engine.poison(err)
             elif "err" in box:
                 err = box["err"]
-        errs = [e for e in self.allgather_object(err) if e]
-        if errs:
-            self.rccl_error = errs[0]
-            return False
-        self._engine = engine
-        self.transport = "rccl"
-        return True
+        reports = self.allgather_object((err, hung))
+        errs = [e for e, _ in reports if e]
+        if not errs:
+            self._engine = engine
+            self.transport = "rccl"
+            return True
+        self.rccl_error = errs[0]
+        if any(h for _, h in reports):
+            raise RcclInitError(errs[0], hung=hung)
+        if uid is not None and err is None and getattr(engine, "comm_size", 0) > 1:
+            try:
+                engine.comm_destroy()       # this rank's half of a communicator other ranks failed to join
+            except Exception:  # noqa: BLE001
+                pass
+        if required:
+            raise RcclInitError(errs[0])
+        return False
 
     def allgather_rows(self, arr):
         """concatenate per-rank row blocks (ragged allowed: counts are exchanged first, blocks padded)"""
@@ -209,7 +410,40 @@ def comm_from_env(timeout=120.0):
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     base = int(os.environ.get("MASTER_PORT", "29500"))
     port = int(os.environ.get("MFGP_COMM_PORT", base + 1000 if base + 1000 < 65536 else base - 1000))
-    return SocketComm(rank, size, addr, port, timeout=timeout)
+    return SocketComm(rank, size, addr, port, timeout=timeout, token=os.environ.get("MFGP_COMM_TOKEN"))
+
+
+def _job_token(token, port, create, loopback):
+    """-> the job's HMAC key.  MFGP_COMM_TOKEN (or the `token` argument) when the launcher provides one (bench.py's
+    own launcher does); otherwise, on a single node, rank 0 writes 32 random bytes to a 0600 file in a 0700 per-user
+    directory and the other ranks -- same user, same node -- read it.  A multi-node rendezvous needs the explicit token."""
+    if token:
+        return hashlib.sha256(("mfgp-comm:" + str(token)).encode("utf-8")).digest()
+    if not loopback:
+        raise RuntimeError("a multi-node rendezvous needs MFGP_COMM_TOKEN (a per-job secret shared by the launcher)")
+    base = os.environ.get("XDG_RUNTIME_DIR") or os.path.join("/tmp", "mfgp-comm-%d" % os.getuid())
+    d = os.path.join(base, "mfgp-comm") if os.environ.get("XDG_RUNTIME_DIR") else base
+    path = os.path.join(d, "token-%d" % int(port))
+    if create:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError("%s is not a private directory of this user" % d)
+        key = secrets.token_bytes(32)
+        tmp = "%s.%d" % (path, os.getpid())
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(key)
+        os.replace(tmp, path)
+        return key
+    st = os.stat(d)                          # FileNotFoundError (an OSError): rank 0 is not there yet -> the caller retries
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("%s is not a private directory of this user" % d)
+    with open(path, "rb") as f:
+        key = f.read()
+    if len(key) != 32:
+        raise ValueError("token file incomplete")
+    return key
 
 
 class TorchComm:

@@ -118,3 +118,171 @@ def test_comm_from_env_single_process_is_local(monkeypatch):
     from multifidelity_datafusion_gps_amd import sharding
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     assert isinstance(sharding.comm_from_env(), sharding.LocalComm)
+
+
+# ---- round 3: nothing executable on the wire, admission by job token, a hung RCCL initialisation is fatal -------------
+def test_wire_format_round_trips_plain_data_and_refuses_everything_else():
+    import pickle
+    from multifidelity_datafusion_gps_amd.sharding import wire_decode, wire_encode
+    obj = [(1.5, np.arange(6.0).reshape(2, 3), 4), {"a": None, "b": [True, False, "x", b"\x00\x01"]}, (), -7,
+           np.array([1, 2, 3], dtype=np.int64), np.zeros((0, 4))]
+    back = wire_decode(wire_encode(obj))
+    assert back[0][0] == 1.5 and back[0][2] == 4 and isinstance(back[0], tuple)
+    np.testing.assert_array_equal(back[0][1], obj[0][1])
+    assert back[1] == obj[1] and back[2] == () and back[3] == -7
+    np.testing.assert_array_equal(back[4], obj[4])
+    assert back[4].dtype == np.int64 and back[5].shape == (0, 4)
+    with pytest.raises(TypeError):
+        wire_encode({"f": len})                      # a callable does not travel
+    with pytest.raises(TypeError):
+        wire_encode(np.array([object()]))            # nor does an object array
+    with pytest.raises(ValueError):
+        wire_decode(pickle.dumps({"r": 1}))          # a pickle is not a frame: rejected, never executed
+    with pytest.raises(ValueError):
+        wire_decode(wire_encode([1, 2]) + b"x")      # trailing bytes
+    with pytest.raises(ValueError):
+        wire_decode(b"l" + (2 ** 40).to_bytes(8, "little"))   # a length that the frame cannot hold
+
+
+def _token_worker(rank, world, port, q, token):
+    from multifidelity_datafusion_gps_amd.sharding import SocketComm
+    comm = SocketComm(rank, world, "127.0.0.1", port, timeout=30, token=token)
+    try:
+        q.put((rank, comm.allgather_object(rank)))
+    finally:
+        comm.close()
+
+
+def test_rendezvous_ignores_connections_without_the_job_token():
+    """a stranger that connects to the hub's port -- with garbage, with a pickle, or with a wrong token -- is dropped
+    before anything it sent is decoded, and the job's own ranks still complete the rendezvous"""
+    import pickle
+    import threading
+    import time
+    from multifidelity_datafusion_gps_amd.sharding import SocketComm
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    hub = ctx.Process(target=_token_worker, args=(0, 2, port, q, "job-secret"))
+    hub.start()
+    outcome = {}
+
+    def stranger(kind):
+        deadline = time.time() + 20
+        while time.time() < deadline:
+            try:
+                s = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                break
+            except OSError:
+                time.sleep(0.05)
+        else:
+            outcome[kind] = "no hub"
+            return
+        try:
+            if kind == "pickle":
+                blob = pickle.dumps({"rank": 1})
+                s.sendall(len(blob).to_bytes(8, "little") + blob)
+                s.settimeout(5.0)
+                s.recv(64)            # the hub's challenge; it answers nothing else
+                outcome[kind] = "closed" if s.recv(64) == b"" else "answered"
+            else:
+                SocketComm._introduce(s, b"k" * 32, 1)      # a wrong token
+                outcome[kind] = "admitted"
+        except (OSError, ValueError, ConnectionError):
+            outcome[kind] = "closed"
+        finally:
+            s.close()
+
+    ts = [threading.Thread(target=stranger, args=(k,)) for k in ("pickle", "wrong-token")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert outcome == {"pickle": "closed", "wrong-token": "closed"}
+    spoke = ctx.Process(target=_token_worker, args=(1, 2, port, q, "job-secret"))
+    spoke.start()
+    out = dict(q.get(timeout=60) for _ in range(2))
+    for p in (hub, spoke):
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert out == {0: [0, 1], 1: [0, 1]}
+
+
+def test_token_file_rendezvous_without_an_explicit_token(tmp_path, monkeypatch):
+    """no MFGP_COMM_TOKEN (a plain torch.distributed.run launch): rank 0 writes a 0600 token under a 0700 directory"""
+    import stat
+    monkeypatch.setenv("XDG_RUNTIME_DIR", str(tmp_path))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_token_worker, args=(r, 2, port, q, None)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert out == {0: [0, 1], 1: [0, 1]}
+    d = tmp_path / "mfgp-comm"
+    assert stat.S_IMODE(d.stat().st_mode) == 0o700
+    assert stat.S_IMODE((d / ("token-%d" % port)).stat().st_mode) == 0o600
+
+
+class _HangingEngine(_FakeEngine):
+    def __init__(self, hang, rank):
+        super().__init__(None, rank)
+        self.hang, self.poisoned = hang, None
+
+    def comm_init(self, uid, rank, size):
+        if self.hang:
+            import time
+            time.sleep(3600)
+        self.comm_size = size
+
+    def comm_destroy(self):
+        self.comm_size = 1
+
+    def poison(self, why):
+        self.poisoned = why
+
+
+def _hang_worker(rank, world, port, q):
+    from multifidelity_datafusion_gps_amd.sharding import RcclInitError, SocketComm
+    comm = SocketComm(rank, world, "127.0.0.1", port, timeout=60, token="t")
+    eng = _HangingEngine(rank == 1, rank)
+    try:
+        comm.attach_engine(eng, init_timeout=2.0)
+        q.put((rank, "attached"))
+    except RcclInitError as ex:
+        q.put((rank, ("hung" if ex.hung else "peer hung", eng.poisoned is not None, comm.transport)))
+    finally:
+        comm.close()
+    import os
+    q.close()
+    q.join_thread()  # the queue's feeder thread has flushed
+    os._exit(0)      # what a caller has to do where the initialisation is stuck
+
+
+def test_hung_rccl_initialisation_raises_on_every_rank_and_poisons_the_stuck_handle():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hang_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert out[1] == ("hung", True, "tcp")           # the rank whose call never returned: handle abandoned
+    assert out[0] == ("peer hung", False, "tcp")     # the other rank raises too: nobody continues half-attached
+
+
+def test_required_attach_raises_instead_of_falling_back():
+    from multifidelity_datafusion_gps_amd.sharding import RcclInitError, SocketComm
+    comm = SocketComm(0, 1)
+    comm.size = 1            # a one-rank communicator still goes through the agreement
+    with pytest.raises(RcclInitError):
+        class _E(_FakeEngine):
+            def comm_init(self, uid, rank, size):
+                raise RuntimeError("ncclCommInitRank: invalid usage (test)")
+        comm.attach_engine(_E(), required=True)

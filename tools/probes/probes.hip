@@ -296,6 +296,126 @@ void run_probe_detail(hipStream_t s, double* out) {
     hipEventDestroy(e1);
 }
 
+
+// ---- fp64 MFMA shapes, data dependence and clock (round 3) ------------------------------------------------------------
+// SHAPE 0: v_mfma_f64_16x16x4_f64 (2048 flops), SHAPE 1: v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks, 512 flops).
+// ZERO: all-zero operands (the clock the chip holds depends on operand toggling: MI355X_MICROARCH.md "DVFS give-back").
+// Eight independent accumulators per wave, four rotating operand pairs; stamps: shader cycles (s_memtime) and 100 MHz
+// real time (s_memrealtime) around the loop -> cycles per MFMA per wave, in-kernel clock.  Launches are sized to run
+// >= 20 ms so that GRBM_GUI_ACTIVE / 8 / wall time of a rocprofv3 --pmc pass is a valid effective clock as well.
+__device__ __forceinline__ double probe_operand(unsigned seed) {
+    unsigned long long h = (seed + 1u) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    // sign 0, exponent of 1.0 (or 0.5), 52 random mantissa bits: magnitudes in [0.5, 2), every mantissa bit toggles
+    const unsigned long long bits = ((h & 1ull) ? 0x3FF0000000000000ull : 0x3FE0000000000000ull) | (h >> 12);
+    return __longlong_as_double((long long)bits) * ((h & 2ull) ? 1.0 : -1.0);
+}
+template <int SHAPE, bool ZERO>
+__global__ __launch_bounds__(256) void mfgp_probe_fp64_shape(unsigned long long* out, int iters) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = ZERO ? 0.0 : probe_operand(threadIdx.x * 8 + i + blockIdx.x * 2048);
+        b[i] = ZERO ? 0.0 : probe_operand(threadIdx.x * 8 + 4 + i + blockIdx.x * 2048);
+    }
+    d4_t acc[8];
+    double acc1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc1[i] = 0.0; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (SHAPE == 0) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+            else acc1[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i & 3], b[(i >> 1) & 3], acc1[i], 0, 0, 0);
+        }
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (SHAPE == 0) ? acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] : acc1[i];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        out[2 * w] = t1 - t0 + (s == 12345.678 ? 1 : 0);
+        out[2 * w + 1] = r1 - r0;
+    }
+}
+
+// out[4*c + 0..3] = {TFLOP/s, shader cycles per MFMA per wave (median), in-kernel clock GHz (median), launch ms}
+//   c = 0: 16x16x4 random 1 wave/SIMD   1: 16x16x4 random 2 w/SIMD   2: 16x16x4 random 4 w/SIMD   3: 16x16x4 ZERO 4 w/SIMD
+//   c = 4: 4x4x4_4b random 1 w/SIMD     5: 4x4x4_4b random 2 w/SIMD  6: 4x4x4_4b random 4 w/SIMD  7: 4x4x4_4b ZERO 4 w/SIMD
+void run_probe_fp64_shapes(hipStream_t s, double* out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    unsigned long long* dbuf = nullptr;
+    const int maxw = 1024 * 4;
+    hipMalloc(&dbuf, sizeof(unsigned long long) * 2 * maxw);
+    std::vector<unsigned long long> hb(2 * maxw);
+    for (int c = 0; c < 8; ++c) {
+        const int shape = c / 4, v = c % 4;
+        const int blocks = (v == 0) ? 256 : (v == 1) ? 512 : 1024;
+        const bool zero = (v == 3);
+        // ~25-45 ms per launch: 16x16x4 ~100-140 cycles per MFMA, 4x4x4 unknown (16-64): iterations per wave chosen per shape
+        const int iters = (shape == 0 ? 64000 : 256000) / (blocks / 256);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, s);
+            if (shape == 0 && !zero) hipLaunchKernelGGL((mfgp_probe_fp64_shape<0, false>), dim3(blocks), dim3(256), 0, s, dbuf, iters);
+            else if (shape == 0) hipLaunchKernelGGL((mfgp_probe_fp64_shape<0, true>), dim3(blocks), dim3(256), 0, s, dbuf, iters);
+            else if (!zero) hipLaunchKernelGGL((mfgp_probe_fp64_shape<1, false>), dim3(blocks), dim3(256), 0, s, dbuf, iters);
+            else hipLaunchKernelGGL((mfgp_probe_fp64_shape<1, true>), dim3(blocks), dim3(256), 0, s, dbuf, iters);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+        }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const int nw = blocks * 4;
+        hipMemcpy(hb.data(), dbuf, sizeof(unsigned long long) * 2 * nw, hipMemcpyDeviceToHost);
+        std::vector<double> cyc(nw), clk(nw);
+        const double nm = (double)iters * 8.0;
+        for (int w = 0; w < nw; ++w) {
+            cyc[w] = (double)hb[2 * w] / nm;
+            clk[w] = (double)hb[2 * w] / ((double)hb[2 * w + 1] * 10.0);
+        }
+        std::sort(cyc.begin(), cyc.end());
+        std::sort(clk.begin(), clk.end());
+        out[4 * c + 0] = (double)nw * nm * (shape == 0 ? 2048.0 : 512.0) / (ms * 1e-3) / 1e12;
+        out[4 * c + 1] = cyc[nw / 2];
+        out[4 * c + 2] = clk[nw / 2];
+        out[4 * c + 3] = ms;
+    }
+    hipFree(dbuf);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+}
+
+// ---- operand / result layout of v_mfma_f64_4x4x4_4b_f64, and whether its A-broadcast controls (CBSZ / ABID) act on f64 ----
+template <int CBSZ, int ABID>
+__global__ __launch_bounds__(64) void mfgp_probe_mfma444_layout(const double* a, const double* b, const double* c, double* d) {
+    const int l = threadIdx.x;
+    d[l] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[l], b[l], c[l], CBSZ, ABID, 0);
+}
+void run_probe_444_layout(hipStream_t s, const double* a, const double* b, const double* c, double* out7x64) {
+    double *da, *db, *dc, *dd;
+    hipMalloc(&da, 512); hipMalloc(&db, 512); hipMalloc(&dc, 512); hipMalloc(&dd, 7 * 512);
+    hipMemcpyAsync(da, a, 512, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(db, b, 512, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(dc, c, 512, hipMemcpyHostToDevice, s);
+    hipLaunchKernelGGL((mfgp_probe_mfma444_layout<0, 0>), dim3(1), dim3(64), 0, s, da, db, dc, dd + 0 * 64);
+    hipLaunchKernelGGL((mfgp_probe_mfma444_layout<1, 0>), dim3(1), dim3(64), 0, s, da, db, dc, dd + 1 * 64);
+    hipLaunchKernelGGL((mfgp_probe_mfma444_layout<1, 1>), dim3(1), dim3(64), 0, s, da, db, dc, dd + 2 * 64);
+    hipLaunchKernelGGL((mfgp_probe_mfma444_layout<2, 0>), dim3(1), dim3(64), 0, s, da, db, dc, dd + 3 * 64);
+    hipLaunchKernelGGL((mfgp_probe_mfma444_layout<2, 1>), dim3(1), dim3(64), 0, s, da, db, dc, dd + 4 * 64);
+    hipLaunchKernelGGL((mfgp_probe_mfma444_layout<2, 2>), dim3(1), dim3(64), 0, s, da, db, dc, dd + 5 * 64);
+    hipLaunchKernelGGL((mfgp_probe_mfma444_layout<2, 3>), dim3(1), dim3(64), 0, s, da, db, dc, dd + 6 * 64);
+    hipMemcpyAsync(out7x64, dd, 7 * 512, hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    hipFree(da); hipFree(db); hipFree(dc); hipFree(dd);
+}
+
 void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -343,6 +463,25 @@ int32_t mfgp_probe_basic(int32_t device, double* out2) {
     hipStream_t s;
     if (hipStreamCreate(&s) != hipSuccess) return -2;
     mfgp::run_probe(s, out2, out2 + 1);
+    hipStreamSynchronize(s);
+    hipStreamDestroy(s);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// a, b, c: one fp64 per lane (64 each); out: 7 x 64 results for (CBSZ, ABID) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (2,3)
+int32_t mfgp_probe_mfma444_layout(int32_t device, const double* a, const double* b, const double* c, double* out7x64) {
+    if (!a || !b || !c || !out7x64 || hipSetDevice(device) != hipSuccess) return -1;
+    hipStream_t s;
+    if (hipStreamCreate(&s) != hipSuccess) return -2;
+    mfgp::run_probe_444_layout(s, a, b, c, out7x64);
+    hipStreamDestroy(s);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// out32: see tools/probes/probes.py (fp64_shapes) for the layout
+int32_t mfgp_probe_fp64_shapes(int32_t device, double* out32) {
+    if (!out32 || hipSetDevice(device) != hipSuccess) return -1;
+    hipStream_t s;
+    if (hipStreamCreate(&s) != hipSuccess) return -2;
+    mfgp::run_probe_fp64_shapes(s, out32);
     hipStreamSynchronize(s);
     hipStreamDestroy(s);
     return hipGetLastError() == hipSuccess ? 0 : -2;

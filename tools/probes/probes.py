@@ -11,7 +11,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 def _lib():
     lib = ctypes.CDLL(LIB)
-    for name in ("mfgp_probe_basic", "mfgp_probe_detail"):
+    for name in ("mfgp_probe_basic", "mfgp_probe_detail", "mfgp_probe_fp64_shapes"):
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int32
         fn.argtypes = [ctypes.c_int32, _dp]
@@ -45,6 +45,23 @@ def detail(device=0):
     return d
 
 
+def fp64_shapes(device=0):
+    """bare fp64 MFMA loops by instruction shape, wave count and operand data (round 3): per configuration TFLOP/s,
+    shader cycles per MFMA per wave (s_memtime, median over waves), in-kernel clock (s_memtime / s_memrealtime), launch ms"""
+    out = np.zeros(32)
+    rc = _lib().mfgp_probe_fp64_shapes(int(device), out.ctypes.data_as(_dp))
+    if rc:
+        raise RuntimeError("mfgp_probe_fp64_shapes failed (%d)" % rc)
+    names = ["16x16x4 random 1w/SIMD", "16x16x4 random 2w/SIMD", "16x16x4 random 4w/SIMD", "16x16x4 ZERO 4w/SIMD",
+             "4x4x4_4b random 1w/SIMD", "4x4x4_4b random 2w/SIMD", "4x4x4_4b random 4w/SIMD", "4x4x4_4b ZERO 4w/SIMD"]
+    return {n: dict(tflops=round(out[4 * i], 2), cycles_per_mfma_per_wave=round(out[4 * i + 1], 2),
+                    clock_ghz=round(out[4 * i + 2], 3), launch_ms=round(out[4 * i + 3], 2)) for i, n in enumerate(names)}
+
+
 if __name__ == "__main__":
     import json
-    print(json.dumps({"basic": basic(), "detail": detail()}, indent=1))
+    import sys
+    if "shapes" in sys.argv[1:]:
+        print(json.dumps({"fp64_shapes": fp64_shapes()}, indent=1))
+    else:
+        print(json.dumps({"basic": basic(), "detail": detail(), "fp64_shapes": fp64_shapes()}, indent=1))
