@@ -2,10 +2,22 @@
 //
 // One workgroup (8 waves, 4x2) computes one BM x BN output tile described by a GemmTask:
 //     C = beta*C + alpha * A[i0.., k0..k0+klen) * B[j0.., k0'..)^T          ("NT": both K-contiguous)
-// on v_mfma_f64_16x16x4_f64.  Cholesky panel solves (as products with the running inverse), SYRK
-// trailing updates, the triangular inverse, K^-1 = L^-T L^-1 and the predictive-variance product
+// on v_mfma_f64_4x4x4_4b_f64 (round 3; v_mfma_f64_16x16x4_f64 before).  Cholesky panel solves (as products with the
+// running inverse), SYRK trailing updates, the triangular inverse, K^-1 = L^-T L^-1 and the predictive-variance product
 // are all expressed as lists of such tasks (see plan.cpp); triangular structure = trimmed K ranges
 // plus one masked diagonal window.
+//
+// Why the 4x4x4 shape (profiles/r03_probes.txt, r03_mfma_counters.json): on gfx950 a v_mfma_f64_16x16x4 occupies the
+// matrix pipe for 64 cycles (SQ_VALU_MFMA_BUSY_CYCLES / instruction) but issues only every ~100 (1, 2 or 4 waves per
+// SIMD alike): 46-49 TFLOP/s, pipe 0.6 busy.  v_mfma_f64_4x4x4_4b (four independent 4x4x4 blocks, 512 flops) takes 16
+// busy cycles and issues every 17.5 from ONE wave per SIMD: 71 TFLOP/s bare, 0.9 of the 78.6 TFLOP/s vendor figure.
+// Its operands sit in the lanes exactly like the 16x16x4 fragments (lane = 16 k + r: element [row r][k]), and block b
+// multiplies rows 4b..4b+3 of the A fragment with rows 4b..4b+3 of the B fragment: the four block DIAGONALS of a
+// 16x16x4 product.  Reading the A fragment four times with its row blocks rotated (s = 0..3: lane r takes row
+// (r + 4s) mod 16 -- the same addresses as the plain fragment, permuted among the lanes, so the swizzled image is
+// conflict-free for them too) gives the whole product in four instructions: the result of rotation s in lane
+// (i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3) is C[4 ((b + s) & 3) + i][4 b + j].  (CBSZ / ABID do not broadcast
+// blocks for f64 -- measured: they act as |A| / |B| modifiers -- hence the rotated reads.)
 //
 // Replaces LAPACK dpotrf/dtrtri/dpotri/dgemm behind GPy's pdinv / Posterior (SURVEY.md 8(a) a4,a7,a11).
 //
@@ -17,6 +29,10 @@
 #include "mfgp_internal.h"
 
 namespace mfgp {
+
+#ifndef MFGP_MFMA_444
+#define MFGP_MFMA_444 1   // 0: the v_mfma_f64_16x16x4 body of rounds 1-2 (kept for A/B measurements and cross-checks)
+#endif
 
 template <int BM, int BN, int WM, int WN, int NBUF = 2, int KT = BK>
 __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, const double* B, double* C, double* C2,
@@ -48,7 +64,14 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
     const int a_lo_shift = t.klen - BM, b_lo_shift = t.klen - BN;
 
     d2_t ra[NA], rb[NBC];
+#if MFGP_MFMA_444
+    // acc[mi][ni][s]: rotation s of the 16x16 block (mi, ni); this lane's element is
+    //   row 16 mi + 4 ((cb + s) & 3) + q,  column 16 ni + fr      (q = lane >> 4, cb = (lane >> 2) & 3, fr = lane & 15)
+    double acc[TM][TN][4];
+    const int cb = (lane >> 2) & 3;
+#else
     d4_t acc[TM][TN];
+#endif
     // Accumulating tasks (beta != 0: the trailing updates C -= A B^T) start from the output tile itself: acc = (beta/alpha) C is
     // loaded HERE, its latency hidden behind the first operand loads, instead of a read-modify-write epilogue that every
     // workgroup pays exposed at the end (a 128x128 tile is 128 KB in and 128 KB out at ~25 GB/s per CU: ~5 us each way
@@ -63,22 +86,45 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
             if (preload) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+#if MFGP_MFMA_444
+                    const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb + r) & 3) + q;
+#else
                     const int row = wm * (BM / WM) + mi * 16 + q + 4 * r;
+#endif
                     const int col = wn * (BN / WN) + ni * 16 + fr;
                     acc[mi][ni][r] = c_scale * Cp[(int64_t)row * ld + col];
                 }
             } else {
-                acc[mi][ni] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
             }
         }
 
+    // Global -> registers: raw 16-byte loads only, so that they stay in flight across the MFMA phase; the triangular masks
+    // (task-uniform flags; most tasks carry none) are applied when the registers are written to LDS, after the compute
+    // phase.  (Rounds 1-2 masked right after the load: every K-step then waited for its NEXT operands before it started.)
+    const bool any_mask = (t.flags & (TF_A_LOWER | TF_A_UPPER | TF_B_LOWER | TF_B_UPPER)) != 0;
     auto load_tiles = [&](int kt) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int g = tid + NT * u;
             const int row = g / CPR, c = g % CPR;
+            ra[u] = *reinterpret_cast<const d2_t*>(Ap + (int64_t)row * ld + kt * KT + 2 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int g = tid + NT * u;
+            const int row = g / CPR, c = g % CPR;
+            rb[u] = *reinterpret_cast<const d2_t*>(Bp + (int64_t)row * ld + kt * KT + 2 * c);
+        }
+    };
+    auto mask_tiles = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int g = tid + NT * u;
+            const int row = g / CPR, c = g % CPR;
             const int k = kt * KT + 2 * c;
-            d2_t v = *reinterpret_cast<const d2_t*>(Ap + (int64_t)row * ld + k);
+            d2_t v = ra[u];
             if (a_lo) {
                 if (k > row + a_lo_shift) v.x = 0.0;
                 if (k + 1 > row + a_lo_shift) v.y = 0.0;
@@ -94,7 +140,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
             const int g = tid + NT * u;
             const int row = g / CPR, c = g % CPR;
             const int k = kt * KT + 2 * c;
-            d2_t v = *reinterpret_cast<const d2_t*>(Bp + (int64_t)row * ld + k);
+            d2_t v = rb[u];
             if (b_lo) {
                 if (k > row + b_lo_shift) v.x = 0.0;
                 if (k + 1 > row + b_lo_shift) v.y = 0.0;
@@ -106,7 +152,8 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
             rb[u] = v;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int kt) {
+        if (any_mask) mask_tiles(kt);
         double* as = As + buf * (BM * KT);
         double* bs = Bs + buf * (BN * KT);
 #pragma unroll
@@ -122,6 +169,40 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
             *reinterpret_cast<d2_t*>(bs + row * KT + ((c ^ (row & SWM)) << 1)) = rb[u];
         }
     };
+#if MFGP_MFMA_444
+    auto compute = [&](int buf) {
+        const double* as = As + buf * (BM * KT) + (wm * (BM / WM)) * KT;
+        const double* bs = Bs + buf * (BN * KT) + (wn * (BN / WN) + fr) * KT;
+        // Eight columns per round: lane (fr, q) fetches the 16-byte chunk 4 g + q of its row -- columns 8 g + 2 q and
+        // 8 g + 2 q + 1 -- with ONE ds_read_b128 and feeds the first half to one MFMA step and the second to the next:
+        // a step's four k-slots are then columns 8 g + {0, 2, 4, 6} (resp. {1, 3, 5, 7}), the same for both operands.
+        // (Bank check, ds_read_b128 lane groups {0-3,12-15,20-27} ...: 8 lanes of slot q on rows R, 8 of slot q + 1 on the
+        // complement of R mod 16; chunk ^ row maps them to 16 distinct 16-byte slots for KT = 32 and for KT = 16.)
+#pragma unroll
+        for (int g = 0; g < KT / 8; ++g) {
+            d2_t a[TM][4], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mi * 16 + ((fr + 4 * r) & 15);
+                    a[mi][r] = *reinterpret_cast<const d2_t*>(as + row * KT + (((4 * g + q) ^ (row & SWM)) << 1));
+                }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                b[ni] = *reinterpret_cast<const d2_t*>(bs + ni * 16 * KT + (((4 * g + q) ^ (fr & SWM)) << 1));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mi][ni][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[mi][r][h], b[ni][h], acc[mi][ni][r], 0, 0, 0);
+        }
+    };
+#else
     auto compute = [&](int buf) {
         const double* as = As + buf * (BM * KT) + (wm * (BM / WM) + fr) * KT + (q & 1);
         const double* bs = Bs + buf * (BN * KT) + (wn * (BN / WN) + fr) * KT + (q & 1);
@@ -141,16 +222,19 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     };
+#endif
 
     load_tiles(0);
-    store_tiles(0);
+    store_tiles(0, 0);
     __syncthreads();
     if constexpr (NBUF == 2) {
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = (kt + 1 < nk);
             if (more) load_tiles(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);      // the loads are issued before, and not waited for until after, the MFMAs
             compute(kt & 1);
-            if (more) store_tiles((kt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) store_tiles((kt + 1) & 1, kt + 1);
             __syncthreads();
         }
     } else {
@@ -159,14 +243,16 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = (kt + 1 < nk);
             if (more) load_tiles(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
             compute(0);
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
-            if (more) store_tiles(0);
+            if (more) store_tiles(0, kt + 1);
             __syncthreads();
         }
     }
 
-    // epilogue: v_mfma_f64_16x16x4 C/D layout: D[row = q + 4*reg][col = fr]
+    // epilogue.  v_mfma_f64_16x16x4 C/D layout: D[row = q + 4*reg][col = fr]; the 4x4x4 form: see acc above
     const double alpha = t.alpha;
     const bool mirror = (t.c2_off >= 0);
     double* C2p = C2 + (mirror ? t.c2_off : 0);
@@ -176,7 +262,11 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#if MFGP_MFMA_444
+                const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb + r) & 3) + q;
+#else
                 const int row = wm * (BM / WM) + mi * 16 + q + 4 * r;
+#endif
                 const int col = wn * (BN / WN) + ni * 16 + fr;
                 const double v = alpha * acc[mi][ni][r];
                 Cp[(int64_t)row * ld + col] = v;
