@@ -53,6 +53,50 @@ def test_golden_vectors(engine, name):
     np.testing.assert_allclose(var, g["var"], rtol=0, atol=ytol)
 
 
+def _extended_precision_variance(K, noise, Kx, kss):
+    """latent predictive variance with the Cholesky and the solves carried out in x87 extended precision (64-bit mantissa):
+    a yardstick for the add_noise regime, where every fp64 form has lost digits (tiny N only: plain loops)"""
+    n = K.shape[0]
+    A = K.astype(np.longdouble) + np.longdouble(noise + 1e-8) * np.eye(n, dtype=np.longdouble)
+    L = np.zeros_like(A)
+    for j in range(n):
+        L[j, j] = np.sqrt(A[j, j] - np.dot(L[j, :j], L[j, :j]))
+        for i in range(j + 1, n):
+            L[i, j] = (A[i, j] - np.dot(L[i, :j], L[j, :j])) / L[j, j]
+    V = np.zeros(Kx.shape, dtype=np.longdouble)
+    Kxl = Kx.astype(np.longdouble)
+    for i in range(n):
+        V[i] = (Kxl[i] - L[i, :i] @ V[:i]) / L[i, i]
+    return np.asarray(np.longdouble(kss) - np.sum(V * V, axis=0), dtype=np.float64)
+
+
+def test_add_noise_regime_against_both_predictive_forms(engine):
+    """sigma_n^2 = 1e-6 (what MultifidelityDataFusion.predict installs with add_noise=True, src/MFDataFusion.py:154-155):
+    the stated tolerance (1e-6 max(1, |y|)) must cover the distance to what the REFERENCE returns -- GPy's explicit-inverse
+    form, oracle `predict` -- and not only to the better-conditioned triangular form the other tests compare with
+    (`predict_stable`).  An extended-precision evaluation says which of the three is closest to the exact value."""
+    g = np.load(os.path.join(GOLD, "rbf_addnoise_n60.npz"))
+    parts = [tuple(int(v) for v in p) for p in g["parts"]]
+    theta, noise = g["theta"], float(g["noise"])
+    assert noise <= 1e-5
+    engine.set_data(g["X"], g["Y"]); engine.set_kernel(parts)
+    engine.eval(theta, noise, 1e-8, want_grad=False)
+    mean, var = engine.predict(g["Xs"], want_var=True, include_noise=False)
+    st = orc.inference(parts, theta, noise, g["X"], g["Y"], want_grad=False)
+    mu_e, var_e = orc.predict(parts, theta, noise, g["X"], st, g["Xs"], include_noise=False)           # GPy's form
+    mu_s, var_s = orc.predict_stable(parts, theta, noise, g["X"], st, g["Xs"], include_noise=False)    # triangular form
+    tol = 1e-6 * max(1.0, np.abs(g["Y"]).max())
+    np.testing.assert_allclose(mean, mu_e, rtol=0, atol=tol)
+    np.testing.assert_allclose(var, np.maximum(var_e, 1e-15), rtol=0, atol=tol)      # vs what the reference returns
+    np.testing.assert_allclose(var, var_s, rtol=0, atol=tol)
+    exact = np.maximum(_extended_precision_variance(st["K"], noise, orc.cov(parts, theta, g["X"], g["Xs"]),
+                                                    orc.cov_diag(parts, theta, 1)[0]), 1e-15)
+    d_hip, d_gpy, d_tri = (np.abs(v - exact).max() for v in (var, np.maximum(var_e, 1e-15), var_s))
+    print("add_noise regime, max |var - extended precision|: HIP %.2e, explicit inverse (GPy form) %.2e, triangular %.2e"
+          % (d_hip, d_gpy, d_tri))
+    assert d_hip <= tol and d_hip <= 10 * max(d_gpy, d_tri, 1e-14)    # the HIP path is not the outlier of the three
+
+
 def test_kinv_and_state_machine(engine):
     c = cases.make_case("nargp_4d_n64")
     engine.set_data(c["X"], c["Y"])
@@ -454,7 +498,7 @@ def test_skinny_variance_path_for_small_batches(engine, N):
     parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01
     engine.set_data(Xa, Y); engine.set_kernel(parts)
     engine.factorize(theta, noise)
-    st = orc.inference(parts, theta, noise, Xa, Y, want_grad=False)
+    st = orc.inference(parts, theta, noise, Xa, Y, want_grad=True)
     Xs_all = rng.uniform(size=(80, 5))
     m_big, v_big = engine.predict(Xs_all)                 # 80 rows: tile-GEMM path
     for ns in (1, 2, 16, 17, 32, 33, 64):
@@ -468,8 +512,13 @@ def test_skinny_variance_path_for_small_batches(engine, N):
         assert np.array_equal(v, v2)                          # deterministic
     # the gradient after a skinny predict is still right (V overwrote the K^-1 storage -> recomputed lazily)
     nlml, grad = engine.eval(theta, noise, 1e-8, want_grad=True)
-    fo, go = st["nlml"], None
-    assert nlml == pytest.approx(fo, rel=1e-10)
+    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
+    assert np.abs(grad - st["grad"]).max() <= 1e-8 * np.abs(st["grad"]).max()
+    # ... and without a refactorisation in between: a lazy gradient straight after a skinny predict
+    engine.factorize(theta, noise)
+    engine.predict(Xs_all[:3])
+    lazy = engine.nlml_grad()
+    assert np.abs(lazy - st["grad"]).max() <= 1e-8 * np.abs(st["grad"]).max()
 
 
 def test_cfg2_single_rbf_n4096_against_oracle(engine):

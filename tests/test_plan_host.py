@@ -89,3 +89,38 @@ def test_the_checker_catches_a_dropped_dependency(simlib):
     assert no_chain_wait[0] == 1 and no_chain_wait[1][4] > 0 and "race" in no_chain_wait[2]
     assert no_join[0] == -3 and "not joined" in no_join[2]
     assert no_leaf_wait[0] == 1 and no_leaf_wait[1][4] > 0
+
+
+# ---- the same planner + checker under AddressSanitizer / UndefinedBehaviorSanitizer (CPU build) -------------
+ASAN_BIN = os.path.join(ROOT, "tests", "host_plan", "plan_sim_asan")
+ASAN_SRC = SRC + [os.path.join(ROOT, "tests", "host_plan", "plan_sim_main.cpp")]
+
+
+@pytest.fixture(scope="module")
+def asan_bin():
+    deps = ASAN_SRC + [os.path.join(ROOT, "multifidelity_datafusion_gps_amd", "csrc", "plan.h")]
+    if not os.path.exists(ASAN_BIN) or any(os.path.getmtime(d) > os.path.getmtime(ASAN_BIN) for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-fno-omit-frame-pointer", "-o", ASAN_BIN] + ASAN_SRC, check=True)
+    return ASAN_BIN
+
+
+@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2"}, {"MFGP_SHIFT": "0"}, {"MFGP_PLAN": "levels"},
+                                 {"MFGP_PLAN": "recursive"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_planner_and_checker_are_clean_under_asan_and_ubsan(asan_bin, env):
+    """heap / stack overflows, use after free, signed overflow, misaligned or out-of-range accesses in plan.cpp while it
+    plans and while its plans are executed: numeric plans up to 9 block columns, schedules up to 128 (N = 16384)"""
+    specs = [(nb, 1, g, 128 if nb % 2 else 0, 0) for nb in (1, 2, 3, 5, 9) for g in (0, 1)]
+    specs += [(nb, 0, 1, 0, 0) for nb in (13, 14, 32, 48, 49, 64, 128)]
+    e = dict(os.environ)
+    e.update(env)
+    e["ASAN_OPTIONS"] = "detect_leaks=1:abort_on_error=0:exitcode=97"
+    e["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    r = subprocess.run([asan_bin] + [str(v) for spec in specs for v in spec], env=e, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(specs)
+    for spec, line in zip(specs, lines):
+        assert line.split()[0] == "0", (spec, line)

@@ -214,7 +214,7 @@ __device__ __forceinline__ void gemm444_pipe(const GemmTask t, const double* A, 
 // ---- glds variant: the tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass);
 // the chunk swizzle sits on the per-lane SOURCE address (the LDS image of one wave-instruction is lane-linear: 4 rows x 256 B);
 // triangular masks are a fix-up of the landed chunks (zeros written by the lane that fetched them) before the barrier.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int LDS_SHIFT = 0>
 __device__ __forceinline__ void gemm444_glds(const GemmTask t, const double* A, const double* B, double* C, double* C2, int ld) {
     constexpr int KT = 32;
     constexpr int NW = WM * WN;
@@ -222,7 +222,7 @@ __device__ __forceinline__ void gemm444_glds(const GemmTask t, const double* A, 
     constexpr int NA = BM / (4 * NW), NBC = BN / (4 * NW);      // wave-instructions (4 rows each) per wave and K-step
     static_assert(NA >= 1 && NBC >= 1, "tile too small for the wave count");
     extern __shared__ __attribute__((aligned(1024))) double smem[];
-    char* const smem_b = reinterpret_cast<char*>(smem);
+    char* const smem_b = reinterpret_cast<char*>(smem) + LDS_SHIFT;      // LDS_SHIFT: probe of the DMA's reach (M0 width)
     constexpr int A_BYTES = BM * KT * 8, B_BYTES = BN * KT * 8;
     constexpr int B_BASE = 2 * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -396,6 +396,186 @@ __device__ __forceinline__ void gemm444_glds(const GemmTask t, const double* A, 
             }
 }
 
+// ---- occupancy-2 variant: 4 waves per workgroup (2 x 2, wave tile 64 x 64), K-steps of 16 columns, two 32 KB LDS stages =
+// 64 KB per workgroup, <= 256 VGPRs: TWO workgroups per CU, so that one's barriers, C pre-load and epilogue run under the
+// other's MFMAs.  LDS-DMA staging as in gemm444_glds; fragments are read per 8-column group without register double buffering
+// (the other workgroup's wave on the same SIMD covers the LDS latency).  SRC_WRAP (probe): take every K-step's operands from
+// the first two K-steps (L2-resident) to tell the fabric's share.
+template <int BM, int BN, int WM, int WN, int KT, int NST, bool SRC_WRAP>
+__device__ __forceinline__ void gemm444_occ2(const GemmTask t, const double* A, const double* B, double* C, double* C2, int ld) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);
+    constexpr int ROWB = KT * 8;                 // bytes per tile row and stage
+    constexpr int CPR = KT / 2, SWM = CPR - 1;   // 16-byte chunks per row
+    constexpr int RPI = 1024 / ROWB;             // tile rows per DMA wave-instruction (1 KiB)
+    constexpr int NA = BM / (RPI * NW), NBC = BN / (RPI * NW);
+    constexpr int NG = KT / 8;
+    static_assert(NA >= 1 && NBC >= 1 && (KT == 16 || KT == 32), "shape");
+    static_assert((RPI * NW) % 16 == 0 || RPI * NW == 8, "row blocks per wave must keep the swizzle phase constant");
+    extern __shared__ __attribute__((aligned(1024))) double smem[];
+    char* const smem_b = reinterpret_cast<char*>(smem);
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int B_BASE = NST * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, q = lane >> 4, cb = (lane >> 2) & 3;
+    const double* Ap = A + t.a_off;
+    const double* Bp = B + t.b_off;
+    const int nk = t.klen / KT;
+    const bool a_lo = t.flags & TF_A_LOWER, a_up = t.flags & TF_A_UPPER;
+    const bool b_lo = t.flags & TF_B_LOWER, b_up = t.flags & TF_B_UPPER;
+    const bool any_mask = (t.flags & 15) != 0;
+    const int a_lo_shift = t.klen - BM, b_lo_shift = t.klen - BN;
+
+    double acc[TM][TN][4];
+    double* const Cp = C + t.c_off;
+    const bool preload = (t.beta != 0.0);
+    const double c_scale = preload ? t.beta / t.alpha : 0.0;
+    if (preload) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb + r) & 3) + q;
+                    const int col = wn * (BN / WN) + ni * 16 + fr;
+                    acc[mi][ni][r] = c_scale * Cp[(int64_t)row * ld + col];
+                }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
+    }
+    // DMA: wave-instruction u covers rows r0 = RPI (wave + NW u) .. r0 + RPI - 1; lane l -> row r0 + l / CPR, slot l % CPR
+    const int dl_row = lane / CPR, dl_slot = lane % CPR;
+    const int drow = ((RPI * wave) + dl_row) & SWM;              // (row & SWM) of this lane's DMA rows (RPI NW u = 0 mod CPR)
+    const unsigned dma_goff = (unsigned)(dl_row * ld + 2 * (dl_slot ^ drow));
+    auto dma_tiles = [&](int kt, int st) {
+        const int ks = SRC_WRAP ? (kt & 1) : kt;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int r0 = RPI * (wave + NW * u);
+            __builtin_amdgcn_global_load_lds(Ap + (int64_t)r0 * ld + ks * KT + dma_goff,
+                                             (lds_ptr_t)(smem_b + st * A_BYTES + r0 * ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int r0 = RPI * (wave + NW * u);
+            __builtin_amdgcn_global_load_lds(Bp + (int64_t)r0 * ld + ks * KT + dma_goff,
+                                             (lds_ptr_t)(smem_b + B_BASE + st * B_BYTES + r0 * ROWB), 16, 0, 0);
+        }
+    };
+    auto fix_masks = [&](int kt, int st) {
+        const int k = kt * KT + 2 * (dl_slot ^ drow);
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int r0 = RPI * (wave + NW * u), row = r0 + dl_row;
+            bool zx = false, zy = false;
+            if (a_lo) { zx |= (k > row + a_lo_shift); zy |= (k + 1 > row + a_lo_shift); }
+            if (a_up) { zx |= (k < row); zy |= (k + 1 < row); }
+            double* p = reinterpret_cast<double*>(smem_b + st * A_BYTES + r0 * ROWB + lane * 16);
+            if (zx) p[0] = 0.0;
+            if (zy) p[1] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int r0 = RPI * (wave + NW * u), row = r0 + dl_row;
+            bool zx = false, zy = false;
+            if (b_lo) { zx |= (k > row + b_lo_shift); zy |= (k + 1 > row + b_lo_shift); }
+            if (b_up) { zx |= (k < row); zy |= (k + 1 < row); }
+            double* p = reinterpret_cast<double*>(smem_b + B_BASE + st * B_BYTES + r0 * ROWB + lane * 16);
+            if (zx) p[0] = 0.0;
+            if (zy) p[1] = 0.0;
+        }
+    };
+    int a_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = (fr + 4 * r) & 15;
+        a_off[r] = (wm * (BM / WM) + row) * ROWB + ((q ^ (row & SWM)) << 4);
+    }
+    const int b_off = (wn * (BN / WN) + fr) * ROWB + ((q ^ (fr & SWM)) << 4) + B_BASE;
+    auto group = [&](int st, auto GC) {
+        constexpr int g = decltype(GC)::value;
+        d2_t a[TM][4], b[TN];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const char* pa = smem_b + st * A_BYTES + (a_off[r] ^ (g << 6));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi][r] = *reinterpret_cast<const d2_t*>(pa + mi * (16 * ROWB));
+        }
+        const char* pb = smem_b + st * B_BYTES + (b_off ^ (g << 6));
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const d2_t*>(pb + ni * (16 * ROWB));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[mi][ni][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[mi][r][h], b[ni][h], acc[mi][ni][r], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // prologue: NST - 1 stages in flight
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < nk) dma_tiles(s0, s0);
+    int st = 0;                               // stage of K-step kt
+    for (int kt = 0; kt < nk; ++kt) {
+        // K-step kt's DMA is the oldest outstanding one of this wave: leave the younger NST - 2 stages in flight
+        if (NST == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NBC)) : "memory");
+        if (any_mask) fix_masks(kt, st);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();         // stage st landed for every wave; every wave finished reading stage st - 1
+        {
+            const int kn = kt + NST - 1;      // refill the stage that K-step kt - 1 used
+            int sn = st - 1; if (sn < 0) sn += NST;
+            if (kn < nk) dma_tiles(kn, sn);
+        }
+        group(st, I0{});
+        group(st, I1{});
+        if (NG == 4) { group(st, I2{}); group(st, I3{}); }
+        st = (st + 1 == NST) ? 0 : st + 1;
+    }
+    const double alpha = t.alpha;
+    const bool mirror = (t.c2_off >= 0);
+    double* C2p = C2 + (mirror ? t.c2_off : 0);
+    int q2 = q, fr2 = fr, cb2 = cb;
+    asm volatile("" : "+v"(q2), "+v"(fr2), "+v"(cb2));
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb2 + r) & 3) + q2;
+                const int col = wn * (BN / WN) + ni * 16 + fr2;
+                const double v = alpha * acc[mi][ni][r];
+                Cp[(int64_t)row * ld + col] = v;
+                if (mirror) C2p[(int64_t)col * ld + row] = v;
+            }
+}
+#define LAB_KERNEL_O(NAME, BM, BN, WM, WN, KT, NST, WRAP, OCC)                                                              \
+    __global__ __launch_bounds__(64 * WM * WN, OCC) void NAME(const GemmTask* __restrict__ tasks, const double* A,          \
+                                                            const double* B, double* C, double* C2, int ld) {              \
+        gemm444_occ2<BM, BN, WM, WN, KT, NST, WRAP>(tasks[blockIdx.x], A, B, C, C2, ld);                                  \
+    }
+LAB_KERNEL_O(lab_o128_w22_k16s2, 128, 128, 2, 2, 16, 2, false, 2)     // 64 KB, two workgroups per CU
+LAB_KERNEL_O(lab_o128_w22_k16s2w, 128, 128, 2, 2, 16, 2, true, 2)     //   ... operands from L2 (probe)
+LAB_KERNEL_O(lab_o128_w42_k16s4, 128, 128, 4, 2, 16, 4, false, 1)     // 8 waves, four 32 KB stages: three DMA stages in flight
+LAB_KERNEL_O(lab_o128_w42_k32s2, 128, 128, 4, 2, 32, 2, false, 1)     // 8 waves, the g128 shape without fragment prefetch
+LAB_KERNEL_O(lab_o128_w42_k32s2w, 128, 128, 4, 2, 32, 2, true, 1)
+LAB_KERNEL_O(lab_o64_w22_k32s2, 64, 64, 2, 2, 32, 2, false, 2)
+
 #define LAB_KERNEL_G(NAME, BM, BN, WM, WN)                                                                                  \
     __global__ __launch_bounds__(64 * WM * WN, 1) void NAME(const GemmTask* __restrict__ tasks, const double* A,            \
                                                           const double* B, double* C, double* C2, int ld) {                \
@@ -404,6 +584,10 @@ __device__ __forceinline__ void gemm444_glds(const GemmTask t, const double* A, 
 LAB_KERNEL_G(lab_g128_w42_m0, 128, 128, 4, 2)
 LAB_KERNEL_G(lab_g128_w22_m0, 128, 128, 2, 2)
 LAB_KERNEL_G(lab_g64_w22_m0, 64, 64, 2, 2)
+__global__ __launch_bounds__(256, 1) void lab_g64_w22_hi(const GemmTask* __restrict__ tasks, const double* A, const double* B,
+                                                         double* C, double* C2, int ld) {
+    gemm444_glds<64, 64, 2, 2, 65536>(tasks[blockIdx.x], A, B, C, C2, ld);      // the same tile, its LDS image above 64 KB
+}
 
 #define LAB_KERNEL(NAME, BM, BN, WM, WN, MODE, WPS)                                                                         \
     __global__ __launch_bounds__(64 * WM * WN, 1) void NAME(const GemmTask* __restrict__ tasks, const double* A,            \
@@ -420,12 +604,16 @@ LAB_KERNEL(lab_p64_w22_m0, 64, 64, 2, 2, 0, 1)
 LAB_KERNEL(lab_p64_w42_m0, 64, 64, 4, 2, 0, 2)   // TM = 1, TN = 2
 
 typedef void (*kern_t)(const GemmTask*, const double*, const double*, double*, double*, int);
-struct Variant { const char* name; kern_t k; int tile, threads; };
+struct Variant { const char* name; kern_t k; int tile, threads; int lds = 0; };
 static const Variant g_variants[] = {
     {"p128_w42_m0", lab_p128_w42_m0, 128, 512}, {"p128_w42_m1", lab_p128_w42_m1, 128, 512}, {"p128_w42_m2", lab_p128_w42_m2, 128, 512},
     {"p128_w22_m0", lab_p128_w22_m0, 128, 256}, {"p128_w22_m1", lab_p128_w22_m1, 128, 256}, {"p128_w22_m2", lab_p128_w22_m2, 128, 256},
     {"p64_w22_m0", lab_p64_w22_m0, 64, 256}, {"p64_w42_m0", lab_p64_w42_m0, 64, 512},
     {"g128_w42_m0", lab_g128_w42_m0, 128, 512}, {"g128_w22_m0", lab_g128_w22_m0, 128, 256}, {"g64_w22_m0", lab_g64_w22_m0, 64, 256},
+    {"g64hi_w22_m0", lab_g64_w22_hi, -64, 256},
+    {"o128_w22_k16s2_m0", lab_o128_w22_k16s2, 128, 256, 2 * 32768}, {"o128_w22_k16s2w", lab_o128_w22_k16s2w, 128, 256, 2 * 32768},
+    {"o128_w42_k16s4_m0", lab_o128_w42_k16s4, 128, 512, 4 * 32768}, {"o128_w42_k32s2_m0", lab_o128_w42_k32s2, 128, 512, 2 * 65536},
+    {"o128_w42_k32s2w", lab_o128_w42_k32s2w, 128, 512, 2 * 65536}, {"o64_w22_k32s2_m0", lab_o64_w22_k32s2, 64, 256, 2 * 32768},
 };
 constexpr int NVAR = sizeof(g_variants) / sizeof(g_variants[0]);
 
@@ -452,7 +640,7 @@ int lab_run(int variant, int n, int K, int flags, double beta, int reps, double*
     using namespace lab;
     if (variant < 0 || variant >= NVAR) return -1;
     const Variant& v = g_variants[variant];
-    const int tile = v.tile;
+    const int tile = v.tile < 0 ? -v.tile : v.tile;
     if (n % tile || K % 32 || K > n) return -1;
     double *S = nullptr, *Cm = nullptr;
     GemmTask* dt = nullptr;
@@ -474,7 +662,7 @@ int lab_run(int variant, int n, int K, int flags, double beta, int reps, double*
         }
     if (hipMalloc(&dt, ts.size() * sizeof(GemmTask)) != hipSuccess) return -2;
     hipMemcpy(dt, ts.data(), ts.size() * sizeof(GemmTask), hipMemcpyHostToDevice);
-    const size_t lds = (size_t)2 * (tile + tile) * 32 * 8;
+    const size_t lds = v.lds ? (size_t)v.lds : (size_t)2 * (tile + tile) * 32 * 8 + (v.tile < 0 ? 65536 : 0);
     hipFuncSetAttribute(reinterpret_cast<const void*>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

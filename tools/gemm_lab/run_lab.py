@@ -9,7 +9,7 @@ lib.lab_variant_name.restype = ctypes.c_char_p
 lib.lab_run.restype = ctypes.c_int
 lib.lab_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, dp, dp, dp, dp]
 names = [lib.lab_variant_name(i).decode() for i in range(lib.lab_num_variants())]
-want = sys.argv[1] if len(sys.argv) > 1 else ""
+wants = sys.argv[1:] or [""]
 
 
 def fill(n, seed):
@@ -40,9 +40,9 @@ def reference(n, K, tile, flags, beta):
 ms, md = ctypes.c_double(), ctypes.c_double()
 print("== correctness, n = 1024, K = 256 (flags x beta)")
 for v, name in enumerate(names):
-    if want not in name or not name.endswith("m0"):
+    if not any(w in name for w in wants) or not name.endswith("m0"):
         continue
-    tile = 128 if "p128" in name else 64
+    tile = 128 if "128" in name else 64
     worst = 0.0
     for flags in (0, 1, 2, 4, 8, 5, 10, 9, 6):
         for beta in (0.0, 1.0):
@@ -54,7 +54,7 @@ for v, name in enumerate(names):
 print("== launch time, n = 8192")
 for K in (512, 2048):
     for v, name in enumerate(names):
-        if want not in name:
+        if not any(w in name for w in wants):
             continue
         rc = lib.lab_run(v, 8192, K, 0, 1.0, 5, ctypes.byref(ms), None, None, None)
         assert rc == 0, (name, rc)
