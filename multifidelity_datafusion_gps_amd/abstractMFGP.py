@@ -125,8 +125,19 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             return
         self.lf_X, self.lf_Y = lf_X, lf_Y
         self.lf_model = self._new_lf_model()
-        self.lf_model.optimize(max_iters=self.lf_max_iters)
+        self._optimize_on_rank0(self.lf_model, lambda: self.lf_model.optimize(max_iters=self.lf_max_iters))
         self.f_low = self._lf_posterior_mean
+
+    def _optimize_on_rank0(self, model, run):
+        """a sequential optimisation every rank needs the result of: rank 0 runs it, the others adopt its optimum (one
+        small object broadcast) and factorise once at it when they next need the level -- instead of N identical
+        L-BFGS-B runs.  (It stays on every rank's critical path: nothing of the next level can start without it.)"""
+        if self.comm.size == 1:
+            run()
+            return
+        if self.comm.rank == 0:
+            run()
+        model.optimizer_array = self.comm.bcast_object(model.optimizer_array if self.comm.rank == 0 else None, src=0)
 
     def _lf_posterior_mean(self, t):
         """f_low of a data-driven level: the CURRENT low-fidelity GP's posterior mean (mean only: the O(N^2 N*) variance
@@ -219,6 +230,10 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         if runs:
             best = min(runs, key=lambda r: (r[0], r[2]))
             model.optimizer_array = best[1]
+        elif size > 1:
+            # no restart produced a result (num_restarts = 0, or every run ended without one): rank 0 keeps the optimum of its
+            # first run and the other ranks -- which never ran it -- adopt that, or the replicated level state would diverge
+            model.optimizer_array = self.comm.bcast_object(model.optimizer_array if rank == 0 else None, src=0)
 
     @staticmethod
     def assign_restarts(num_restarts, size):

@@ -255,6 +255,73 @@ def test_cfg5_adaptation_with_refit_and_add_noise_counts_evaluations():
     model.close()
 
 
+def test_cfg5_at_its_stated_size_512_to_8192(engine_cls):
+    """BASELINE.json config 5 at size: N_lf = 16384 (data-driven low-fidelity GP), the high-fidelity set grown from 512 to
+    8192 rows by the entropy-reduction loop (src/abstractMFGP.py:317-359) with add_noise=True (src/MFDataFusion.py:154-155:
+    sigma_n^2 = 1e-6, cond(Ky) ~ 1e9-1e10) -- 7680 acquisitions as rank-1 appends at fixed hyper-parameters
+    (reoptimize=False), a budgeted refit at every 1024 rows, the capacity regrowth of the device slab and the refactorisation
+    at every 128-row boundary on the way.  At 1024, 4096 and 8192 rows the model is compared with the oracle at the current
+    hyper-parameters (add_noise tolerances) and with a FRESH factorisation of the same data on a second handle: a stretch of
+    up to 1023 consecutive appends must not have drifted (1e-7).  The maximiser is the batched DIRECT-L with a short
+    iteration budget and the loop's diagonal prediction is cut to 8 points: the test is about the factorisation, not about
+    where the points land."""
+    import time
+    import multifidelity_datafusion_gps_amd as mf
+    t0 = time.perf_counter()
+    rng = np.random.default_rng(4)
+    X_lf = rng.uniform(size=(16384, 4))
+    maximizer = mf.DIRECT1Maximizer()
+    maximizer.maxT = 4
+    Model = _budgeted(evals=3, restarts=1)
+    Model.diagonal_points = 8
+    model = Model(4, col(cases.hf_4d), None, lf_X=X_lf, lf_Y=col(cases.lf_4d)(X_lf), lf_hf_adapt_ratio=0, seed=5,
+                  add_noise=True, adapt_maximizer=maximizer)
+    model.fit(rng.uniform(size=(512, 4)))
+    model.predict(rng.uniform(size=(2, 4)))                 # add_noise: sigma_n^2 := 1e-6 from here on
+    fresh = engine_cls(0)
+    appended = 0
+    for target in (1024, 2048, 3072, 4096, 5120, 6144, 7168, 8192):
+        n_before = len(model.hf_X)
+        evals_before = model.hf_model.n_evals
+        model.adapt(target - n_before, reoptimize=False)
+        assert len(model.hf_X) == target and model.hf_model.X.shape == (target, 5)
+        assert len(model.acquired_points) == target - n_before
+        appended += target - n_before
+        # appends only: at most one lazy refactorisation per 128-row boundary crossed (re-upload), no optimiser run
+        assert model.hf_model.n_evals - evals_before <= (target - n_before) // 128 + 1
+        if target in (1024, 4096, 8192):
+            Xs = rng.uniform(size=(48, 4))
+            mean, var = model.predict(Xs)
+            parts, theta, noise = _theta_noise(model)
+            assert noise == 1e-6
+            Xa, Y = model.hf_model.X, model.hf_Y[:, 0]
+            Xsa = model._augment_data(Xs)
+            # (1) no drift: a fresh factorisation of the same rows at the same hyper-parameters
+            fresh.set_data(Xa, Y); fresh.set_kernel(parts)
+            nlml_fresh = fresh.eval(theta, noise, model.hf_model._jitter_used, want_grad=False)
+            m_f, v_f = fresh.predict(Xsa)
+            assert model.hf_model.objective_function() == pytest.approx(nlml_fresh, rel=1e-7)
+            np.testing.assert_allclose(mean[:, 0], m_f, rtol=0, atol=1e-7 * max(1.0, np.abs(Y).max()))
+            np.testing.assert_allclose(var[:, 0], v_f, rtol=0, atol=1e-7)
+            # (2) the oracle at the current hyper-parameters (add_noise regime tolerances)
+            st = orc.inference(parts, theta, noise, Xa, Y, want_grad=False)
+            mu, v = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
+            # add_noise tolerance 1e-7 (SURVEY 8(c)); 3e-7 from 4096 rows: cond(Ky) grows with N at sigma_n^2 = 1e-6 and the
+            # host LAPACK run loses the same digits (measured 0.9e-7 at 8192 while appended and fresh GPU runs agree to 1e-9)
+            assert model.hf_model.objective_function() == pytest.approx(st["nlml"], rel=1e-7 if target < 4096 else 3e-7)
+            np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-6 * max(1.0, np.abs(Y).max()))
+            np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-6)
+            print("cfg5 N_hf = %d: nlml %.6f (oracle %.6f, fresh %.6f), %.1f s so far"
+                  % (target, model.hf_model.objective_function(), st["nlml"], nlml_fresh, time.perf_counter() - t0))
+        if target < 8192:
+            model.fit(model.hf_X)                           # the budgeted refit (1 + 1 runs of 3 evaluations)
+            model.predict(rng.uniform(size=(2, 4)))
+    assert appended == 7680
+    fresh.close()
+    model.close()
+    print("cfg5 at size: 512 -> 8192 in %.1f s" % (time.perf_counter() - t0))
+
+
 def test_add_noise_adapt_does_not_refactorise_per_prediction():
     """add_noise=True, adapt(3) with the batched DIRECT at N ~ 1000: the high-fidelity model's
     evaluation count grows by the refits only, not by one per predict()."""

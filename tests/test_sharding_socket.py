@@ -286,3 +286,71 @@ def test_required_attach_raises_instead_of_falling_back():
             def comm_init(self, uid, rank, size):
                 raise RuntimeError("ncclCommInitRank: invalid usage (test)")
         comm.attach_engine(_E(), required=True)
+
+
+# ---- the sequential pieces run on rank 0 only and are adopted by the others -----------------------------------------------
+def _run_datalf_model(comm, restarts):
+    import multifidelity_datafusion_gps_amd as mf
+    from tests.oracle_engine import OracleEngine
+    from tests.test_sharding_gloo import hf, lf
+    rng = np.random.default_rng(3)
+    X_lf = rng.uniform(size=(40, 2))
+    engines = {k: OracleEngine() for k in ("lf", "hf", "hf#1", "hf#2")}
+
+    class M(mf.NARGP):
+        lf_max_iters = first_run_max_iters = restart_max_iters = 20
+        num_restarts = restarts
+        restart_concurrency = 2
+
+    model = M(2, hf, None, lf_X=X_lf, lf_Y=lf(X_lf), seed=5, comm=comm, engines=engines, device_chaining=False)
+    model.fit(rng.uniform(size=(20, 2)))
+    mean, var = model.predict(rng.uniform(size=(37, 2)))
+    return dict(lf_theta=np.array([p.value for p in model.lf_model.parameters()]),
+                theta=np.array([p.value for p in model.hf_model.parameters()]), mean=mean, var=var,
+                lf_evals=engines["lf"].n_evals)
+
+
+def _datalf_worker(rank, world, port, q, restarts):
+    from multifidelity_datafusion_gps_amd.sharding import SocketComm
+    comm = SocketComm(rank, world, "127.0.0.1", port, timeout=60, token="t")
+    try:
+        q.put((rank, _run_datalf_model(comm, restarts)))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("restarts", [6, 0])
+def test_low_fidelity_run_happens_on_rank0_only_and_every_rank_ends_in_the_same_state(restarts):
+    """data-driven low-fidelity level on 3 ranks: only rank 0 runs its L-BFGS-B, the others adopt the optimum and factorise
+    once; with no restarts at all (restarts = 0) the ranks that never ran the first high-fidelity run adopt rank 0's optimum
+    too: every rank's predictions are the single-process ones."""
+    from multifidelity_datafusion_gps_amd.sharding import LocalComm
+    ref = _run_datalf_model(LocalComm(), restarts)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_datalf_worker, args=(r, 3, port, q, restarts)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0]["lf_evals"] > 5 and out[1]["lf_evals"] <= 2 and out[2]["lf_evals"] <= 2     # one factorisation, no run
+    for r in range(3):
+        np.testing.assert_array_equal(out[r]["lf_theta"], out[0]["lf_theta"])
+        np.testing.assert_array_equal(out[r]["theta"], out[0]["theta"])
+        np.testing.assert_array_equal(out[r]["mean"], out[0]["mean"])
+        np.testing.assert_allclose(out[r]["theta"], ref["theta"], rtol=1e-10)
+        np.testing.assert_allclose(out[r]["mean"], ref["mean"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(out[r]["var"], ref["var"], rtol=0, atol=1e-6)
+
+
+def test_restart_assignment_on_eight_ranks():
+    """the bench's HF level on 8 ranks: rank 0 keeps the sequential first run -> restart 0, the five randomized restarts go
+    one each to the highest ranks, ranks 1-2 have no optimiser run (they adopt the winner and shard the predict)"""
+    from multifidelity_datafusion_gps_amd.abstractMFGP import AbstractMFGP
+    a = AbstractMFGP.assign_restarts(6, 8)
+    assert a == [[], [], [], [5], [4], [3], [2], [1]]
+    assert AbstractMFGP.assign_restarts(6, 2) == [[4], [1, 2, 3, 5]] and AbstractMFGP.assign_restarts(6, 1) == [[1, 2, 3, 4, 5]]
+    assert AbstractMFGP.assign_restarts(6, 4) == [[], [3], [2, 5], [1, 4]]
