@@ -141,33 +141,47 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
     if (bad != 0 && lane == 0 && *info == 0) *info = pivot0 + __ffsll((long long)bad);
 }
 
+// 16x16x16 block products on v_mfma_f64_4x4x4_4b_f64 (round 3; four v_mfma_f64_16x16x4 on ONE accumulator before: a dependent
+// chain of ~100-cycle instructions).  The 4x4x4 form multiplies the four block diagonals of a 16x16x4 product (gemm_f64.hip has
+// the measurement and the layout); with the A fragment read in its four row rotations a block product is four INDEPENDENT
+// chains of four 16-cycle instructions, interleaved.  Lane (q = lane >> 4, cb = (lane >> 2) & 3, fr = lane & 15) supplies
+// A[(fr + 4 r) & 15][k = 4 s + q] for rotation r and B^T[fr][k], and owns C[4 ((cb + r) & 3) + q][fr] of rotation r.
+// (Pitch-130 rows: the rotation only permutes rows among the lanes of a 32-lane group, the reads stay conflict-free.)
+__device__ __forceinline__ double mfma444(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 // rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
 template <int YP = LP>
 __device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
-    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int cb = (fr >> 2) & 3;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const double av = sL[(ib * 16 + fr) * LP + jb * 16 + 4 * s + q];
         const double bv = Y[fr * YP + 4 * s + q];   // B[k][n] = Y[n][k]
-        acc = mfma(av, bv, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[r] = mfma444(sL[(ib * 16 + ((fr + 4 * r) & 15)) * LP + jb * 16 + 4 * s + q], bv, acc[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + jb * 16 + fr] = acc[r];
+    for (int r = 0; r < 4; ++r) sL[(ib * 16 + 4 * ((cb + r) & 3) + q) * LP + jb * 16 + fr] = acc[r];
 }
 
 // C[ib][kb] -= L[ib][jb] L[kb][jb]^T on 16x16 blocks of the LDS matrix
 __device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb, int fr, int q) {
-    d4_t acc;
+    double acc[4];
+    const int cb = (fr >> 2) & 3;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = sL[(ib * 16 + q + 4 * r) * LP + kb * 16 + fr];
+    for (int r = 0; r < 4; ++r) acc[r] = sL[(ib * 16 + 4 * ((cb + r) & 3) + q) * LP + kb * 16 + fr];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const double av = -sL[(ib * 16 + fr) * LP + jb * 16 + 4 * s + q];
         const double bv = sL[(kb * 16 + fr) * LP + jb * 16 + 4 * s + q];
-        acc = mfma(av, bv, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[r] = mfma444(-sL[(ib * 16 + ((fr + 4 * r) & 15)) * LP + jb * 16 + 4 * s + q], bv, acc[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + kb * 16 + fr] = acc[r];
+    for (int r = 0; r < 4; ++r) sL[(ib * 16 + 4 * ((cb + r) & 3) + q) * LP + kb * 16 + fr] = acc[r];
 }
 
 // ---- leaf v3: the inverse rides on the factorisation --------------------------------------------------------------------
@@ -186,15 +200,17 @@ constexpr int SY_SIZE = 2 * 16 * YP16;       // TWO of them (panel jb's, and the
 
 // first touch of row jb of B:  B[jb, J] = -Y_jj^T L[J, jb]^T
 __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb, int J, int fr, int q) {
-    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int cb = (fr >> 2) & 3;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const double av = -Y[(4 * s + q) * YP16 + fr];                       // A[row fr][k] = Y^T[fr][k] = Y[k][fr]
         const double bv = sL[(J * 16 + fr) * LP + jb * 16 + 4 * s + q];      // B[k][n = fr] = L[J*16 + fr][jb*16 + k]
-        acc = mfma(av, bv, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[r] = mfma444(-Y[(4 * s + q) * YP16 + ((fr + 4 * r) & 15)], bv, acc[r]);   // A[row][k] = Y^T[row][k] = Y[k][row]
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sL[(jb * 16 + q + 4 * r) * LP + J * 16 + fr] = acc[r];
+    for (int r = 0; r < 4; ++r) sL[(jb * 16 + 4 * ((cb + r) & 3) + q) * LP + J * 16 + fr] = acc[r];
 }
 
 __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restrict__ A, double* Lout, double* S, int ld, int blk,

@@ -361,6 +361,7 @@ class GPRegression:
         self._fail_count = 0
         self.optimization_runs = []
         self.n_evals = 0           # objective(+gradient) evaluations issued to the GPU
+        self._main_evals = 0       # ... of those, the ones issued through this object's own state (not by background restarts)
         self.update_model = True
 
     # ---- parameter plumbing ----------------------------------------------------------------------
@@ -445,9 +446,11 @@ class GPRegression:
             try:
                 res = self._engine.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=want_grad)
                 self.n_evals += 1
+                self._main_evals += 1
                 break
             except NotPositiveDefinite:
                 self.n_evals += 1
+                self._main_evals += 1
                 tries += 1
                 diag_mean = self.kern.Kdiag_value() + noise + CONST_JITTER
                 if tries > 5 or not np.isfinite(diag_mean):
@@ -514,7 +517,7 @@ class GPRegression:
         x0 = self.optimizer_array.copy()
         if x0.size == 0:
             return None
-        n0 = self.n_evals
+        m0 = self._main_evals   # this run's own evaluations (self.n_evals also counts background restarts running beside it)
         fun, budget = _capped(self._objective_grads, self.eval_cap, x0)
         try:
             x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(fun, x0, maxfun=int(max_iters), maxiter=int(max_iters),
@@ -522,7 +525,7 @@ class GPRegression:
         except _BudgetExhausted:
             x_opt, f_opt, d = budget["x"], budget["f"], {"task": "STOP: evaluation cap reached"}
         self.optimizer_array = x_opt
-        run = _OptRun(np.array(x_opt), float(f_opt), self.n_evals - n0, d.get("task", d.get("warnflag")))
+        run = _OptRun(np.array(x_opt), float(f_opt), self._main_evals - m0, d.get("task", d.get("warnflag")))
         self.optimization_runs.append(run)
         return run
 
