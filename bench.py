@@ -377,7 +377,7 @@ def main():
         sweep_tf_alone = _rate(clf["cholinv_flops"], clf["cholinv_ms"]) / 1e12
         kb_gbs = _rate(tot["kbuild_bytes"], tot["kbuild_ms"]) / 1e9
         kb_gbs_alone = _rate(clf["kbuild_bytes"], clf["kbuild_ms"]) / 1e9
-        pv_tf = _rate(tot["predict_var_flops"], tot["predict_var_ms"]) / 1e12
+        pv_tf = _rate(tot["timed_predict_var_flops"], tot["predict_var_ms"]) / 1e12
         kinv_tf = _rate(tot["kinv_flops"], tot["kinv_ms"]) / 1e12
         streamed = tot["kinv_flops"] == 0
         out = {
@@ -391,7 +391,7 @@ def main():
                                    "1 LF run + (1+%d) HF runs, then predict" % (args.n, args.evals, args.restarts),
                        "n": args.n, "evals_per_run": args.evals, "restarts": args.restarts,
                        "evals_issued_rank0_per_step": evals / args.steps,
-                       "gpu_ms_per_evaluation": round(tot["total_ms"] / max(evals, 1), 3),
+                       "gpu_ms_per_evaluation": (round(tot["total_ms"] / tot["timed_evals"], 3) if tot["timed_evals"] else None),
                        "wall_ms_per_evaluation": round(ms_per_step * args.steps / max(evals, 1), 3),
                        "restart_concurrency": args.concurrency, "collectives": collectives,
                        "ranks": world, "rccl_ranks": int(engines["hf"].comm_size),

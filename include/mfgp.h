@@ -63,6 +63,10 @@ typedef struct mfgp_timings {
     double kinv_flops;   /* algorithmic flops of the K^-1 launch (Np^3/3)                               */
     double cholinv_flops;/* 2*Np^3/3                                                                    */
     int64_t n_launches;  /* kernel launches issued by the call                                          */
+    int64_t timed;       /* which of the millisecond fields were measured by the call: 0 = none (no event was
+                          * recorded: below Np = 4096 a handle records none unless MFGP_TIMING / MFGP_STAGE_TIMING
+                          * ask for them -- the fields are then 0, not a measurement), 1 = total_ms and the two
+                          * predict fields, 3 = the per-stage fields as well.  Bytes / flops are always filled.   */
 } mfgp_timings;
 
 /* running sums over every mfgp_eval / mfgp_predict since the last reset: lets a benchmark attribute
@@ -73,7 +77,10 @@ typedef struct mfgp_counters {
     double kbuild_bytes, kinv_flops, cholinv_flops;
     double predict_panel_ms;   /* K(X*,X) panel + mean                                                          */
     double predict_var_ms;     /* V = K(X*,X) L^-T + row sums of squares                                         */
-    double predict_var_flops;  /* algorithmic flops of the variance products: Np^2 * rows per predict */
+    double predict_var_flops;  /* algorithmic flops of the variance products: Np^2 * rows per predict,
+                                * counted whether or not the call was timed                                         */
+    double timed_evals;        /* evaluations whose total_ms entered the sums (see mfgp_timings.timed)              */
+    double timed_predict_var_flops; /* variance-product flops of the predicts whose predict_var_ms entered the sums  */
 } mfgp_counters;
 
 /* ---- lifecycle --------------------------------------------------------------------------------- */

@@ -48,7 +48,7 @@ class KernPart(ctypes.Structure):
 class Timings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in (
         "kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms", "grad_ms", "predict_panel_ms", "predict_var_ms",
-        "total_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops")] + [("n_launches", ctypes.c_int64)]
+        "total_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops")] + [("n_launches", ctypes.c_int64), ("timed", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -58,7 +58,7 @@ class Counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in (
         "evals", "grad_evals", "predicts", "predict_rows", "kbuild_ms", "cholinv_ms", "solve_ms", "kinv_ms",
         "grad_ms", "total_ms", "predict_ms", "kbuild_bytes", "kinv_flops", "cholinv_flops", "predict_panel_ms",
-        "predict_var_ms", "predict_var_flops")]
+        "predict_var_ms", "predict_var_flops", "timed_evals", "timed_predict_var_flops")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -418,7 +418,9 @@ __device__ __forceinline__ void gemm_nt_dma(const GemmTask t, const double* A, c
     const int b_off = (wn * (BN / WN) + fr) * ROWB + ((q ^ (fr & SWM)) << 4) + B_BASE;
     // One 8-column group.  The A fragments are taken one row block at a time (MH) where TM = 4: with all of them in flight the body
     // needs 256 VGPRs, and two such waves per SIMD leave no register for a wave of the serial chain's kernels, which then wait
-    // for a bulk workgroup to retire (measured: chain launches 27 -> 46 us at N = 8192).  At 224 a 64-register chain wave fits.
+    // for a bulk workgroup to retire (measured: chain launches 27 -> 46 us at N = 8192).  As written: 206, so a chain wave of
+    // up to 96 registers fits beside two bulk waves.  (No sched_barrier inside the group: pinning the order there makes the
+    // register allocator ping-pong 40 of the 64 accumulators between two registers -- MFMAs with D != C -- 240 VGPRs.)
     auto group = [&](int st, auto GC) {
         constexpr int g = decltype(GC)::value;
         constexpr int MH = TM > 2 ? TM / 4 : TM;
@@ -445,7 +447,6 @@ __device__ __forceinline__ void gemm_nt_dma(const GemmTask t, const double* A, c
                         for (int r = 0; r < 4; ++r)
                             acc[m0 + mi][ni][r] =
                                 __builtin_amdgcn_mfma_f64_4x4x4f64(a[mi][r][h], b[ni][h], acc[m0 + mi][ni][r], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // the next half's fragment reads stay behind these MFMAs (registers)
         }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_chain(const 
 // per SIMD behind eight serial K-steps); as 32x32 tiles the same work spreads over four times as many workgroups and four
 // K-steps: panel launch 12 -> 9.5 us, in-macro update 13-20 -> 10-17 us (N = 4096), one evaluation at N = 2048 1.20 -> 1.03 ms.
 // (Measured beside it: K-steps of 16, single- and double-buffered: 1.07 / 1.08 ms.)
-__global__ __launch_bounds__(256, 1) void mfgp_gemm_nt_f64_chain32(const GemmTask* __restrict__ tasks, const double* A,
+__global__ __launch_bounds__(256, 5) void mfgp_gemm_nt_f64_chain32(const GemmTask* __restrict__ tasks, const double* A,
                                                           const double* B, double* C, double* C2, int ld) {
     __builtin_amdgcn_s_setprio(3);
     gemm_nt_tile<32, 32, 2, 2, 1, 32>(tasks[blockIdx.x], A, B, C, C2, ld);

@@ -141,8 +141,16 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
     if (bad != 0 && lane == 0 && *info == 0) *info = pivot0 + __ffsll((long long)bad);
 }
 
-// 16x16x16 block products on v_mfma_f64_4x4x4_4b_f64 (round 3; four v_mfma_f64_16x16x4 on ONE accumulator before: a dependent
-// chain of ~100-cycle instructions).  The 4x4x4 form multiplies the four block diagonals of a 16x16x4 product (gemm_f64.hip has
+// 16x16x16 block products.  MFGP_LEAF_444 = 1: on v_mfma_f64_4x4x4_4b_f64 (the shape the tile GEMM moved to in round 3);
+// 0 (default): four v_mfma_f64_16x16x4 on one accumulator, as in rounds 1-2.  MEASURED (round 3, profiles/r03_plan_ab.txt): the
+// 4x4x4 form makes the leaf SLOWER, 27 -> 36 us alone -- the block products are not what bounds the leaf: wave 0's
+// micro-Cholesky is, it shares SIMD 0 with a worker wave, and four times as many MFMA issues on that SIMD stretch its VALU
+// chain ("a latency-critical VALU chain must not share a SIMD with MFMA-bound waves").  Kept for the record.
+#ifndef MFGP_LEAF_444
+#define MFGP_LEAF_444 0
+#endif
+//
+// The 4x4x4 form:  The 4x4x4 form multiplies the four block diagonals of a 16x16x4 product (gemm_f64.hip has
 // the measurement and the layout); with the A fragment read in its four row rotations a block product is four INDEPENDENT
 // chains of four 16-cycle instructions, interleaved.  Lane (q = lane >> 4, cb = (lane >> 2) & 3, fr = lane & 15) supplies
 // A[(fr + 4 r) & 15][k = 4 s + q] for rotation r and B^T[fr][k], and owns C[4 ((cb + r) & 3) + q][fr] of rotation r.
@@ -151,6 +159,7 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+#if MFGP_LEAF_444
 // rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
 template <int YP = LP>
 __device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
@@ -184,6 +193,38 @@ __device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb,
     for (int r = 0; r < 4; ++r) sL[(ib * 16 + 4 * ((cb + r) & 3) + q) * LP + kb * 16 + fr] = acc[r];
 }
 
+#else
+// rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
+template <int YP = LP>
+__device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
+    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double av = sL[(ib * 16 + fr) * LP + jb * 16 + 4 * s + q];
+        const double bv = Y[fr * YP + 4 * s + q];   // B[k][n] = Y[n][k]
+        acc = mfma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + jb * 16 + fr] = acc[r];
+}
+
+// C[ib][kb] -= L[ib][jb] L[kb][jb]^T on 16x16 blocks of the LDS matrix
+__device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb, int fr, int q) {
+    d4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sL[(ib * 16 + q + 4 * r) * LP + kb * 16 + fr];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double av = -sL[(ib * 16 + fr) * LP + jb * 16 + 4 * s + q];
+        const double bv = sL[(kb * 16 + fr) * LP + jb * 16 + 4 * s + q];
+        acc = mfma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + kb * 16 + fr] = acc[r];
+}
+
+#endif
+
 // ---- leaf v3: the inverse rides on the factorisation --------------------------------------------------------------------
 // Same block-in-LDS, 16-column-panel factorisation as v2, but the inverse is no longer a second phase: it is produced by
 // the augmented system [A; I] INSIDE the panel loop, as idle-wave work in the shadow of wave 0's micro-Cholesky (which is
@@ -198,6 +239,7 @@ constexpr int SY_SIZE = 2 * 16 * YP16;       // TWO of them (panel jb's, and the
                                              // panel jb's solves, first touches and output are through -- 138 KB of LDS in all, so
                                              // that a 16 KB chain workgroup of another evaluation still fits on the CU beside the leaf
 
+#if MFGP_LEAF_444
 // first touch of row jb of B:  B[jb, J] = -Y_jj^T L[J, jb]^T
 __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb, int J, int fr, int q) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -212,6 +254,22 @@ __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb
 #pragma unroll
     for (int r = 0; r < 4; ++r) sL[(jb * 16 + 4 * ((cb + r) & 3) + q) * LP + J * 16 + fr] = acc[r];
 }
+
+#else
+// first touch of row jb of B:  B[jb, J] = -Y_jj^T L[J, jb]^T
+__device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb, int J, int fr, int q) {
+    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double av = -Y[(4 * s + q) * YP16 + fr];                       // A[row fr][k] = Y^T[fr][k] = Y[k][fr]
+        const double bv = sL[(J * 16 + fr) * LP + jb * 16 + 4 * s + q];      // B[k][n = fr] = L[J*16 + fr][jb*16 + k]
+        acc = mfma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sL[(jb * 16 + q + 4 * r) * LP + J * 16 + fr] = acc[r];
+}
+
+#endif
 
 __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restrict__ A, double* Lout, double* S, int ld, int blk,
                                              double* logdet_part, int* info, unsigned long long* stamps) {

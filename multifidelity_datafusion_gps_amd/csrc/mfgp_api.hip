@@ -339,6 +339,8 @@ static int finish_eval(mfgp_handle* h, bool want_grad) {
         }
     }
     if (h->timing) t.total_ms = ev_ms(h->ev[0], h->ev[want_grad ? 5 : 3]);
+    t.timed = h->stage_timing ? 3 : (h->timing ? 1 : 0);
+    if (h->timing) h->cum.timed_evals += 1;
     const double np = (double)h->Np;
     t.kbuild_bytes = 4.0 * np * (np + 64.0);
     // a streamed plan accumulates K^-1 inside the sweep (between the cholinv stamps): its N^3/3 flops are counted there
@@ -588,7 +590,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     return 0;
 }
 
-static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double var_ms) {
+static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double var_ms, bool want_var) {
     h->tm.predict_panel_ms = pan_ms;
     h->tm.predict_var_ms = var_ms;
     h->cum.predicts += 1;
@@ -596,7 +598,11 @@ static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double
     h->cum.predict_ms += pan_ms + var_ms;
     h->cum.predict_panel_ms += pan_ms;
     h->cum.predict_var_ms += var_ms;
-    if (var_ms > 0) h->cum.predict_var_flops += (double)h->Np * (double)h->Np * (double)Nstar;
+    if (want_var) {
+        h->cum.predict_var_flops += (double)h->Np * (double)h->Np * (double)Nstar;      // the work, timed or not
+        if (h->timing) h->cum.timed_predict_var_flops += (double)h->Np * (double)h->Np * (double)Nstar;
+    }
+    h->tm.timed = h->timing ? (h->tm.timed | 1) : h->tm.timed;
     h->tm.n_launches = h->launches;
 }
 
@@ -632,7 +638,7 @@ int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double*
                            &var_ms, pinned);
         if (rc) return rc;
     }
-    predict_account(h, Nstar, pan_ms, var_ms);
+    predict_account(h, Nstar, pan_ms, var_ms, want_var != 0);
     return 0;
 }
 
@@ -759,7 +765,7 @@ int32_t mfgp_predict_chained(mfgp_handle* h, mfgp_handle* lf, const double* Xsta
                            &var_ms, rows_p <= mfgp_handle::IO_OUT);
         if (rc) return rc;
     }
-    predict_account(h, Nstar, pan_ms, var_ms);
+    predict_account(h, Nstar, pan_ms, var_ms, want_var != 0);
     return 0;
 }
 

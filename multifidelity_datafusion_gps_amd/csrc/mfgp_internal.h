@@ -122,7 +122,7 @@ struct mfgp_handle {
     double* hio = nullptr;   // host view
     double* dio = nullptr;   // device view
     int* hinfo = nullptr;    // pinned
-    bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 1024 unless MFGP_STAGE_TIMING=1)
+    bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 4096 unless MFGP_STAGE_TIMING=1; mfgp_timings.timed says what a call measured)
     bool timing = true;          // any timing events at all (start / end of an evaluation, of a predict)
     mfgp::Plan pl;                  // factorisation / inverse / K^-1 / predictive-variance launch lists (plan.cpp)
     mfgp::KernSpecDev spec{};

@@ -33,8 +33,8 @@ def test_library_builds_loads_and_exports_every_symbol():
 def test_struct_layouts_match_header():
     from multifidelity_datafusion_gps_amd import _lib
     assert ctypes.sizeof(_lib.KernPart) == 16
-    assert ctypes.sizeof(_lib.Timings) == 12 * 8
-    assert ctypes.sizeof(_lib.Counters) == 17 * 8
+    assert ctypes.sizeof(_lib.Timings) == 13 * 8      # + timed (round 3)
+    assert ctypes.sizeof(_lib.Counters) == 19 * 8     # + timed_evals, timed_predict_var_flops
 
 
 def test_no_cpu_fallback_engine_fails_loudly_without_gpu():

@@ -1,5 +1,6 @@
 """Runs the five BASELINE.json configurations end to end on the GPU (synthetic data of SURVEY 8(d)) and prints one
 line each: sizes, wall time, per-evaluation stage times.  `--quick` shrinks the large ones for smoke runs."""
+import os as _os; _os.environ.setdefault("MFGP_STAGE_TIMING", "1")   # per-stage stamps at every size (a handle records none below Np = 4096 by default)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

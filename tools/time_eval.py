@@ -15,7 +15,7 @@ def main():
         Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
         parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
         e.set_data(Xa, Y); e.set_kernel(parts)
-        for _ in range(3):   # plain first use, graph capture at the second (MFGP_GRAPH), one replay
+        for _ in range(3):   # warm-up: first use plans and allocates
             e.eval(theta, noise)
         acc = {}
         reps = 5
