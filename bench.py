@@ -205,7 +205,9 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=45.0):
                          lf_eval_s, hf_eval_s, lf_means_s, hf_predict_s, measured, n_lf_evals, n_hf_evals)}
 
 
-PMC_FILE = os.path.join("profiles", "r02_pmc.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+MFMA_FILE = os.path.join("profiles", "r03_mfma_counters.json")
+BARE_MFMA_TFLOPS = 71.0   # bare v_mfma_f64_4x4x4_4b loop on this part (profiles/r03_probes.txt): what the instruction itself can issue
 
 
 def pmc_traffic(kernel, n):
@@ -213,6 +215,16 @@ def pmc_traffic(kernel, n):
     try:
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
         return int(d[kernel]["traffic_bytes"]) if int(d.get("n", -1)) == int(n) else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def mfma_busy():
+    """matrix-pipe busy fraction per kernel from the committed SQ counter pass over one evaluation at N = 8192
+    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); profiles/README.md has the calibration on the bare probes)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, MFMA_FILE)))["pmcA_eval"]
+        return {k: v["mfma_busy"] for k, v in d.items() if v.get("mfma_busy", 0) > 0}
     except Exception:  # noqa: BLE001
         return None
 
@@ -398,10 +410,13 @@ def main():
                        "sharding": "randomized restarts + predictive rows over ranks; LF run replicated; first HF run -> restart 0 on rank 0 only"},
             # the dominant work: ONE sweep per evaluation = Cholesky + triangular inverse%s, timed with HIP events on the
             # engine's main stream around the sweep (the bulk stream joins before the closing event)
-            "roofline": {"kernel": "factorisation sweep per evaluation: mfgp_leaf_cholinv_f64 + mfgp_gemm_nt_f64_{t128,t64,chain} "
+            "roofline": {"kernel": "factorisation sweep per evaluation: mfgp_leaf_cholinv_f64 + mfgp_gemm_nt_f64_{t128,t64,chain} on v_mfma_f64_4x4x4_4b "
                                    "(Cholesky N^3/3 + inverse N^3/3%s)" % (" + streamed K^-1 N^3/3" if streamed else ""),
                          "bound": "mfma", "achieved": round(sweep_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(sweep_tf / FP64_PEAK_TFLOPS, 4),
+                         "frac_of_bare_mfma_loop": round(sweep_tf / BARE_MFMA_TFLOPS, 4), "bare_mfma_loop": BARE_MFMA_TFLOPS,
+                         "mfma_busy": mfma_busy(), "mfma_busy_source": MFMA_FILE + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                         "SQ_BUSY_CU_CYCLES ... over tools/time_eval.py 8192, committed; not measured by this run)",
                          "traffic": pmc_traffic("sweep", args.n), "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes over "
                          "tools/time_eval.py, committed; not measured by this run)",
                          "launches": int(evals), "flops_per_launch": tot["cholinv_flops"] / max(evals, 1),
@@ -422,7 +437,7 @@ def main():
             "roofline_kbuild": {"kernel": "mfgp_kbuild_rbf2_f64<MODE_TRI> (K(X,X)+noise lower triangle, one launch per evaluation)",
                                 "bound": "hbm", "achieved": round(kb_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(kb_gbs / HBM_PEAK_GBS, 4),
-                                "traffic": pmc_traffic("mfgp_kbuild_f64<0>", args.n),
+                                "traffic": pmc_traffic("mfgp_kbuild_rbf2_f64<0>", args.n),
                                 "launches": int(evals), "avg_launch_ms": round(tot["kbuild_ms"] / max(evals, 1), 4),
                                 "uncontended": {"achieved": round(kb_gbs_alone, 1), "frac": round(kb_gbs_alone / HBM_PEAK_GBS, 4),
                                                 "avg_launch_ms": round(clf["kbuild_ms"] / max(clf["evals"], 1), 4)}},
