@@ -31,13 +31,20 @@ typedef struct mfgp_handle mfgp_handle;
 
 /* kernel-part types: GPy.kern.RBF / Matern32 / Matern52 (src/abstractMFGP.py:60, :62 kern_class1..3) */
 enum { MFGP_KERN_RBF = 0, MFGP_KERN_MATERN32 = 1, MFGP_KERN_MATERN52 = 2 };
+/* OR-ed into mfgp_kern_part.type: one lengthscale PER active column (GPy's ARD=True; the "ARD weights" the reference's model
+ * docstrings speak of, src/models/NARGP.py:13, src/models/GPDF.py:12 -- the reference itself never passes the flag):
+ * k = variance * shape( sqrt( sum_d (x_d - x'_d)^2 / lengthscale_d^2 ) ) */
+#define MFGP_KERN_ARD 0x100
 
 /*
  * One stationary factor k_f(x,x') = variance_f * shape_f(|x[c0:c1]-x'[c0:c1]| / lengthscale_f).
  * The covariance is   K = sum over distinct `term` ids of ( product of the factors with that id ),
  * which covers GPy.kern.RBF(D) (one factor, one term; src/abstractMFGP.py:59-60) and the NARGP
  * composite kern1*kern2 + kern3 with active_dims column slices (src/abstractMFGP.py:73-80).
- * Parameter vector layout used by every call: theta[2*f] = variance_f, theta[2*f+1] = lengthscale_f.
+ * Parameter vector layout used by every call, factor after factor: variance_f, then the factor's lengthscale(s) -- ONE for an
+ * isotropic factor (so theta[2*f] = variance_f, theta[2*f+1] = lengthscale_f when no factor is ARD), col_end - col_begin of
+ * them, in column order, for an MFGP_KERN_ARD factor.  P = the total (mfgp_num_params), at most MFGP_MAX_THETA.  Gradients use
+ * the same layout followed by the noise-variance entry: P + 1 doubles.
  */
 typedef struct mfgp_kern_part {
     int32_t type;      /* MFGP_KERN_* */
@@ -47,6 +54,10 @@ typedef struct mfgp_kern_part {
 } mfgp_kern_part;
 
 #define MFGP_MAX_PARTS 6
+#define MFGP_MAX_THETA 40
+
+/* P for a kernel description (no handle needed); < 0 for an invalid description */
+int32_t mfgp_num_params(const mfgp_kern_part* parts, int32_t n_parts);
 
 /* hipEvent stage timers of the most recent mfgp_eval / mfgp_predict (milliseconds) and the
  * algorithmic work of the two single-launch kernels the bench reports rooflines for. */

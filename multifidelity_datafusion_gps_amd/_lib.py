@@ -13,12 +13,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmfgp_hip.so")
 
 KERN_RBF, KERN_MATERN32, KERN_MATERN52 = 0, 1, 2
+KERN_ARD = 0x100      # OR-ed into a part's type: one lengthscale per active column (include/mfgp.h)
 MAX_PARTS = 6
+MAX_THETA = 40
+
+
+def num_params(parts):
+    """P of a kernel description [(type, col_begin, col_end, term)]: per factor a variance + 1 (or, ARD, one per column) lengthscale"""
+    return sum(1 + ((int(p[2]) - int(p[1])) if (int(p[0]) & KERN_ARD) else 1) for p in parts)
 
 # every symbol include/mfgp.h declares (tests check the .so exports each of them)
 EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
-    "mfgp_set_kernel", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
+    "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters", "mfgp_device_synchronize",
@@ -91,6 +98,7 @@ def load_library(path=None):
         "mfgp_device_info": (ctypes.c_char_p, [H]),
         "mfgp_set_data": (i32, [H, dp, i64, i32, dp]),
         "mfgp_set_kernel": (i32, [H, ctypes.POINTER(KernPart), i32]),
+        "mfgp_num_params": (i32, [ctypes.POINTER(KernPart), i32]),
         "mfgp_eval": (i32, [H, dp, f64, f64, i32, dp, dp]),
         "mfgp_kbuild_rows": (i32, [H, dp, f64, f64, i64, i64]),
         "mfgp_dev_matrix": (i32, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(i64)]),
@@ -160,6 +168,7 @@ class Engine:
         self.device = device
         self.n = 0
         self.n_parts = 0
+        self.n_params = 0      # P: kernel parameters of the description last given to set_kernel (theta length)
         self.comm_rank, self.comm_size = 0, 1
 
     # -- plumbing -------------------------------------------------------------------------------
@@ -216,22 +225,27 @@ class Engine:
         arr = (KernPart * len(parts))(*[KernPart(*map(int, p)) for p in parts])
         self._check(self._lib.mfgp_set_kernel(self._h, arr, len(parts)), "mfgp_set_kernel")
         self.n_parts = len(parts)
+        self.n_params = int(self._lib.mfgp_num_params(arr, len(parts)))
 
     # -- hot calls ------------------------------------------------------------------------------
     def eval(self, theta, noise, jitter=1e-8, want_grad=True):
-        theta = _c64(theta).reshape(-1)
-        if theta.shape[0] != 2 * self.n_parts:
-            raise ValueError("theta must have 2*n_parts entries")
+        theta = self._theta(theta)
         nlml = ctypes.c_double()
-        grad = np.zeros(2 * self.n_parts + 1)
+        grad = np.zeros(self.n_params + 1)
         rc = self._lib.mfgp_eval(self._h, _dptr(theta), float(noise), float(jitter), int(bool(want_grad)),
                                  ctypes.byref(nlml), _dptr(grad))
         self._check(rc, "mfgp_eval")
         return (nlml.value, grad) if want_grad else nlml.value
 
     # -- row-block K build + all-gather (multi-GPU layout of SURVEY 8(e3)) ---------------------------
-    def kbuild_rows(self, theta, noise, jitter, row_begin, row_end):
+    def _theta(self, theta):
         theta = _c64(theta).reshape(-1)
+        if theta.shape[0] != self.n_params:     # the library reads exactly P entries
+            raise ValueError("theta must have %d entries (variance + lengthscale(s) per part)" % self.n_params)
+        return theta
+
+    def kbuild_rows(self, theta, noise, jitter, row_begin, row_end):
+        theta = self._theta(theta)
         self._check(self._lib.mfgp_kbuild_rows(self._h, _dptr(theta), float(noise), float(jitter), int(row_begin),
                                                int(row_end)), "mfgp_kbuild_rows")
 
@@ -287,13 +301,13 @@ class Engine:
 
     def eval_prebuilt(self, want_grad=True):
         nlml = ctypes.c_double()
-        grad = np.zeros(2 * self.n_parts + 1)
+        grad = np.zeros(self.n_params + 1)
         self._check(self._lib.mfgp_eval_prebuilt(self._h, int(bool(want_grad)), ctypes.byref(nlml), _dptr(grad)),
                     "mfgp_eval_prebuilt")
         return (nlml.value, grad) if want_grad else nlml.value
 
     def factorize(self, theta, noise, jitter=1e-8):
-        theta = _c64(theta).reshape(-1)
+        theta = self._theta(theta)
         self._check(self._lib.mfgp_factorize(self._h, _dptr(theta), float(noise), float(jitter)), "mfgp_factorize")
 
     def nlml(self):
@@ -302,7 +316,7 @@ class Engine:
         return v.value
 
     def nlml_grad(self):
-        g = np.zeros(2 * self.n_parts + 1)
+        g = np.zeros(self.n_params + 1)
         self._check(self._lib.mfgp_nlml_grad(self._h, _dptr(g)), "mfgp_nlml_grad")
         return g
 

@@ -77,6 +77,43 @@ __device__ __forceinline__ void pair_r2(const double* sxi, const double* sxj, in
     }
 }
 
+// the same with one inverse squared lengthscale per column (MFGP_KERN_ARD): r2[e] = sum_d (x_d - x'_d)^2 / l_d^2, and the
+// share of ONE column d of it (the per-column gradient needs it)
+// (the lengthscales are read as sp.theta[lbase + d - c0]: a pointer into the by-value kernel argument would send it to scratch)
+__device__ __forceinline__ void pair_r2_ard(const KernSpecDev& sp, const double* sxi, const double* sxj, int ty, int tx, int c0,
+                                            int c1, int lbase, double (&r2)[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r2[e] = 0.0;
+    for (int d = c0; d < c1; ++d) {
+        const double l = sp.theta[lbase + (d - c0)], w = 1.0 / (l * l);
+        const d2_t xi0 = *reinterpret_cast<const d2_t*>(sxi + d * XP + 4 * ty);
+        const d2_t xi1 = *reinterpret_cast<const d2_t*>(sxi + d * XP + 4 * ty + 2);
+        const d2_t xa = *reinterpret_cast<const d2_t*>(sxj + d * XP + 2 * tx);
+        const d2_t xb = *reinterpret_cast<const d2_t*>(sxj + d * XP + 32 + 2 * tx);
+        const double xi[4] = {xi0.x, xi0.y, xi1.x, xi1.y};
+        const double xj[4] = {xa.x, xa.y, xb.x, xb.y};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double df = xi[r] - xj[c];
+                r2[r * 4 + c] = __builtin_fma(df * df, w, r2[r * 4 + c]);
+            }
+    }
+}
+
+// scaled squared distances of factor f (isotropic: r^2 / l^2 is applied by the caller through inv_l2; ARD: already scaled)
+__device__ __forceinline__ double factor_r2(const KernSpecDev& sp, int f, const double* sxi, const double* sxj, int ty, int tx,
+                                            double (&r2)[16]) {
+    if (sp.nl[f] == 1) {
+        const double l = sp.theta[sp.toff[f] + 1];
+        pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
+        return 1.0 / (l * l);
+    }
+    pair_r2_ard(sp, sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], sp.toff[f] + 1, r2);
+    return 1.0;
+}
+
 // One factor of a product term for the 16 pairs of a thread (wave-uniform shape per call).  RBF factors only add
 // to the term's exponent (expo) and variance product: a term of m RBF factors costs ONE exp per pair, not m
 // (k1*k2 = s1 s2 exp(-r1^2/2l1^2 - r2^2/2l2^2)); Matern factors multiply prod directly.
@@ -158,10 +195,10 @@ __device__ __forceinline__ void cov_values(const KernSpecDev& sp, const double* 
             cur = sp.term[f];
             any_rbf = false;
         }
-        const double var = sp.theta[2 * f], l = sp.theta[2 * f + 1];
-        pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
+        const double var = sp.theta[sp.toff[f]];
+        const double inv_l2 = factor_r2(sp, f, sxi, sxj, ty, tx, r2);
         any_rbf = any_rbf || (sp.type[f] == MFGP_KERN_RBF);
-        apply_factor(sp.type[f], var, 1.0 / (l * l), r2, prod, expo, varprod);
+        apply_factor(sp.type[f], var, inv_l2, r2, prod, expo, varprod);
     }
     finish_term(prod, expo, varprod, any_rbf);
 #pragma unroll
@@ -202,7 +239,7 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_f64(KernSpecDev sp, const dou
 
     double Kv[16];
     cov_values(sp, sxi, sxj, ty, tx, Kv);
-    const double diag_add = (MODE == MODE_TRI || MODE == MODE_ROWS) ? (sp.theta[2 * sp.nf] + sp.theta[2 * sp.nf + 1]) : 0.0;
+    const double diag_add = (MODE == MODE_TRI || MODE == MODE_ROWS) ? (sp.theta[sp.np] + sp.theta[sp.np + 1]) : 0.0;
 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -323,10 +360,10 @@ static bool rbf2_match(const KernSpecDev& s, Rbf2Spec& o) {
     static const bool on = !(getenv("MFGP_KBUILD_FAST") && atoi(getenv("MFGP_KBUILD_FAST")) == 0);
     if (!on) return false;
     for (int f = 0; f < s.nf; ++f)
-        if (s.type[f] != MFGP_KERN_RBF) return false;
+        if (s.type[f] != MFGP_KERN_RBF || s.nl[f] != 1) return false;   // (ARD factors take the generic kernels)
     o = Rbf2Spec{};
     o.D = s.D;
-    o.diag_add = s.theta[2 * s.nf] + s.theta[2 * s.nf + 1];
+    o.diag_add = s.theta[s.np] + s.theta[s.np + 1];
     auto half_inv_l2 = [&](int f) { const double l = s.theta[2 * f + 1]; return 0.5 * (1.0 / (l * l)); };
     if (s.nf == 1) {
         o.b0 = s.c0[0]; o.b1 = s.c1[0];
@@ -393,7 +430,36 @@ void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X,
 // Per-tile partials go to `partials`; a second single-block kernel adds them in a fixed order
 // (bitwise reproducible) and applies the factors.
 // ------------------------------------------------------------------------------------------------
-constexpr int NSUM = 2 * MFGP_MAX_PARTS + 1;
+constexpr int NSUM = MFGP_MAX_THETA + 1;   // stride of a tile's partial sums: slot i < P = parameter i (include/mfgp.h layout), slot P = noise
+
+// g / s of one factor for the 16 pairs, with g = (dk/dl) l / k of the ISOTROPIC factor and s the scaled squared distance:
+// the column shares of an ARD factor are (dk/dl_d) l_d / k = (g / s) (x_d - x'_d)^2 / l_d^2  (finite at s = 0)
+__device__ __forceinline__ void factor_logderiv_over_s(int type, const double (&s)[16], double (&rho)[16]) {
+    if (type == MFGP_KERN_RBF) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rho[e] = 1.0;
+    } else if (type == MFGP_KERN_MATERN32) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rho[e] = 3.0 / (1.0 + 1.7320508075688772 * sqrt(s[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double s5r = 2.23606797749979 * sqrt(s[e]);
+            rho[e] = (5.0 / 3.0) * (1.0 + s5r) / (1.0 + s5r + (5.0 / 3.0) * s[e]);
+        }
+    }
+}
+
+// sum of v over the 256 threads of the block in a fixed order (bitwise reproducible) -> *dst, by thread 0
+__device__ __forceinline__ void block_sum_to(double v, double* sred, double* dst) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sred[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const double* __restrict__ X,
                                                            const double* __restrict__ Kinv, int ld,
@@ -402,7 +468,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sxi = smem;
     double* sxj = smem + sp.D * XP;
-    double* red = smem + 2 * sp.D * XP;  // [NSUM][256] per-thread sums
+    double* sred = smem + 2 * sp.D * XP;  // [4] wave sums
     const int b = blockIdx.x;
     int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
@@ -410,10 +476,9 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
     const int bj = b - bi * (bi + 1) / 2;
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
+    double* out = partials + (int64_t)b * NSUM;
     stage_rows(X, (int64_t)bi * KT, sp.D, sxi);
     stage_rows(X, (int64_t)bj * KT, sp.D, sxj);
-#pragma unroll
-    for (int i = 0; i < NSUM; ++i) red[i * 256 + tid] = 0.0;
     __syncthreads();
 
     // G = w * (alpha_i alpha_j - Kinv_ij), zero outside the real N x N block
@@ -441,9 +506,9 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
             }
         }
     }
-    red[(NSUM - 1) * 256 + tid] = sn;
+    block_sum_to(sn, sred, out + sp.np);
 
-    // term by term: pass A forms the term product, pass B the per-factor lengthscale weights
+    // term by term: pass A forms the term product, pass B the per-factor (per-column, for ARD factors) lengthscale weights
     int f0 = 0;
     while (f0 < sp.nf) {
         int f1 = f0 + 1;
@@ -456,10 +521,9 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
             expo[e] = 0.0;
         }
         for (int f = f0; f < f1; ++f) {
-            const double l = sp.theta[2 * f + 1];
-            pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
+            const double inv_l2 = factor_r2(sp, f, sxi, sxj, ty, tx, r2);
             any_rbf = any_rbf || (sp.type[f] == MFGP_KERN_RBF);
-            apply_factor(sp.type[f], sp.theta[2 * f], 1.0 / (l * l), r2, prod, expo, varprod);
+            apply_factor(sp.type[f], sp.theta[sp.toff[f]], inv_l2, r2, prod, expo, varprod);
         }
         finish_term(prod, expo, varprod, any_rbf);
         double sv = 0.0;
@@ -469,26 +533,31 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
             sv += prod[e];
         }
         for (int f = f0; f < f1; ++f) {
-            const double l = sp.theta[2 * f + 1];
-            double g[16];
-            pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
-            factor_logderiv(sp.type[f], 1.0 / (l * l), r2, g);
-            double sl = 0.0;
+            block_sum_to(sv, sred, out + sp.toff[f]);          // every factor of the term shares sum G K_term
+            double rho[16];
+            const double inv_l2 = factor_r2(sp, f, sxi, sxj, ty, tx, r2);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sl = __builtin_fma(prod[e], g[e], sl);
-            red[(2 * f) * 256 + tid] = sv;
-            red[(2 * f + 1) * 256 + tid] = sl;
+            for (int e = 0; e < 16; ++e) r2[e] *= inv_l2;      // scaled squared distance s
+            factor_logderiv_over_s(sp.type[f], r2, rho);
+            if (sp.nl[f] == 1) {
+                double sl = 0.0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sl = __builtin_fma(prod[e] * rho[e], r2[e], sl);
+                block_sum_to(sl, sred, out + sp.toff[f] + 1);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rho[e] *= prod[e];
+                for (int d = sp.c0[f]; d < sp.c1[f]; ++d) {    // column d's share of s: (x_d - x'_d)^2 / l_d^2
+                    double col[16];
+                    pair_r2_ard(sp, sxi, sxj, ty, tx, d, d + 1, sp.toff[f] + 1 + (d - sp.c0[f]), col);
+                    double sl = 0.0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sl = __builtin_fma(rho[e], col[e], sl);
+                    block_sum_to(sl, sred, out + sp.toff[f] + 1 + (d - sp.c0[f]));
+                }
+            }
         }
         f0 = f1;
-    }
-    __syncthreads();
-    // block reduction in a fixed order: wave w reduces slots w, w+4, ...
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int i = wave; i < NSUM; i += 4) {
-        double v = (red[i * 256 + lane] + red[i * 256 + 64 + lane]) + (red[i * 256 + 128 + lane] + red[i * 256 + 192 + lane]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) partials[(int64_t)b * NSUM + i] = v;
     }
 }
 
@@ -508,8 +577,8 @@ __global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp,
     }
     if (tid == 0) {
         const double S = red[0];
-        if (i == NSUM - 1) out[2 * sp.nf] = -0.5 * S;
-        else if (i / 2 < sp.nf) out[i] = -0.5 * S / sp.theta[i];  // theta[2f]=var_f, theta[2f+1]=l_f
+        if (i == sp.np) out[sp.np] = -0.5 * S;                     // noise
+        else if (i < sp.np) out[i] = -0.5 * S / sp.theta[i];      // slot i = parameter i: sum G K_term / var, sum G K_term g / l
     }
 }
 
@@ -605,7 +674,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_rbf2_f64(Rbf2Spec sp, const dou
                 if (i == 0) out[0] = v;
                 if (i == 2) out[1] = v * (2.0 * sp.cb);
             }
-            if (i == 5) out[NSUM - 1] = v;
+            if (i == 5) out[sp.has2 ? 6 : 2] = v;       // noise slot = P (6 for the composite, 2 for one RBF)
         }
     }
 }
@@ -619,7 +688,7 @@ void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
                  const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
                  double* out) {
     const int nb = grad_num_partials(Np);
-    const size_t lds = kb_lds(spec.D) + (size_t)256 * NSUM * sizeof(double);
+    const size_t lds = kb_lds(spec.D) + (size_t)8 * sizeof(double);
     Rbf2Spec f;
     if (rbf2_match(spec, f)) {
         hipLaunchKernelGGL(mfgp_grad_rbf2_f64, dim3(nb), dim3(256), kb_lds(spec.D) + (size_t)256 * 6 * sizeof(double), s, f, X,
@@ -628,7 +697,7 @@ void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
         hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, Kinv, ld, alpha, N,
                            partials);
     }
-    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(NSUM), dim3(256), 0, s, spec, partials, nb, out);
+    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(spec.np + 1), dim3(256), 0, s, spec, partials, nb, out);
 }
 
 // var[i] = max(kss - ss[i], 1e-15) + add,  kss = sum_terms prod var_f  (GPy Kdiag of a stationary kernel)
@@ -642,7 +711,7 @@ __global__ void mfgp_finish_var_f64(KernSpecDev sp,
             prod = 1.0;
             cur = sp.term[f];
         }
-        prod *= sp.theta[2 * f];
+        prod *= sp.theta[sp.toff[f]];
     }
     kss += prod;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -120,9 +120,9 @@ static int create_body(mfgp_handle* h, int device_id) {
     // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
     // pinned, device-mapped host memory: no copy kernel at the end of a call and no fill kernel for the status at its
     // start (each costs ~5 us plus a gap; an evaluation at N <= 128 is ~75 us of GPU time in all)
-    HIPCHK(h, hipHostMalloc(&h->hres, 64 * sizeof(double), hipHostMallocMapped));
+    HIPCHK(h, hipHostMalloc(&h->hres, 128 * sizeof(double), hipHostMallocMapped));   // [0,1] scalars, [30] status, [48..51] append, [64..] gradient
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dres), h->hres, 0));
-    memset(h->hres, 0, 64 * sizeof(double));
+    memset(h->hres, 0, 128 * sizeof(double));
     HIPCHK(h, hipHostMalloc(&h->hio, (size_t)(mfgp_handle::IO_IN + 2 * mfgp_handle::IO_OUT) * sizeof(double), hipHostMallocMapped));
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dio), h->hio, 0));
     h->dinfo = reinterpret_cast<int*>(h->dres + 30);   // the pivot status lives beside the results
@@ -209,7 +209,7 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
         for (double** p : {&h->dY, &h->dz, &h->dalpha, &h->dvec, &h->dvec2})
             HIPCHK(h, hipMalloc(p, (size_t)cap * sizeof(double)));
         HIPCHK(h, hipMalloc(&h->dlogdet, (size_t)(cap / NB) * sizeof(double)));
-        HIPCHK(h, hipMalloc(&h->dpart, (size_t)grad_num_partials((int)cap) * (2 * MFGP_MAX_PARTS + 1) * sizeof(double)));
+        HIPCHK(h, hipMalloc(&h->dpart, (size_t)grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1) * sizeof(double)));
         h->cap = cap;
     }
     const bool replan = (Np != h->Np) || realloc_;   // (the plan's offsets depend on the slab stride = cap^2)
@@ -232,6 +232,17 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
     return 0;
 }
 
+int32_t mfgp_num_params(const mfgp_kern_part* parts, int32_t n_parts) {
+    if (!parts || n_parts < 1 || n_parts > MFGP_MAX_PARTS) return -1;
+    int np = 0;
+    for (int f = 0; f < n_parts; ++f) {
+        const int base = parts[f].type & ~MFGP_KERN_ARD;
+        if (base < 0 || base > MFGP_KERN_MATERN52 || parts[f].col_end <= parts[f].col_begin) return -1;
+        np += 1 + ((parts[f].type & MFGP_KERN_ARD) ? parts[f].col_end - parts[f].col_begin : 1);
+    }
+    return np;
+}
+
 int32_t mfgp_set_kernel(mfgp_handle* h, const mfgp_kern_part* parts, int32_t n_parts) {
     if (!h || !parts) return fail(h, -1, "mfgp_set_kernel: NULL argument");
     if (n_parts < 1 || n_parts > MFGP_MAX_PARTS) return fail(h, -1, "mfgp_set_kernel: 1..6 parts supported");
@@ -239,13 +250,19 @@ int32_t mfgp_set_kernel(mfgp_handle* h, const mfgp_kern_part* parts, int32_t n_p
     sp.nf = n_parts;
     sp.D = h->D;
     sp.ng = 0;
+    sp.np = 0;
     for (int f = 0; f < n_parts; ++f) {
         const mfgp_kern_part& p = parts[f];
-        if (p.type < 0 || p.type > MFGP_KERN_MATERN52) return fail(h, -1, "mfgp_set_kernel: unknown kernel type");
+        const int base = p.type & ~MFGP_KERN_ARD;
+        if (p.type < 0 || base > MFGP_KERN_MATERN52) return fail(h, -1, "mfgp_set_kernel: unknown kernel type");
         if (p.col_begin < 0 || p.col_end <= p.col_begin || p.col_end > 32)
             return fail(h, -1, "mfgp_set_kernel: bad column range");
         if (f > 0 && p.term < parts[f - 1].term) return fail(h, -1, "mfgp_set_kernel: term ids must be ascending");
-        sp.type[f] = p.type; sp.c0[f] = p.col_begin; sp.c1[f] = p.col_end; sp.term[f] = p.term;
+        sp.type[f] = base; sp.c0[f] = p.col_begin; sp.c1[f] = p.col_end; sp.term[f] = p.term;
+        sp.toff[f] = sp.np;
+        sp.nl[f] = (p.type & MFGP_KERN_ARD) ? p.col_end - p.col_begin : 1;
+        sp.np += 1 + sp.nl[f];
+        if (sp.np > MFGP_MAX_THETA) return fail(h, -1, "mfgp_set_kernel: more than MFGP_MAX_THETA kernel parameters");
         int g = -1;
         for (int k = 0; k < sp.ng; ++k)
             if (sp.gc0[k] == p.col_begin && sp.gc1[k] == p.col_end) g = k;
@@ -275,8 +292,8 @@ static int check_ready(mfgp_handle* h, const char* who) {
 // enqueue K-build + cholinv + solve (+ K^-1 + gradient); no host sync
 static int set_params(mfgp_handle* h, const double* theta, double noise, double jitter) {
     // the hyper-parameters ride in the kernel arguments (KernSpecDev::theta): nothing to upload
-    const int nf = h->spec.nf;
-    for (int i = 0; i < 2 * nf; ++i) {
+    const int np = h->spec.np;
+    for (int i = 0; i < np; ++i) {
         if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "parameters must be positive and finite");
         h->theta[i] = theta[i];
         h->spec.theta[i] = theta[i];
@@ -284,8 +301,8 @@ static int set_params(mfgp_handle* h, const double* theta, double noise, double 
     if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "noise and jitter must be >= 0");
     h->noise = noise; h->jitter = jitter;
     h->params_set = true;
-    h->spec.theta[2 * nf] = noise;
-    h->spec.theta[2 * nf + 1] = jitter;
+    h->spec.theta[np] = noise;
+    h->spec.theta[np + 1] = jitter;
     return 0;
 }
 
@@ -316,7 +333,7 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
         if (!stream_kinv) run_step(h, h->pl.kinv_step);   // (streamed plans have accumulated K^-1 behind the chain already)
         if (stages) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
-                    h->dpart, h->dres + 2);
+                    h->dpart, h->dres + 64);
         h->launches += 2;
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
     }
@@ -364,7 +381,7 @@ static int finish_eval(mfgp_handle* h, bool want_grad) {
     h->kinv_valid = want_grad;
     h->grad_valid = want_grad;
     if (want_grad)
-        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) h->grad[i] = h->hres[2 + i];
+        for (int i = 0; i < h->spec.np + 1; ++i) h->grad[i] = h->hres[64 + i];
     const int info = *h->hinfo;
     if (info != 0) {
         h->factorized = false;
@@ -388,7 +405,7 @@ int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitt
     if (rc) return rc;
     if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
     if (want_grad && grad)
-        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) grad[i] = h->grad[i];
+        for (int i = 0; i < h->spec.np + 1; ++i) grad[i] = h->grad[i];
     return 0;
 }
 
@@ -429,7 +446,7 @@ int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, doub
     if (rc) return rc;
     if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
     if (want_grad && grad)
-        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) grad[i] = h->grad[i];
+        for (int i = 0; i < h->spec.np + 1; ++i) grad[i] = h->grad[i];
     return 0;
 }
 
@@ -468,7 +485,7 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     int cur = h->spec.term[0];
     for (int f = 0; f < h->spec.nf; ++f) {
         if (h->spec.term[f] != cur) { kdiag += prod; prod = 1.0; cur = h->spec.term[f]; }
-        prod *= h->theta[2 * f];
+        prod *= h->theta[h->spec.toff[f]];
     }
     kdiag += prod + h->noise + h->jitter;
     launch_append_finish(s, h->buf[BUF_L], h->buf[BUF_S], (int)Np, n, h->dvec, h->dvec2, h->dz, kdiag, y_new, h->dres + 48,
@@ -508,13 +525,13 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
         run_step(h, h->pl.kinv_step);
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
-                    h->dpart, h->dres + 2);
+                    h->dpart, h->dres + 64);
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
         HIPCHK(h, hipStreamSynchronize(s));
         HIPCHK(h, hipGetLastError());
         h->tm.kinv_ms = h->timing ? ev_ms(h->ev[3], h->ev[4]) : 0.f;
         h->tm.grad_ms = h->timing ? ev_ms(h->ev[4], h->ev[5]) : 0.f;
-        for (int i = 0; i < 2 * h->spec.nf + 1; ++i) h->grad[i] = h->hres[2 + i];
+        for (int i = 0; i < h->spec.np + 1; ++i) h->grad[i] = h->hres[64 + i];
         h->kinv_valid = h->grad_valid = true;
         h->cum.grad_evals += 1;
         h->cum.kinv_ms += h->tm.kinv_ms;
@@ -522,7 +539,7 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
         h->cum.total_ms += h->tm.kinv_ms + h->tm.grad_ms;
         h->cum.kinv_flops += (double)h->Np * h->Np * h->Np / 3.0;
     }
-    for (int i = 0; i < 2 * h->spec.nf + 1; ++i) grad[i] = h->grad[i];
+    for (int i = 0; i < h->spec.np + 1; ++i) grad[i] = h->grad[i];
     return 0;
 }
 

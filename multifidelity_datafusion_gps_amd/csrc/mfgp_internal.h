@@ -16,9 +16,12 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // kernel-structure descriptor passed by value to the covariance kernels
 struct KernSpecDev {
-    double theta[2 * MFGP_MAX_PARTS + 2];   // [var_f, len_f]*, then noise, jitter: travels with the kernel arguments
-                                            // (no parameter upload per evaluation)
+    double theta[MFGP_MAX_THETA + 2]; // per factor: variance, lengthscale(s); then noise, jitter at [np], [np + 1]: travels
+                                      // with the kernel arguments (no parameter upload per evaluation)
     int32_t nf;                       // number of factors
+    int32_t np;                       // P = number of kernel parameters (include/mfgp.h: layout)
+    int32_t toff[MFGP_MAX_PARTS];     // index of variance_f in theta; its lengthscales follow
+    int32_t nl[MFGP_MAX_PARTS];       // lengthscales of factor f: 1 (isotropic) or c1 - c0 (MFGP_KERN_ARD)
     int32_t D;                        // columns of X
     int32_t type[MFGP_MAX_PARTS];
     int32_t c0[MFGP_MAX_PARTS];
@@ -128,10 +131,10 @@ struct mfgp_handle {
     mfgp::KernSpecDev spec{};
     bool have_kernel = false, have_data = false, factorized = false, kinv_valid = false, grad_valid = false,
          params_set = false;
-    double theta[2 * MFGP_MAX_PARTS] = {0};
+    double theta[MFGP_MAX_THETA] = {0};
     double noise = 0, jitter = 0;
     double quad = 0, logdet = 0;
-    double grad[2 * MFGP_MAX_PARTS + 1] = {0};
+    double grad[MFGP_MAX_THETA + 1] = {0};
     hipEvent_t ev[10] = {};
     mfgp_timings tm{};
     mfgp_counters cum{};

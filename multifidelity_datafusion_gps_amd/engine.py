@@ -29,7 +29,7 @@ import numpy as np
 from scipy import optimize as _sciopt
 
 from . import _lib
-from ._lib import KERN_MATERN32, KERN_MATERN52, KERN_RBF, NotPositiveDefinite
+from ._lib import KERN_ARD, KERN_MATERN32, KERN_MATERN52, KERN_RBF, NotPositiveDefinite
 
 _LIM_VAL = 36.0
 _LOG_LIM_VAL = np.log(np.finfo(np.float64).max)  # paramz: _log_lim_val
@@ -107,6 +107,42 @@ class Param:
         return "Param(%s=%.6g%s)" % (self.name, self._value, ", fixed" if self.fixed else "")
 
 
+class _ParamVector:
+    """the ARD lengthscales of one kernel seen as GPy sees them: one array-valued parameter"""
+
+    def __init__(self, params):
+        self.params = list(params)
+
+    @property
+    def values(self):
+        return np.array([p.value for p in self.params])
+
+    def __getitem__(self, i):
+        return self.values[i]
+
+    def __len__(self):
+        return len(self.params)
+
+    def __iter__(self):
+        return iter(self.values)
+
+    def fix(self):
+        for p in self.params:
+            p.fix()
+        return self
+
+    def unfix(self):
+        for p in self.params:
+            p.unfix()
+        return self
+
+    def constrain_positive(self):
+        return self
+
+    def __repr__(self):
+        return "ParamVector(lengthscale=%s)" % np.array2string(self.values, precision=6)
+
+
 # ------------------------------------------------------------------------------------------------
 # kernel specification objects
 # ------------------------------------------------------------------------------------------------
@@ -128,18 +164,21 @@ class Kern:
         out = []
         for term in self._terms():
             for f in term:
-                for p in (f.variance, f.lengthscale):
+                for p in [f.variance] + f.lengthscales:
                     if not any(p is q for q in out):
                         out.append(p)
         return out
 
     def engine_parts(self):
-        """flatten to the C-ABI description: parts [(type, c0, c1, term)], and per part (variance, lengthscale) Params"""
+        """flatten to the C-ABI description: parts [(type, c0, c1, term)], and per part (variance, [lengthscale Params]):
+        one lengthscale for an isotropic factor, one per active column for an ARD factor (include/mfgp.h layout)"""
         parts, plist = [], []
         for t, term in enumerate(self._terms()):
             for f in term:
-                parts.append((f.ktype, f.col_begin, f.col_end, t))
-                plist.append((f.variance, f.lengthscale))
+                parts.append((f.ktype | (KERN_ARD if f.ARD else 0), f.col_begin, f.col_end, t))
+                plist.append((f.variance, list(f.lengthscales)))
+        if sum(1 + len(ls) for _, ls in plist) > _lib.MAX_THETA:
+            raise NotImplementedError("kernel has more than %d parameters" % _lib.MAX_THETA)
         if len(parts) > _lib.MAX_PARTS:
             raise NotImplementedError("kernel expands to %d factors; the engine supports %d" % (len(parts), _lib.MAX_PARTS))
         return parts, plist
@@ -158,9 +197,10 @@ class Stationary(Kern):
     ktype = None
     _default_name = "stationary"
 
-    def __init__(self, input_dim, variance=1.0, lengthscale=1.0, ARD=False, active_dims=None, name=None):
-        if ARD:
-            raise NotImplementedError("ARD lengthscales are not used by the reference (src/abstractMFGP.py:60 passes none)")
+    def __init__(self, input_dim, variance=1.0, lengthscale=None, ARD=False, active_dims=None, name=None):
+        # ARD=True: one lengthscale per input dimension (GPy Stationary [GPy-recall]; the "ARD weights" of the reference's model
+        # docstrings, src/models/NARGP.py:13 -- the reference never passes the flag, its kern_class hooks are where a user would)
+        self.ARD = bool(ARD)
         self.input_dim = int(input_dim)
         if active_dims is None:
             active_dims = np.arange(self.input_dim)
@@ -174,7 +214,14 @@ class Stationary(Kern):
         self.col_end = int(active_dims[-1]) + 1
         self.name = name or self._default_name
         self.variance = Param("variance", variance)
-        self.lengthscale = Param("lengthscale", lengthscale)
+        ls = np.ones(self.input_dim if self.ARD else 1) if lengthscale is None else np.asarray(lengthscale, dtype=np.float64).reshape(-1)
+        if self.ARD and ls.size == 1:
+            ls = np.full(self.input_dim, ls[0])
+        if ls.size != (self.input_dim if self.ARD else 1):
+            raise ValueError("lengthscale must have %d entries" % (self.input_dim if self.ARD else 1))
+        self.lengthscales = [Param("lengthscale" if not self.ARD else "lengthscale[%d]" % i, v) for i, v in enumerate(ls)]
+        # GPy spelling: kern.lengthscale (a 1-vector, or one entry per dimension with ARD)
+        self.lengthscale = self.lengthscales[0] if not self.ARD else _ParamVector(self.lengthscales)
 
     def _terms(self):
         return [[self]]
@@ -182,7 +229,7 @@ class Stationary(Kern):
     def to_dict(self):
         return {"class": "GPy.kern." + type(self).__name__, "name": self.name, "input_dim": self.input_dim,
                 "active_dims": self.active_dims.tolist(), "variance": [self.variance.value],
-                "lengthscale": [self.lengthscale.value], "ARD": False}
+                "lengthscale": [p.value for p in self.lengthscales], "ARD": self.ARD}
 
 
 class RBF(Stationary):
@@ -373,8 +420,8 @@ class GPRegression:
 
     def _named_parameters(self):
         out = []
-        for i, (v, l) in enumerate(self._part_params):
-            for p, n in ((v, "variance"), (l, "lengthscale")):
+        for i, (v, ls) in enumerate(self._part_params):
+            for p, n in [(v, "variance")] + [(l, l.name) for l in ls]:
                 if not any(p is q for _, q in out):
                     out.append(("%s.kern_%d.%s" % (self.name, i, n), p))
         out.append(("%s.Gaussian_noise.variance" % self.name, self.likelihood.variance))
@@ -427,8 +474,8 @@ class GPRegression:
     # ---- evaluation --------------------------------------------------------------------------------
     def _theta(self):
         th = []
-        for v, l in self._part_params:
-            th += [v.value, l.value]
+        for v, ls in self._part_params:
+            th += [v.value] + [l.value for l in ls]
         return np.array(th)
 
     def _ensure(self, want_grad):
@@ -475,10 +522,11 @@ class GPRegression:
         """dNLML/d(param) for every distinct Param (shared params accumulate)"""
         self._ensure(True)
         g = self._grad_nat
-        acc = {}
-        for i, (v, l) in enumerate(self._part_params):
-            acc[id(v)] = acc.get(id(v), 0.0) + g[2 * i]
-            acc[id(l)] = acc.get(id(l), 0.0) + g[2 * i + 1]
+        acc, k = {}, 0
+        for v, ls in self._part_params:      # gradient layout = theta layout (variance, lengthscale(s) per part), noise last
+            for p in [v] + ls:
+                acc[id(p)] = acc.get(id(p), 0.0) + g[k]
+                k += 1
         acc[id(self.likelihood.variance)] = g[-1]
         for p in self.parameters():
             p.gradient = -acc[id(p)]  # GPy stores d log-likelihood / d param
@@ -536,7 +584,7 @@ class GPRegression:
         params = self.parameters()
         base = {id(p): p.value for p in params}
         free_ids = [id(p) for p in free]
-        part_ids = [(id(v), id(l)) for v, l in self._part_params]
+        part_ids = [[id(v)] + [id(l) for l in ls] for v, ls in self._part_params]
         term_ids = [[id(f.variance) for f in term] for term in self.kern._terms()]
         noise_id = id(self.likelihood.variance)
         state = {"fails": 0, "g": None}
@@ -546,7 +594,7 @@ class GPRegression:
             pv = _logexp_f(np.asarray(x, dtype=np.float64))
             for k, v in zip(free_ids, pv):
                 vals[k] = float(v)
-            theta = np.array([vals[k] for pair in part_ids for k in pair])
+            theta = np.array([vals[k] for ids in part_ids for k in ids])
             noise = vals[noise_id]
             jitter_extra, tries = 0.0, 0
             try:
@@ -570,10 +618,11 @@ class GPRegression:
                 state["fails"] += 1
                 stale = state["g"] if state["g"] is not None else np.zeros_like(pv)
                 return _F_FAILED, np.clip(stale, -_G_CLIP_FAILED, _G_CLIP_FAILED)
-            acc = {}
-            for i, (kv, kl) in enumerate(part_ids):
-                acc[kv] = acc.get(kv, 0.0) + g[2 * i]
-                acc[kl] = acc.get(kl, 0.0) + g[2 * i + 1]
+            acc, pos = {}, 0
+            for ids in part_ids:
+                for k in ids:
+                    acc[k] = acc.get(k, 0.0) + g[pos]
+                    pos += 1
             acc[noise_id] = g[-1]
             gf = _logexp_gradfactor(pv, np.array([acc[k] for k in free_ids]))
             state["g"] = gf

@@ -23,13 +23,25 @@ Reference call sites this follows (what the reference ASKS of the engine):
   * prediction: src/MFDataFusion.py:154-156, src/abstractMFGP.py:104
 
 Kernel description (same POD layout as include/mfgp.h): parts = [(type, col_begin, col_end, term)],
-theta = [var_0, len_0, var_1, len_1, ...];  K = sum_terms prod_{f in term} k_f.
+theta = [var_0, len_0, var_1, len_1, ...];  K = sum_terms prod_{f in term} k_f.  A factor whose type carries the ARD flag has one
+lengthscale per active column, in column order, in place of len_f (theta = [var_0, len_0_0 .. len_0_{k-1}, var_1, ...]).
 """
 import numpy as np
 from scipy.linalg import lapack
 
 RBF, MATERN32, MATERN52 = 0, 1, 2
+ARD = 0x100            # flag on the type: GPy's ARD=True (Stationary with one lengthscale per input dimension)
 LOG_2_PI = np.log(2.0 * np.pi)
+
+
+def layout(parts):
+    """-> [(index of variance_f, slice of its lengthscale(s))] and the number of kernel parameters P"""
+    out, i = [], 0
+    for ktype, c0, c1, _ in parts:
+        nl = (c1 - c0) if (ktype & ARD) else 1
+        out.append((i, slice(i + 1, i + 1 + nl)))
+        i += 1 + nl
+    return out, i
 
 
 # ------------------------------------------------------------------------------------------------
@@ -71,10 +83,13 @@ def dk_dr(ktype, variance, r):
 
 
 def _factor_r(part, lengthscale, X, X2):
-    _, c0, c1, _ = part
+    ktype, c0, c1, _ = part
     Xa = X[:, c0:c1]
     X2a = None if X2 is None else X2[:, c0:c1]
-    return unscaled_dist(Xa, X2a) / lengthscale   # Stationary._scaled_dist (non-ARD)
+    lengthscale = np.asarray(lengthscale, dtype=np.float64).reshape(-1)
+    if ktype & ARD:                                  # Stationary._scaled_dist, ARD branch: distances of the rescaled inputs
+        return unscaled_dist(Xa / lengthscale, None if X2a is None else X2a / lengthscale)
+    return unscaled_dist(Xa, X2a) / lengthscale[0]   # Stationary._scaled_dist (non-ARD)
 
 
 def _terms(parts):
@@ -87,10 +102,13 @@ def _terms(parts):
 def cov(parts, theta, X, X2=None):
     """K(X, X2) for the sum-of-products structure (Prod.K = product of part Ks, Add.K = sum)."""
     K = 0.0
+    lay, _ = layout(parts)
+    theta = np.asarray(theta, dtype=np.float64)
     for fs in _terms(parts):
         prod = 1.0
         for f in fs:
-            prod = prod * k_of_r(parts[f][0], theta[2 * f], _factor_r(parts[f], theta[2 * f + 1], X, X2))
+            iv, il = lay[f]
+            prod = prod * k_of_r(parts[f][0] & ~ARD, theta[iv], _factor_r(parts[f], theta[il], X, X2))
         K = K + prod
     return K
 
@@ -98,10 +116,11 @@ def cov(parts, theta, X, X2=None):
 def cov_diag(parts, theta, n):
     """Kdiag: stationary kernels return their variance; Prod multiplies, Add sums."""
     kss = 0.0
+    lay, _ = layout(parts)
     for fs in _terms(parts):
         prod = 1.0
         for f in fs:
-            prod *= theta[2 * f]
+            prod *= theta[lay[f][0]]
         kss += prod
     return np.full(n, kss)
 
@@ -112,22 +131,36 @@ def cov_param_grads(parts, theta, X, dL_dK):
     RBF/Stationary: variance.gradient = sum(K o dL_dK)/variance ;
                     lengthscale.gradient = -sum(dL_dr o r)/lengthscale , dL_dr = dK_dr o dL_dK.
     Prod: each part sees dL_dK multiplied by the K of the other parts of its product.
+    ARD (Stationary._lengthscale_grads_pure): lengthscale_q.gradient = -sum_ij (dL_dr / r)_ij (x_iq - x_jq)^2 / l_q^3,
+    with 1/r := 0 where r = 0 (Stationary._inv_dist).
     """
+    theta = np.asarray(theta, dtype=np.float64)
     g = np.zeros(len(theta))
+    lay, _ = layout(parts)
     for fs in _terms(parts):
         Ks, rs = {}, {}
         for f in fs:
-            rs[f] = _factor_r(parts[f], theta[2 * f + 1], X, None)
-            Ks[f] = k_of_r(parts[f][0], theta[2 * f], rs[f])
+            iv, il = lay[f]
+            rs[f] = _factor_r(parts[f], theta[il], X, None)
+            Ks[f] = k_of_r(parts[f][0] & ~ARD, theta[iv], rs[f])
         for f in fs:
+            iv, il = lay[f]
             other = 1.0
             for h in fs:
                 if h != f:
                     other = other * Ks[h]
             dl = dL_dK * other
-            g[2 * f] = np.sum(Ks[f] * dl) / theta[2 * f]
-            dL_dr = dk_dr(parts[f][0], theta[2 * f], rs[f]) * dl
-            g[2 * f + 1] = -np.sum(dL_dr * rs[f]) / theta[2 * f + 1]
+            g[iv] = np.sum(Ks[f] * dl) / theta[iv]
+            dL_dr = dk_dr(parts[f][0] & ~ARD, theta[iv], rs[f]) * dl
+            if parts[f][0] & ARD:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tmp = np.where(rs[f] > 0, dL_dr / rs[f], 0.0)
+                c0 = parts[f][1]
+                for q, ell in enumerate(theta[il]):
+                    dq = X[:, c0 + q:c0 + q + 1] - X[:, c0 + q:c0 + q + 1].T
+                    g[il.start + q] = -np.sum(tmp * np.square(dq)) / ell ** 3
+            else:
+                g[il.start] = -np.sum(dL_dr * rs[f]) / theta[il.start]
     return g
 
 

@@ -6,6 +6,7 @@ Test functions are the closed forms of the reference's experiment scripts
 import numpy as np
 
 RBF, M32, M52 = 0, 1, 2
+ARD = 0x100     # OR-ed into a type: one lengthscale per active column (include/mfgp.h MFGP_KERN_ARD)
 
 
 def hf_2d(x):
@@ -89,8 +90,22 @@ def make_case(name):
     if name == "rbf_addnoise_n60":  # the add_noise=True regime: sigma_n^2 = 1e-6 (src/MFDataFusion.py:154-155)
         X = rng.uniform(size=(60, 3)); Y = hf_3d(X)
         return dict(parts=single(RBF, 3), theta=[1.0, 0.25], noise=1e-6, X=X, Y=Y, Xs=rng.uniform(size=(16, 3)))
+    # ARD lengthscales (round 3): theta = [variance, l_0 .. l_{k-1}] per ARD factor, [variance, l] per isotropic one
+    if name == "rbf_ard_3d_n50":
+        X = rng.uniform(size=(50, 3)); Y = hf_3d(X)
+        return dict(parts=single(RBF | ARD, 3), theta=[1.3, 0.35, 0.6, 1.1], noise=0.01 * Y.var(), X=X, Y=Y, Xs=rng.uniform(size=(16, 3)))
+    if name == "nargp_ard_4d_n64":   # the composite with "ARD weights" on the two input-space factors (src/models/NARGP.py:13)
+        c = make_case("nargp_4d_n64")
+        c.update(parts=composite(4, 1, RBF, RBF | ARD, RBF | ARD),
+                 theta=[1.2, 1.1, 0.9, 0.6, 0.75, 0.5, 0.95, 0.4, 0.8, 0.55, 1.3, 0.7])
+        return c
+    if name == "matern_ard_mixed_n48":
+        c = make_case("matern52_mixed_n48")
+        c.update(parts=composite(4, 1, M52, RBF | ARD, M32 | ARD), theta=[1.1, 1.3, 0.7, 0.8, 0.6, 1.2, 0.9, 0.5, 0.9, 0.7, 1.4, 0.65])
+        return c
     raise KeyError(name)
 
 
 GOLDEN_CASES = ["rbf_3d_n50", "rbf_1d_forrester_lf", "nargp_1d_forrester_hf", "nargp_4d_n64", "gpdfc_2d_n40",
-                "gpdf_2d_n40", "matern32_3d_n48", "matern52_mixed_n48", "rbf_addnoise_n60"]
+                "gpdf_2d_n40", "matern32_3d_n48", "matern52_mixed_n48", "rbf_addnoise_n60",
+                "rbf_ard_3d_n50", "nargp_ard_4d_n64", "matern_ard_mixed_n48"]

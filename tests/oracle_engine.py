@@ -21,6 +21,7 @@ class OracleEngine:
     def set_kernel(self, parts):
         self.parts = [tuple(int(v) for v in p) for p in parts]
         self.n_parts = len(self.parts)
+        self.n_params = orc.layout(self.parts)[1]
 
     def eval(self, theta, noise, jitter=1e-8, want_grad=True):
         self.n_evals += 1

@@ -39,6 +39,36 @@ def test_gpregression_objective_gradient_and_transform_match_oracle():
     m.close()
 
 
+def test_ard_lengthscales_on_the_gpu_match_the_oracle_and_the_cpu_driver():
+    """ARD (MFGP_KERN_ARD): objective and per-column lengthscale gradients of the composite with ARD input-space factors against
+    the oracle in optimizer space, then the same L-BFGS-B driver on both back-ends from the same start."""
+    from scipy.optimize import fmin_l_bfgs_b
+    from multifidelity_datafusion_gps_amd import engine as gp
+    c = cases.make_case("nargp_ard_4d_n64")
+    k = gp.RBF(1, active_dims=[4]) * gp.RBF(4, active_dims=[0, 1, 2, 3], ARD=True) + gp.RBF(4, active_dims=[0, 1, 2, 3], ARD=True)
+    m = gp.GPRegression(c["X"], c["Y"][:, None], kernel=k)
+    assert m._parts == [tuple(p) for p in c["parts"]]
+    m.optimizer_array = orc.logexp_finv(np.array(list(c["theta"]) + [c["noise"]]))
+    x = m.optimizer_array.copy()
+    assert len(x) == 13
+    f, g = m._objective_grads(x)
+    fo, go = orc.objective_transformed(c["parts"], x, c["X"], c["Y"])
+    assert f == pytest.approx(fo, rel=1e-10)
+    np.testing.assert_allclose(g, go, rtol=0, atol=1e-8 * np.abs(go).max())
+    c1 = cases.make_case("rbf_ard_3d_n50")
+    m1 = gp.GPRegression(c1["X"], c1["Y"][:, None], kernel=gp.RBF(3, ARD=True))
+    run = m1.optimize(max_iters=200)
+    x0 = orc.logexp_finv(np.ones(5))
+    xo, fo1, _ = fmin_l_bfgs_b(lambda x_: orc.objective_transformed(c1["parts"], x_, c1["X"], c1["Y"]), x0, maxfun=200, maxiter=200)
+    assert run.f_opt == pytest.approx(fo1, rel=1e-6)
+    mean, var = m1.predict(c1["Xs"])
+    st = orc.inference(c1["parts"], m1._theta(), m1.likelihood.variance.value, c1["X"], c1["Y"], want_grad=False)
+    mu, v = orc.predict_stable(c1["parts"], m1._theta(), m1.likelihood.variance.value, c1["X"], st, c1["Xs"])
+    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-8 * max(1.0, np.abs(c1["Y"]).max()))
+    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-8)
+    m.close(); m1.close()
+
+
 def test_optimize_lowers_objective_and_matches_cpu_driver():
     """same L-BFGS-B driver on the GPU objective and on the oracle objective from the same start:
     trajectories agree to optimiser tolerance on this well-conditioned case."""

@@ -37,8 +37,10 @@ def test_golden_vectors(engine, name):
     tight = noise >= 1e-4
     nlml, grad, mean, var = _run(engine, parts, theta, noise, g["X"], g["Y"], g["Xs"])
     K = engine.get_K()
-    lmin = theta[1::2].min()
-    assert np.abs(K - g["K"]).max() <= 2e-13 * theta[0::2].max() ** 2 * (1 + 1 / lmin ** 2)
+    lay, _ = orc.layout(parts)
+    lmin = min(theta[il].min() for _, il in lay)
+    vmax = max(theta[iv] for iv, _ in lay)
+    assert np.abs(K - g["K"]).max() <= 2e-13 * max(vmax, 1.0) ** 2 * (1 + 1 / lmin ** 2)
     N = len(g["Y"])
     Ky = g["K"] + (noise + 1e-8) * np.eye(N)
     L = engine.get_L()

@@ -20,15 +20,18 @@ HUGE = 1e9   # length scale of an inactive column
 
 def _sk_factor(ktype, var, ls, c0, c1, D):
     scales = np.full(D, HUGE)
-    scales[c0:c1] = ls
+    scales[c0:c1] = ls            # one value (isotropic) or one per active column (ARD)
+    ktype &= ~orc.ARD
     base = SkRBF(length_scale=scales) if ktype == orc.RBF else Matern(length_scale=scales, nu=1.5 if ktype == orc.MATERN32 else 2.5)
     return C(var) * base
 
 
 def _sk_kernel(parts, theta, D):
     terms = {}
+    theta = np.asarray(theta, dtype=float)
+    lay, _ = orc.layout(parts)
     for i, (t, c0, c1, term) in enumerate(parts):
-        f = _sk_factor(t, theta[2 * i], theta[2 * i + 1], c0, c1, D)
+        f = _sk_factor(t, theta[lay[i][0]], theta[lay[i][1]], c0, c1, D)
         terms[term] = f if term not in terms else terms[term] * f
     k = None
     for t in sorted(terms):
@@ -45,8 +48,9 @@ def test_covariance_nlml_and_prediction_agree_with_sklearn(name):
     parts, theta, noise, X, Y, Xs = c["parts"], c["theta"], c["noise"], c["X"], c["Y"], c["Xs"]
     D = X.shape[1]
     k = _sk_kernel(parts, theta, D)
-    np.testing.assert_allclose(orc.cov(parts, theta, X), k(X), rtol=0, atol=1e-10 * np.abs(theta[::2]).sum())
-    np.testing.assert_allclose(orc.cov(parts, theta, X, Xs), k(X, Xs), rtol=0, atol=1e-10 * np.abs(theta[::2]).sum())
+    vsum = sum(abs(theta[iv]) for iv, _ in orc.layout(parts)[0])
+    np.testing.assert_allclose(orc.cov(parts, theta, X), k(X), rtol=0, atol=1e-10 * vsum)
+    np.testing.assert_allclose(orc.cov(parts, theta, X, Xs), k(X, Xs), rtol=0, atol=1e-10 * vsum)
     gpr = sk.GaussianProcessRegressor(kernel=k, alpha=noise + 1e-8, optimizer=None, normalize_y=False).fit(X, Y)
     st = orc.inference(parts, theta, noise, X, Y)
     lml = gpr.log_marginal_likelihood(gpr.kernel_.theta)
@@ -72,15 +76,21 @@ def test_gradient_agrees_with_sklearn(name):
     sizes = [h.n_elements for h in gpr.kernel_.hyperparameters]
     assert len(names) == 2 * len(parts)
     order = _tree_order(parts)
+    lay, _ = orc.layout(parts)
+    theta = np.asarray(theta, dtype=float)
     pos = 0
     for slot, i in enumerate(order):
         t, c0, c1, term = parts[i]
         n_c, n_l = sizes[2 * slot], sizes[2 * slot + 1]
         g_var = g_sk[pos]
-        g_len = g_sk[pos + n_c + c0: pos + n_c + c1].sum()      # the isotropic length scale is shared by the active columns
+        g_cols = g_sk[pos + n_c + c0: pos + n_c + c1]            # d/d log(length scale) of every active column
         pos += n_c + n_l
-        assert g_var == pytest.approx(theta[2 * i] * g[2 * i], rel=1e-7, abs=1e-7)
-        assert g_len == pytest.approx(theta[2 * i + 1] * g[2 * i + 1], rel=1e-7, abs=1e-7)
+        iv, il = lay[i]
+        assert g_var == pytest.approx(theta[iv] * g[iv], rel=1e-7, abs=1e-7)
+        if t & orc.ARD:                                          # one lengthscale per column
+            np.testing.assert_allclose(g_cols, theta[il] * g[il], rtol=1e-7, atol=1e-7)
+        else:                                                    # the isotropic length scale is shared by the active columns
+            assert g_cols.sum() == pytest.approx(theta[il][0] * g[il][0], rel=1e-7, abs=1e-7)
 
 
 def _tree_order(parts):
