@@ -24,7 +24,7 @@ def col(f):
 
 def _theta_noise(model):
     parts, plist = model.kernel.engine_parts()
-    theta = np.array([p.value for pair in plist for p in pair])
+    theta = np.array([q.value for v, ls in plist for q in [v] + ls])
     return parts, theta, model.hf_model.likelihood.variance.value
 
 

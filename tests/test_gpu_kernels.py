@@ -37,6 +37,27 @@ def test_gemm_nt_against_numpy(engine, tile, M, N, K):
     assert np.abs(Cn - A @ B.T).max() < 1e-12 * K
 
 
+@pytest.mark.parametrize("tile,n,K", [(128, 1536, 544), (64, 1152, 288), (128, 1024, 32), (64, 512, 32)])
+def test_dma_staged_gemm_many_workgroups_repeatable(engine, tile, n, K):
+    """race screen for the LDS-DMA staging of the bulk body (round 3: a new synchronisation structure -- counted vmcnt, raw
+    s_barrier, stages refilled while the other workgroup of the CU computes): launches of several hundred workgroups (two or
+    more per CU) with odd K-step counts, repeated; every repeat must be bit-identical and equal to numpy.  A stage read before
+    its DMA landed, or refilled before its last read, shows up as a changing or wrong tile."""
+    rng = np.random.default_rng(n + K)
+    A = rng.standard_normal((n, K))
+    B = rng.standard_normal((n, K))
+    C0 = rng.standard_normal((n, n))
+    ref = A @ B.T + C0
+    first = None
+    for rep in range(6):
+        C = engine.dbg_gemm_nt(A, B, C0, alpha=1.0, beta=1.0, tile=tile)
+        assert np.abs(C - ref).max() < 1e-12 * K
+        if first is None:
+            first = C
+        else:
+            np.testing.assert_array_equal(C, first)
+
+
 def _spd(n, rng, cond=1e3):
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     w = np.logspace(0, np.log10(cond), n)
