@@ -518,7 +518,14 @@ static void plan_sweep(Plan& p) {
     // Up to 13 block columns ONE macro panel (and then one stream and K^-1 on the chain, see the end): N = 1024 0.527 -> 0.42,
     // 1280 0.60 -> 0.55, 1536 0.72 -> 0.68 (1792: 0.825 either way, 2048: 0.94 / 0.99 in favour of two-column panels).
     // Between: 6 for 52 .. 63 block columns (N = 6656 7.96 -> 7.81 ms, 7040 9.35 -> 8.95, 7680 11.3 -> 11.0 against 4 / 8).
-    int MB = nb >= 96 ? 16 : (nb >= 64 ? 8 : (nb >= 52 ? 6 : (nb > 40 ? 4 : (nb > 32 ? 3 : (nb > 13 ? 2 : nb)))));
+    // Round 3 (bulk kernels on the 4x4x4 MFMA, 52-62 TFLOP/s per launch instead of 47-50): the bulk stream is no longer the
+    // longer side, the chain is -- and the in-macro K = 128 updates are chain work, so SHORTER macro panels win at every size
+    // (profiles/r03_macro_sweep.txt, one evaluation alone, ms at MB = 2 / 3 / 4 / 5 / 6 / 8 / 16):
+    //   N = 2048 0.88 / 0.83 / 0.85;  3072 1.55 / 1.42 / 1.56;  3584 1.82 / 2.11 / 2.15;  4096 2.32 / 2.50 / 2.65;
+    //   6144 6.02 / 6.21 / 6.22 / 6.24 / 6.29;  8192 12.27 / 12.05 / 11.80 / 11.92 / 12.00 / 12.35 / 13.5;
+    //   12288 - / - / 34.50 / 34.48 / 34.66 / 36.0 / 37.2;  16384 - / - / 75.9 / 75.7 / 77.6 / 77.9 / 81.7
+    // (rounds 1-2 had 2 / 3 / 4 / 6 / 8 / 16 from 14 / 33 / 41 / 52 / 64 / 96 block columns up).
+    int MB = nb >= 80 ? 5 : (nb >= 56 ? 4 : (nb >= 25 ? 2 : (nb > 13 ? 3 : nb)));
     if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
     bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
