@@ -576,6 +576,244 @@ LAB_KERNEL_O(lab_o128_w42_k32s2, 128, 128, 4, 2, 32, 2, false, 1)     // 8 waves
 LAB_KERNEL_O(lab_o128_w42_k32s2w, 128, 128, 4, 2, 32, 2, true, 1)
 LAB_KERNEL_O(lab_o64_w22_k32s2, 64, 64, 2, 2, 32, 2, false, 2)
 
+// ---- two independent 4-wave teams in ONE 8-wave workgroup (128 KB), persistent over a task counter ------------------------------
+// Why: with two 64 KB workgroups per CU a kernel that needs a whole CU (the leaf: 138 KB) starves until the bulk launch has no
+// workgroup left to dispatch -- every slot a retiring workgroup frees is refilled at once (timeline at N = 8192: the leaf waits
+// 365 us per macro panel, chain and bulk stream do not overlap any more).  One 128 KB workgroup per CU keeps the leaf's wait at one
+// workgroup's retirement, and a grid of fewer workgroups than CUs leaves CUs free for the chain altogether -- if the two halves of
+// the workgroup stay as independent as two workgroups were: separate tasks, separate LDS stages, separate (software) barriers.
+#ifndef LAB_TEAM_SLEEP
+#define LAB_TEAM_SLEEP 0
+#endif
+__device__ __forceinline__ void team_barrier(volatile unsigned* bar, unsigned& epoch) {
+    // every LDS operation of this wave has completed (the callers wait lgkmcnt(0) / vmcnt as their protocol needs) -> arrive, poll
+    epoch += 4;
+    if ((threadIdx.x & 63) == 0) atomicAdd(const_cast<unsigned*>(bar), 1u);
+    unsigned spins = 0;
+    while ((int)(*bar - epoch) < 0) {      // wave-uniform broadcast read
+        if (LAB_TEAM_SLEEP) __builtin_amdgcn_s_sleep(LAB_TEAM_SLEEP);
+        if (++spins > (1u << 22)) break;   // bounded: a lost wave ends the kernel with wrong numbers, never with a hang
+    }
+}
+template <int BM, int BN, int WM, int WN, int KT, int NST>
+__device__ __forceinline__ void gemm_team_body(const GemmTask t, const double* A, const double* B, double* C, double* C2, int ld,
+                                               char* const smem_b, const int wave, volatile unsigned* bar, unsigned& epoch) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);
+    constexpr int ROWB = KT * 8;                 // bytes per tile row and stage
+    constexpr int CPR = KT / 2, SWM = CPR - 1;   // 16-byte chunks per row; XOR mask of the chunk swizzle
+    constexpr int RPI = 1024 / ROWB;             // tile rows per DMA wave-instruction (1 KiB)
+    constexpr int NA = BM / (RPI * NW), NBC = BN / (RPI * NW);
+    constexpr int NG = KT / 8;                   // 8-column groups per K-step
+    static_assert(NA >= 1 && NBC >= 1 && (KT == 16 || KT == 32) && NST >= 2 && NST <= 4, "tile / stage combination");
+    static_assert((RPI * NW) % CPR == 0, "a wave's DMA row blocks must share one swizzle phase");
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int B_BASE = NST * A_BYTES;
+    const int lane = threadIdx.x & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, q = lane >> 4, cb = (lane >> 2) & 3;
+    const double* Ap = A + t.a_off;
+    const double* Bp = B + t.b_off;
+    const int nk = t.klen / KT;
+    const bool a_lo = t.flags & TF_A_LOWER, a_up = t.flags & TF_A_UPPER;
+    const bool b_lo = t.flags & TF_B_LOWER, b_up = t.flags & TF_B_UPPER;
+    const bool any_mask = (t.flags & (TF_A_LOWER | TF_A_UPPER | TF_B_LOWER | TF_B_UPPER)) != 0;
+    const int a_lo_shift = t.klen - BM, b_lo_shift = t.klen - BN;
+
+    // acc[mi][ni][s]: rotation s of the 16x16 block (mi, ni): row 16 mi + 4 ((cb + s) & 3) + q, column 16 ni + fr
+    double acc[TM][TN][4];
+    double* const Cp = C + t.c_off;
+    const bool preload = (t.beta != 0.0);
+    const double c_scale = preload ? t.beta / t.alpha : 0.0;
+    if (preload) {   // ONE branch around all the loads: issued together, waited for progressively (inside the element loop the
+                     // compiler emits a branch, a load and a vmcnt(0) per element: 32-64 serial round trips per tile)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb + r) & 3) + q;
+                    const int col = wn * (BN / WN) + ni * 16 + fr;
+                    acc[mi][ni][r] = c_scale * Cp[(int64_t)row * ld + col];
+                }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
+    }
+    // DMA: wave-instruction u of this wave covers tile rows r0 = RPI (wave + NW u) .. r0 + RPI - 1; lane l lands at LDS byte
+    // r0 ROWB + 16 l = (row r0 + l / CPR, slot l % CPR) and therefore fetches chunk slot ^ (row & SWM) of that row.
+    const int dl_row = lane / CPR, dl_slot = lane % CPR;
+    const int drow = ((RPI * wave) + dl_row) & SWM;              // (row & SWM) of this lane's rows: the same for every u
+    // ONE 64-bit lane pointer per operand; the row block of instruction u and the K-step are scalar offsets added per
+    // instruction (laundered so that they are not folded back into eight loop-invariant vector bases: 12 VGPRs)
+    const double* const a_lane = Ap + (dl_row * ld + 2 * (dl_slot ^ drow));
+    const double* const b_lane = Bp + (dl_row * ld + 2 * (dl_slot ^ drow));
+    auto dma_tiles = [&](int kt, int st) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int r0 = RPI * (wave + NW * u);
+            int off = r0 * ld + kt * KT;
+            asm volatile("" : "+s"(off));
+            __builtin_amdgcn_global_load_lds(a_lane + off, (lds_ptr_t)(smem_b + st * A_BYTES + r0 * ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int r0 = RPI * (wave + NW * u);
+            int off = r0 * ld + kt * KT;
+            asm volatile("" : "+s"(off));
+            __builtin_amdgcn_global_load_lds(b_lane + off, (lds_ptr_t)(smem_b + B_BASE + st * B_BYTES + r0 * ROWB), 16, 0, 0);
+        }
+    };
+    auto fix_masks = [&](int kt, int st) {
+        int dr = dl_row, ds = dl_slot ^ drow;
+        asm volatile("" : "+v"(dr), "+v"(ds));   // rare path: recompute per call instead of keeping per-chunk rows live
+        const int k = kt * KT + 2 * ds;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int r0 = RPI * (wave + NW * u), row = r0 + dr;
+            bool zx = false, zy = false;
+            if (a_lo) { zx |= (k > row + a_lo_shift); zy |= (k + 1 > row + a_lo_shift); }
+            if (a_up) { zx |= (k < row); zy |= (k + 1 < row); }
+            double* p = reinterpret_cast<double*>(smem_b + st * A_BYTES + r0 * ROWB + lane * 16);
+            if (zx) p[0] = 0.0;
+            if (zy) p[1] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int r0 = RPI * (wave + NW * u), row = r0 + dr;
+            bool zx = false, zy = false;
+            if (b_lo) { zx |= (k > row + b_lo_shift); zy |= (k + 1 > row + b_lo_shift); }
+            if (b_up) { zx |= (k < row); zy |= (k + 1 < row); }
+            double* p = reinterpret_cast<double*>(smem_b + B_BASE + st * B_BYTES + r0 * ROWB + lane * 16);
+            if (zx) p[0] = 0.0;
+            if (zy) p[1] = 0.0;
+        }
+    };
+    // Fragment addresses: chunk(g) = (4 g + q) ^ (row & SWM) = chunk(0) ^ 4 g, so group g is group 0 with byte-offset bit 6
+    // (and 7) flipped: five address registers per lane (four rotations of A, one for B), everything else immediate.
+    int a_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = (fr + 4 * r) & 15;
+        a_off[r] = (wm * (BM / WM) + row) * ROWB + ((q ^ (row & SWM)) << 4);
+    }
+    const int b_off = (wn * (BN / WN) + fr) * ROWB + ((q ^ (fr & SWM)) << 4) + B_BASE;
+    // One 8-column group.  The A fragments are taken one row block at a time (MH) where TM = 4: with all of them in flight the body
+    // needs 256 VGPRs, and two such waves per SIMD leave no register for a wave of the serial chain's kernels, which then wait
+    // for a bulk workgroup to retire (measured: chain launches 27 -> 46 us at N = 8192).  As written: 206, so a chain wave of
+    // up to 96 registers fits beside two bulk waves.  (No sched_barrier inside the group: pinning the order there makes the
+    // register allocator ping-pong 40 of the 64 accumulators between two registers -- MFMAs with D != C -- 240 VGPRs.)
+    auto group = [&](int st, auto GC) {
+        constexpr int g = decltype(GC)::value;
+        constexpr int MH = TM > 2 ? TM / 4 : TM;
+        d2_t b[TN];
+        const char* pb = smem_b + st * B_BYTES + (b_off ^ (g << 6));
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const d2_t*>(pb + ni * (16 * ROWB));
+#pragma unroll
+        for (int m0 = 0; m0 < TM; m0 += MH) {
+            d2_t a[MH][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const char* pa = smem_b + st * A_BYTES + (a_off[r] ^ (g << 6));
+#pragma unroll
+                for (int mi = 0; mi < MH; ++mi) a[mi][r] = *reinterpret_cast<const d2_t*>(pa + (m0 + mi) * (16 * ROWB));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[m0 + mi][ni][r] =
+                                __builtin_amdgcn_mfma_f64_4x4x4f64(a[mi][r][h], b[ni][h], acc[m0 + mi][ni][r], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)      // prologue: NST - 1 stages in flight
+        if (s0 < nk) dma_tiles(s0, s0);
+    int st = 0;                               // stage of K-step kt
+    for (int kt = 0; kt < nk; ++kt) {
+        // K-step kt's DMA is this wave's oldest outstanding one: the younger NST - 2 stages stay in flight
+        if (NST == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NBC)) : "memory");
+        if (any_mask) fix_masks(kt, st);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        team_barrier(bar, epoch);
+        {
+            const int kn = kt + NST - 1;      // refill the stage K-step kt - 1 used
+            int sn = st - 1;
+            if (sn < 0) sn += NST;
+            if (kn < nk) dma_tiles(kn, sn);
+        }
+        group(st, I0{});
+        group(st, I1{});
+        if (NG == 4) {
+            group(st, I2{});
+            group(st, I3{});
+        }
+        st = (st + 1 == NST) ? 0 : st + 1;
+    }
+    const double alpha = t.alpha;
+    const bool mirror = (t.c2_off >= 0);
+    double* C2p = C2 + (mirror ? t.c2_off : 0);
+    // output addresses from laundered lane indices: shared with the pre-load they would stay live across the K loop
+    int q2 = q, fr2 = fr, cb2 = cb;
+    asm volatile("" : "+v"(q2), "+v"(fr2), "+v"(cb2));
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb2 + r) & 3) + q2;
+                const int col = wn * (BN / WN) + ni * 16 + fr2;
+                const double v = alpha * acc[mi][ni][r];
+                Cp[(int64_t)row * ld + col] = v;
+                if (mirror) C2p[(int64_t)col * ld + row] = v;
+            }
+}
+
+
+template <int RESERVED>
+__global__ __launch_bounds__(512, 1) void lab_team_persist(const GemmTask* __restrict__ tasks, int ntasks, unsigned* counter,
+                                                           const double* A, const double* B, double* C, double* C2, int ld) {
+    extern __shared__ __attribute__((aligned(1024))) double smem[];
+    char* const base = reinterpret_cast<char*>(smem);
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int team = wave8 >> 2, wave = wave8 & 3;
+    unsigned* const ctl = reinterpret_cast<unsigned*>(base + 2 * 65536) + team * 32;    // [0] barrier counter, [16] next task
+    if (threadIdx.x < 64) reinterpret_cast<unsigned*>(base + 2 * 65536)[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned epoch = 0;
+    for (int round = 0;; ++round) {
+        unsigned t;
+        if (RESERVED == 2) {               // probe: one task per team, no counter (what the fetch and the lost locality cost)
+            if (round) break;
+            t = 2 * blockIdx.x + team;
+        } else {
+            if (wave == 0 && (threadIdx.x & 63) == 0) ctl[16] = atomicAdd(counter, 1u);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            team_barrier(ctl, epoch);
+            t = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(ctl + 16));
+        }
+        if (t >= (unsigned)ntasks) break;
+        gemm_team_body<128, 128, 2, 2, 16, 2>(tasks[t], A, B, C, C2, ld, base + team * 65536, wave, ctl, epoch);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        team_barrier(ctl, epoch);        // every wave of the team is through with the task's LDS stages and with ctl[16]
+    }
+}
+
 #define LAB_KERNEL_G(NAME, BM, BN, WM, WN)                                                                                  \
     __global__ __launch_bounds__(64 * WM * WN, 1) void NAME(const GemmTask* __restrict__ tasks, const double* A,            \
                                                           const double* B, double* C, double* C2, int ld) {                \
@@ -611,6 +849,8 @@ static const Variant g_variants[] = {
     {"p64_w22_m0", lab_p64_w22_m0, 64, 256}, {"p64_w42_m0", lab_p64_w42_m0, 64, 512},
     {"g128_w42_m0", lab_g128_w42_m0, 128, 512}, {"g128_w22_m0", lab_g128_w22_m0, 128, 256}, {"g64_w22_m0", lab_g64_w22_m0, 64, 256},
     {"g64hi_w22_m0", lab_g64_w22_hi, -64, 256},
+    {"team128_persist_m0", nullptr, 128, 512, 2 * 65536 + 1280},
+    {"team128_onetask_m0", nullptr, 1128, 512, 2 * 65536 + 1280},
     {"o128_w22_k16s2_m0", lab_o128_w22_k16s2, 128, 256, 2 * 32768}, {"o128_w22_k16s2w", lab_o128_w22_k16s2w, 128, 256, 2 * 32768},
     {"o128_w42_k16s4_m0", lab_o128_w42_k16s4, 128, 512, 4 * 32768}, {"o128_w42_k32s2_m0", lab_o128_w42_k32s2, 128, 512, 2 * 65536},
     {"o128_w42_k32s2w", lab_o128_w42_k32s2w, 128, 512, 2 * 65536}, {"o64_w22_k32s2_m0", lab_o64_w22_k32s2, 64, 256, 2 * 32768},
@@ -628,7 +868,9 @@ __global__ void lab_fill(double* p, int64_t n, unsigned seed) {
 }
 }  // namespace lab
 
+static int g_persist_grid = 250;
 extern "C" {
+void lab_set_persist_grid(int g) { g_persist_grid = g; }
 int lab_num_variants() { return lab::NVAR; }
 const char* lab_variant_name(int v) { return (v >= 0 && v < lab::NVAR) ? lab::g_variants[v].name : ""; }
 
@@ -640,7 +882,8 @@ int lab_run(int variant, int n, int K, int flags, double beta, int reps, double*
     using namespace lab;
     if (variant < 0 || variant >= NVAR) return -1;
     const Variant& v = g_variants[variant];
-    const int tile = v.tile < 0 ? -v.tile : v.tile;
+    const bool onetask = (v.tile == 1128);
+    const int tile = onetask ? 128 : (v.tile < 0 ? -v.tile : v.tile);
     if (n % tile || K % 32 || K > n) return -1;
     double *S = nullptr, *Cm = nullptr;
     GemmTask* dt = nullptr;
@@ -663,10 +906,28 @@ int lab_run(int variant, int n, int K, int flags, double beta, int reps, double*
     if (hipMalloc(&dt, ts.size() * sizeof(GemmTask)) != hipSuccess) return -2;
     hipMemcpy(dt, ts.data(), ts.size() * sizeof(GemmTask), hipMemcpyHostToDevice);
     const size_t lds = v.lds ? (size_t)v.lds : (size_t)2 * (tile + tile) * 32 * 8 + (v.tile < 0 ? 65536 : 0);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (v.k) hipFuncSetAttribute(reinterpret_cast<const void*>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(v.k, dim3((unsigned)ts.size()), dim3(v.threads), lds, 0, dt, S, S, Cm, nullptr, n);   // warm + result
+    unsigned* ctr = nullptr;
+    hipMalloc(&ctr, 64);
+    const int grid_p = std::min((int)(ts.size() + 1) / 2, g_persist_grid);
+    auto launch = [&]() {
+        if (v.k) {
+            hipLaunchKernelGGL(v.k, dim3((unsigned)ts.size()), dim3(v.threads), lds, 0, dt, S, S, Cm, nullptr, n);
+        } else {
+            hipMemsetAsync(ctr, 0, 4, 0);
+            if (onetask)
+                hipLaunchKernelGGL(lab_team_persist<2>, dim3((unsigned)(ts.size() + 1) / 2), dim3(512), lds, 0, dt, (int)ts.size(), ctr, S, S, Cm, nullptr, n);
+            else
+                hipLaunchKernelGGL(lab_team_persist<0>, dim3(grid_p), dim3(512), lds, 0, dt, (int)ts.size(), ctr, S, S, Cm, nullptr, n);
+        }
+    };
+    if (!v.k) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lab_team_persist<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lab_team_persist<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    launch();   // warm + result
     if (out || ref) {
         std::vector<double> host((size_t)n * n);
         hipMemcpy(host.data(), Cm, bytes, hipMemcpyDeviceToHost);
@@ -678,15 +939,14 @@ int lab_run(int variant, int n, int K, int flags, double beta, int reps, double*
         }
     }
     hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(v.k, dim3((unsigned)ts.size()), dim3(v.threads), lds, 0, dt, S, S, Cm, nullptr, n);
+    for (int r = 0; r < reps; ++r) launch();
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float t_ms = 0.f;
     hipEventElapsedTime(&t_ms, e0, e1);
     *ms = t_ms / reps;
     const hipError_t err = hipGetLastError();
-    hipFree(S); hipFree(Cm); hipFree(dt);
+    hipFree(S); hipFree(Cm); hipFree(dt); hipFree(ctr);
     hipEventDestroy(e0); hipEventDestroy(e1);
     return err == hipSuccess ? 0 : -3;
 }

@@ -51,6 +51,8 @@ for v, name in enumerate(names):
             assert rc == 0, (name, rc)
             worst = max(worst, md.value)
     print("%-14s max |C - numpy| = %.3e %s" % (name, worst, "OK" if worst < 1e-10 else "WRONG"), flush=True)
+if hasattr(lib, "lab_set_persist_grid"):
+    lib.lab_set_persist_grid(int(os.environ.get("LAB_PERSIST_GRID", "250")))
 print("== launch time, n = 8192")
 for K in (512, 2048):
     for v, name in enumerate(names):

@@ -416,6 +416,23 @@ void run_probe_444_layout(hipStream_t s, const double* a, const double* b, const
     hipFree(da); hipFree(db); hipFree(dc); hipFree(dd);
 }
 
+// ---- where does the dispatcher put the workgroups of a launch that does not fill the chip?  (round 3) ---------------------------
+// G workgroups of 256 threads with `lds` bytes of LDS each record (XCC id, HW_ID) and stay resident for ~hold_us, so that the
+// placement of the whole grid is seen at once.  Question: does a grid of 2 x 250 64-KB workgroups leave six CUs EMPTY (a kernel
+// that needs a whole CU could start at once) or twelve CUs half full?
+__global__ __launch_bounds__(256) void mfgp_probe_placement(unsigned* out, long long hold_ticks) {
+    extern __shared__ double lds_dummy[];
+    if (threadIdx.x == 0) {
+        lds_dummy[0] = 1.0;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID (id 4), 32 bits
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID (id 20), bits 3:0
+        out[2 * blockIdx.x] = hw;
+        out[2 * blockIdx.x + 1] = xcc;
+    }
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -474,6 +491,18 @@ int32_t mfgp_probe_mfma444_layout(int32_t device, const double* a, const double*
     if (hipStreamCreate(&s) != hipSuccess) return -2;
     mfgp::run_probe_444_layout(s, a, b, c, out7x64);
     hipStreamDestroy(s);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// out[2 g] = HW_ID, out[2 g + 1] = XCC_ID of workgroup g of a grid of G workgroups with lds_bytes of LDS each
+int32_t mfgp_probe_placement(int32_t device, int32_t G, int32_t lds_bytes, int32_t hold_us, uint32_t* out) {
+    if (!out || hipSetDevice(device) != hipSuccess) return -1;
+    unsigned* d = nullptr;
+    if (hipMalloc(&d, (size_t)G * 8) != hipSuccess) return -2;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(mfgp::mfgp_probe_placement), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(mfgp::mfgp_probe_placement, dim3(G), dim3(256), (size_t)lds_bytes, 0, d, (long long)hold_us * 100);
+    hipDeviceSynchronize();
+    hipMemcpy(out, d, (size_t)G * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 // out32: see tools/probes/probes.py (fp64_shapes) for the layout
