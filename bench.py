@@ -233,6 +233,9 @@ def _rate(num, ms):
     return num / (ms * 1e-3) if ms > 0 else 0.0
 
 
+EXIT_PEER_LOST = 4    # a rank whose peer vanished mid-collective (the launcher reports the rank that vanished, not this one)
+
+
 def launch_ranks(n_ranks, argv, script=None):
     """the --gpus N > 1 job started as a plain process: N child processes of this script, one rank per GPU.  Runs BEFORE
     this process imports the engine or touches HIP (it never does).  Children inherit stdout / stderr, so rank 0's JSON
@@ -253,20 +256,33 @@ def launch_ranks(n_ranks, argv, script=None):
     for r in range(n_ranks):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
-    rc = 0
+    failed = []                         # (rank, code) in the order the launcher saw them end
     live = list(procs)
+    deadline = None
     while live:
-        time.sleep(0.2)
+        time.sleep(0.05)
         for p in list(live):
             code = p.poll()
             if code is None:
                 continue
             live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 128 - code
-                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (procs.index(p), code))
-                for q in live:          # exactly the processes started above: they would wait for ever in a collective
-                    q.terminate()
+            if code != 0:
+                failed.append((procs.index(p), code))
+        if failed and deadline is None:
+            # a rank that fails takes its peers down with it (their next collective raises ConnectionError -> EXIT_PEER_LOST):
+            # give them a moment to say so, so that the code reported is the ORIGINATING rank's, then stop whatever is left
+            deadline = time.monotonic() + 1.0
+        if deadline is not None and time.monotonic() >= deadline:
+            for q in live:              # exactly the processes started above: they would wait for ever in a collective
+                q.terminate()
+            deadline = float("inf")
+    rc = 0
+    if failed:
+        origin = [f for f in failed if f[1] != EXIT_PEER_LOST] or failed
+        r0, c0 = origin[0]
+        rc = c0 if c0 > 0 else 128 - c0
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were stopped%s\n" % (
+            r0, c0, "".join(" [rank %d: %d]" % f for f in failed if f != (r0, c0))))
     for p in procs:
         try:
             p.wait(timeout=30)
@@ -480,4 +496,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except ConnectionError as ex:
+        if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+            raise
+        # a peer vanished mid-collective: say so with a code of its own, so that the launcher reports the rank that failed first
+        sys.stderr.write("bench.py: rank %s lost a peer: %s\n" % (os.environ.get("RANK", "?"), ex))
+        sys.stderr.flush()
+        os._exit(EXIT_PEER_LOST)

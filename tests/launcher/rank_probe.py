@@ -19,8 +19,11 @@ seen = comm.allgather_object({"rank": rank, "local_rank": int(os.environ["LOCAL_
                               "token": bool(os.environ.get("MFGP_COMM_TOKEN")), "addr": os.environ["MASTER_ADDR"]})
 if rank == fail_rank:
     sys.exit(7)
-res = _run_model(comm, 2)
-comm.barrier()          # with a failed rank the others wait here until the launcher stops them
+try:
+    res = _run_model(comm, 2)
+    comm.barrier()      # with a failed rank the others wait here until the launcher stops them, or lose their peer
+except ConnectionError:
+    sys.exit(4)         # bench.EXIT_PEER_LOST, as bench.py's own ranks do
 if rank == 0:
     print(json.dumps({"seen": seen, "mean_sum": float(res["mean"].sum()), "var_sum": float(res["var"].sum()),
                       "theta": res["theta"].tolist()}), flush=True)

@@ -471,9 +471,58 @@ void run_probe(hipStream_t s, double* mfma_tflops, double* copy_gbs) {
     hipEventDestroy(e1);
 }
 
+
+// ---- sustained matrix load (round 3): does the 71 TFLOP/s of the ~30 ms bare loops hold over SECONDS? --------------------
+// The bench keeps the fp64 matrix pipe busy for 1.5 s at a time; a part that is power- or thermally managed lowers its clock
+// under such a load, and then the ceiling a sustained job can reach is lower than the burst figure.  `launches` back-to-back
+// launches of the 4x4x4_4b loop (1 wave per SIMD, random operands, ~25 ms each): per launch TFLOP/s (events) and the
+// in-kernel clock (s_memtime / s_memrealtime, median over waves).  shape 0 = 16x16x4 for comparison.
+void run_probe_sustained(hipStream_t s, int shape, int launches, double* out) {
+    std::vector<hipEvent_t> ev(launches + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    unsigned long long* dbuf = nullptr;
+    const int blocks = 256, nw = blocks * 4;
+    hipMalloc(&dbuf, sizeof(unsigned long long) * 2 * nw * (size_t)launches);
+    const int iters = shape == 0 ? 64000 : 256000;
+    hipEventRecord(ev[0], s);
+    for (int l = 0; l < launches; ++l) {
+        unsigned long long* o = dbuf + (size_t)l * 2 * nw;
+        if (shape == 0) hipLaunchKernelGGL((mfgp_probe_fp64_shape<0, false>), dim3(blocks), dim3(256), 0, s, o, iters);
+        else hipLaunchKernelGGL((mfgp_probe_fp64_shape<1, false>), dim3(blocks), dim3(256), 0, s, o, iters);
+        hipEventRecord(ev[l + 1], s);
+    }
+    hipEventSynchronize(ev[launches]);
+    std::vector<unsigned long long> hb(2 * (size_t)nw * launches);
+    hipMemcpy(hb.data(), dbuf, sizeof(unsigned long long) * hb.size(), hipMemcpyDeviceToHost);
+    const double nm = (double)iters * 8.0;
+    for (int l = 0; l < launches; ++l) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev[l], ev[l + 1]);
+        std::vector<double> clk(nw);
+        for (int w = 0; w < nw; ++w)
+            clk[w] = (double)hb[(size_t)l * 2 * nw + 2 * w] / ((double)hb[(size_t)l * 2 * nw + 2 * w + 1] * 10.0);
+        std::sort(clk.begin(), clk.end());
+        out[3 * l + 0] = ms;
+        out[3 * l + 1] = (double)nw * nm * (shape == 0 ? 2048.0 : 512.0) / (ms * 1e-3) / 1e12;
+        out[3 * l + 2] = clk[nw / 2];
+    }
+    hipFree(dbuf);
+    for (auto& e : ev) hipEventDestroy(e);
+}
+
 }  // namespace mfgp
 
 extern "C" {
+// out[3 l + {0, 1, 2}] = {ms, TFLOP/s, in-kernel clock GHz} of launch l of `launches` back-to-back bare MFMA launches
+int32_t mfgp_probe_sustained(int32_t device, int32_t shape, int32_t launches, double* out) {
+    if (!out || launches < 1 || launches > 4096 || hipSetDevice(device) != hipSuccess) return -1;
+    hipStream_t s;
+    if (hipStreamCreate(&s) != hipSuccess) return -2;
+    mfgp::run_probe_sustained(s, shape, launches, out);
+    hipStreamSynchronize(s);
+    hipStreamDestroy(s);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 // out2 = {bare fp64 MFMA TFLOP/s, 1 GiB device copy GB/s}
 int32_t mfgp_probe_basic(int32_t device, double* out2) {
     if (!out2 || hipSetDevice(device) != hipSuccess) return -1;
