@@ -19,7 +19,9 @@ MASTER_*) this process IS one rank.  Started as a plain process with --gpus N > 
 touches HIP it starts N copies of itself, one per GPU, with that environment (and a per-job token for the
 rendezvous), waits for them, and exits non-zero if any rank did.  A rank whose RCCL communicator does not come up
 prints the reason and exits non-zero -- an N-GPU line is never produced by a job that fell back to TCP
-(`--single-device` is the explicit rehearsal of the N-rank code path on one GPU; its line says n_gpus = 1).
+(`--single-device` is the explicit rehearsal of the N-rank code path on one GPU, RCCL included: the ranks pose as
+separate hosts -- sharding.rehearsal_env -- so that RCCL builds a real N-rank communicator over its socket transport;
+its line says n_gpus = 1).
 
 N > 1 is STRONG scaling of the same job: the randomized restarts and the N* predictive rows are sharded over the
 ranks (sharding.py: rendezvous + tiny object gathers over TCP, device collectives = RCCL inside libmfgp_hip.so; no
@@ -304,7 +306,8 @@ def main():
                     help="randomized restarts in flight beside the main run (auxiliary engine handles per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal only: every rank uses GPU 0 (collectives over TCP: RCCL refuses two ranks on one device)")
+                    help="rehearsal only: every rank uses GPU 0; RCCL is made to accept that by giving every rank its own "
+                         "NCCL_HOSTID (a real N-rank communicator over RCCL's socket transport on loopback)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -318,6 +321,8 @@ def main():
     # No PyTorch: the host side needs a rendezvous and a few tiny object gathers (sharding.SocketComm, TCP on
     # MASTER_ADDR), the device collectives are RCCL inside libmfgp_hip.so on the engine's own stream.
     from multifidelity_datafusion_gps_amd import sharding
+    if world > 1 and args.single_device:
+        os.environ.update(sharding.rehearsal_env(rank))      # before librccl is loaded (lazily, by attach_engine)
     from multifidelity_datafusion_gps_amd._lib import Engine
     comm = sharding.comm_from_env()
     try:
@@ -332,9 +337,7 @@ def main():
     for j in range(1, args.concurrency + 1 if args.concurrency > 1 else 1):
         engines["hf#%d" % j] = Engine(local_rank)
     collectives = "none (1 rank)"
-    if world > 1 and args.single_device:
-        collectives = "tcp (single-device rehearsal: RCCL refuses two ranks on one device)"
-    elif world > 1:
+    if world > 1:
         try:
             comm.attach_engine(engines["hf"], required=True)
         except sharding.RcclInitError as ex:
@@ -344,6 +347,8 @@ def main():
             sys.stderr.flush()
             os._exit(3)
         collectives = "rccl (ncclAllGather on the engine stream; rendezvous + object gathers over tcp)"
+        if args.single_device:
+            collectives += "; single-device rehearsal: %d ranks on GPU 0 posing as %d hosts (NCCL_HOSTID), RCCL socket transport" % (world, world)
 
     def barrier():
         engines["hf"].device_synchronize()

@@ -399,6 +399,17 @@ class SocketComm:
         self._peers, self._hub = [], None
 
 
+def rehearsal_env(rank):
+    """Environment under which RCCL accepts SEVERAL ranks on ONE device -- for rehearsing the N-rank path on a one-GPU box.
+    RCCL refuses two ranks of a communicator that share a bus id on the same host ("Duplicate GPU detected"); the host
+    identity it compares is NCCL_HOSTID when that is set, so ranks that name different hosts are taken for different
+    machines and connect through the socket transport (loopback) -- a real communicator of N ranks: ncclCommInitRank on a
+    shared unique id, ncclAllGather between processes.  Must be in os.environ before librccl is loaded (the library
+    dlopens it lazily in mfgp_comm_unique_id / mfgp_comm_init).  Never used by a job with one GPU per rank."""
+    return {"NCCL_HOSTID": "mfgp-rehearsal-host-%d" % int(rank), "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1",
+            "NCCL_P2P_DISABLE": "1", "NCCL_SHM_DISABLE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
 def comm_from_env(timeout=120.0):
     """the communicator of a process launched one-per-GPU (torch.distributed.run / any launcher that exports RANK,
     WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  The launcher's own store owns MASTER_PORT, so the hub listens on

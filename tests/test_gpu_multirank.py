@@ -1,8 +1,12 @@
-"""Multi-rank tests with the REAL HIP engine: two processes share GPU 0 of the one-GPU box.
+"""Multi-rank tests with the REAL HIP engine: several processes share GPU 0 of the one-GPU box.
 
-RCCL refuses two ranks on one device, so the two-process test moves the device data of the row-block layout through
-host memory (mfgp_rows_download / mfgp_rows_upload) and the small gathers over sharding.SocketComm; the RCCL calls
-themselves (mfgp_comm_init, mfgp_allgather_rows, mfgp_allgather_host) are exercised with a communicator of size 1.
+* over TCP: RCCL refuses two ranks on one device as it finds them, so the first two-process test moves the device data of
+  the row-block layout through host memory (mfgp_rows_download / mfgp_rows_upload) and the small gathers over
+  sharding.SocketComm;
+* over RCCL, for real: with sharding.rehearsal_env every rank names a host of its own (NCCL_HOSTID), RCCL takes them for
+  separate machines and builds a communicator of 2 / 3 ranks over its socket transport -- ncclCommInitRank on the shared
+  unique id, the in-place ncclAllGather of the K row blocks between processes, the host-staged gather of the predictive rows;
+* the RCCL calls with a communicator of size 1.
 Covers e1 (predictive rows sharded), e2 (restarts sharded) and e3 (K row blocks + all-gather + prebuilt evaluation)."""
 import multiprocessing as mp
 import socket
@@ -95,6 +99,73 @@ def test_two_processes_on_one_gpu_with_the_hip_engine():
         # e3: K built by two ranks' row blocks + gathered = the fused evaluation, bit for bit (same kernels, same order)
         (f0, g0), (f1, g1) = out[r]["rowblock"]
         assert f1 == f0 and np.array_equal(g1, g0)
+
+
+def _rccl_worker(rank, world, port, q):
+    import os
+    from multifidelity_datafusion_gps_amd import sharding
+    os.environ.update(sharding.rehearsal_env(rank))       # before librccl is loaded (lazily, by attach_engine)
+    from multifidelity_datafusion_gps_amd._lib import Engine
+    comm = sharding.SocketComm(rank, world, "127.0.0.1", port, timeout=120)
+    res = {}
+    try:
+        e = Engine(0)
+        comm.attach_engine(e, required=True, init_timeout=90)     # RcclInitError on every rank if the communicator fails
+        res["transport"], res["comm_size"] = comm.transport, int(e.comm_size)
+        got = e.allgather_host(np.arange(7.0) + 100.0 * rank)
+        res["host_gather"] = got
+        # ragged row counts through the communicator's own row gather (pads to the longest block, trims after)
+        res["ragged"] = comm.allgather_rows(np.full((3 + 2 * rank, 2), float(rank)))
+        rng = np.random.default_rng(3)
+        X = rng.uniform(size=(700, 4))
+        Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+        e.set_data(Xa, cases.hf_4d(X))
+        e.set_kernel(cases.composite(4, 1))
+        theta, noise = np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.02
+        res["fused"] = e.eval(theta, noise, 1e-8)
+        res["sharded"] = sharding.eval_rowblock_allgather(e, comm, theta, noise)   # 768 padded rows: 6 blocks of 128 over the ranks
+        res["model"] = _model_run(comm, 2)                 # e1 + e2 with the row gathers on RCCL
+        comm.barrier()
+        e.comm_destroy()                                   # every rank still alive
+        comm.barrier()
+        e.close()
+    finally:
+        q.put((rank, res))
+        comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
+    """A REAL RCCL communicator with more than one rank ("an RCCL collective with >= 2 ranks has never executed
+    anywhere"): mfgp_comm_unique_id on rank 0 -> TCP -> mfgp_comm_init on every rank, then mfgp_allgather_rows (ONE
+    in-place ncclAllGather on the device matrix) and mfgp_allgather_host between the processes."""
+    from multifidelity_datafusion_gps_amd.sharding import LocalComm
+    ref = _model_run(LocalComm(), 1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        o = out[r]
+        assert o["transport"] == "rccl" and o["comm_size"] == world
+        np.testing.assert_array_equal(o["host_gather"], np.arange(7.0)[None, :] + 100.0 * np.arange(world)[:, None])
+        np.testing.assert_array_equal(o["ragged"], np.concatenate([np.full((3 + 2 * k, 2), float(k)) for k in range(world)]))
+        (f0, g0), (f1, g1) = o["fused"], o["sharded"]
+        assert f1 == f0 and np.array_equal(g1, g0)         # e3 over ncclAllGather: bit for bit the fused evaluation
+        m = o["model"]
+        np.testing.assert_allclose(m["theta"], ref["theta"], rtol=1e-9)
+        np.testing.assert_allclose(m["mean"], ref["mean"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(m["var"], ref["var"], rtol=0, atol=1e-7)
+        np.testing.assert_array_equal(m["mean"], out[0]["model"]["mean"])
+        assert m["evals"] < ref["evals"]
 
 
 def test_rccl_calls_with_a_communicator_of_one(engine):

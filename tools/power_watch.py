@@ -1,0 +1,61 @@
+"""Run a command and sample rocm-smi beside it (socket power, sclk, junction temperature): is a sustained run power-managed?
+usage: python tools/power_watch.py [--period 0.2] -- <command ...>     (the child is started as a plain subprocess; this
+process never touches HIP).  Prints the child's output, then one JSON line with the samples' summary."""
+import json
+import subprocess
+import sys
+import threading
+import time
+
+
+def sample():
+    r = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks", "--showtemp", "--json"], capture_output=True, text=True,
+                       timeout=5)
+    d = json.loads(r.stdout)["card0"]
+    num = lambda s: float("".join(ch for ch in s if ch.isdigit() or ch == "."))   # noqa: E731
+    return {"power_w": num(d["Current Socket Graphics Package Power (W)"]), "sclk_mhz": num(d["sclk clock speed:"]),
+            "temp_c": num(d["Temperature (Sensor junction) (C)"])}
+
+
+def main():
+    argv = sys.argv[1:]
+    period = 0.2
+    if argv and argv[0] == "--period":
+        period = float(argv[1])
+        argv = argv[2:]
+    if argv and argv[0] == "--":
+        argv = argv[1:]
+    cap = subprocess.run(["rocm-smi", "-d", "0", "--showmaxpower", "--json"], capture_output=True, text=True).stdout.strip()
+    rows, stop = [], threading.Event()
+
+    def loop():
+        t0 = time.time()
+        while not stop.is_set():
+            try:
+                s = sample()
+                s["t"] = round(time.time() - t0, 2)
+                rows.append(s)
+            except Exception as ex:  # noqa: BLE001
+                rows.append({"t": round(time.time() - t0, 2), "error": repr(ex)[:100]})
+            time.sleep(period)
+
+    th = threading.Thread(target=loop)
+    th.start()
+    rc = subprocess.run(argv).returncode
+    stop.set()
+    th.join()
+    good = [r for r in rows if "power_w" in r]
+    busy = [r for r in good if r["power_w"] > 500]
+    summ = {"max_power_cap": cap[:200], "samples": len(good), "busy_samples(>500W)": len(busy)}
+    if busy:
+        p = sorted(r["power_w"] for r in busy)
+        c = sorted(r["sclk_mhz"] for r in busy)
+        summ.update({"power_w_median": p[len(p) // 2], "power_w_max": p[-1], "sclk_mhz_median": c[len(c) // 2], "sclk_mhz_min": c[0],
+                     "sclk_mhz_max": c[-1], "temp_c_max": max(r["temp_c"] for r in busy)})
+    summ["trace(t,power,sclk)"] = [(r["t"], r["power_w"], r["sclk_mhz"]) for r in good][:400]
+    print(json.dumps({"power_watch": summ}))
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    main()
