@@ -37,7 +37,7 @@ namespace mfgp {
 #define MFGP_MFMA_444 1   // 0: the v_mfma_f64_16x16x4 body of rounds 1-2 (kept for A/B measurements and cross-checks)
 #endif
 
-template <int BM, int BN, int WM, int WN, int NBUF = 2, int KT = BK>
+template <int BM, int BN, int WM, int WN, int NBUF = 2, int KT = BK, int AH = 0>   // AH > 0: register-lean form, AH A row blocks held at once
 __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, const double* B, double* C, double* C2,
                                              int ld) {
     constexpr int NT = 64 * WM * WN;      // threads per workgroup (wave grid WM x WN)
@@ -107,7 +107,20 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
     // (task-uniform flags; most tasks carry none) are applied when the registers are written to LDS, after the compute
     // phase.  (Rounds 1-2 masked right after the load: every K-step then waited for its NEXT operands before it started.)
     const bool any_mask = (t.flags & (TF_A_LOWER | TF_A_UPPER | TF_B_LOWER | TF_B_UPPER)) != 0;
+    // register-lean form: ONE 32-bit lane offset shared by both operands on top of the task-uniform (scalar) bases instead of
+    // a 64-bit lane pointer per 16-byte load
+    const unsigned lane_off = (unsigned)(tid / CPR) * (unsigned)ld + 2u * (unsigned)(tid % CPR);
     auto load_tiles = [&](int kt) {
+        if constexpr (AH > 0) {
+            static_assert(NT % CPR == 0, "a thread's chunks must share one column slot");
+#pragma unroll
+            for (int u = 0; u < NA; ++u)
+                ra[u] = *reinterpret_cast<const d2_t*>(Ap + (lane_off + (unsigned)((NT / CPR) * u * ld + kt * KT)));
+#pragma unroll
+            for (int u = 0; u < NBC; ++u)
+                rb[u] = *reinterpret_cast<const d2_t*>(Bp + (lane_off + (unsigned)((NT / CPR) * u * ld + kt * KT)));
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int g = tid + NT * u;
@@ -181,6 +194,47 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
         // a step's four k-slots are then columns 8 g + {0, 2, 4, 6} (resp. {1, 3, 5, 7}), the same for both operands.
         // (Bank check, ds_read_b128 lane groups {0-3,12-15,20-27} ...: 8 lanes of slot q on rows R, 8 of slot q + 1 on the
         // complement of R mod 16; chunk ^ row maps them to 16 distinct 16-byte slots for KT = 32 and for KT = 16.)
+        if constexpr (AH > 0) {
+            // register-lean form (the 4-wave chain kernel: 96 VGPRs in all): the 8-column groups are NOT unrolled -- one set of
+            // fragment addresses, group g reached by flipping byte-offset bit 6 (chunk (4 g + q) ^ s = (q ^ s) ^ 4 g) -- and
+            // the A fragments are taken AH row blocks at a time
+            int a_ad[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (fr + 4 * r) & 15;
+                a_ad[r] = (row * KT + ((q ^ (row & SWM)) << 1)) * 8;
+            }
+            const int b_ad = ((q ^ (fr & SWM)) << 1) * 8;
+            const char* asb = reinterpret_cast<const char*>(as);
+            const char* bsb = reinterpret_cast<const char*>(bs);
+#pragma unroll 1
+            for (int g = 0; g < KT / 8; ++g) {
+                const int gx = g << 6;
+                d2_t b[TN];
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const d2_t*>(bsb + ni * 16 * KT * 8 + (b_ad ^ gx));
+#pragma unroll
+                for (int m0 = 0; m0 < TM; m0 += AH) {
+                    d2_t a[AH][4];
+#pragma unroll
+                    for (int mi = 0; mi < AH; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            a[mi][r] = *reinterpret_cast<const d2_t*>(asb + (m0 + mi) * 16 * KT * 8 + (a_ad[r] ^ gx));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int mi = 0; mi < AH; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    acc[m0 + mi][ni][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[mi][r][h], b[ni][h],
+                                                                                             acc[m0 + mi][ni][r], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < KT / 8; ++g) {
             d2_t a[TM][4], b[TN];
@@ -523,6 +577,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_chain(const 
     __builtin_amdgcn_s_setprio(3);
     gemm_nt_tile<64, 64, GW_M, GW_N, 1, 16>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
+// 4-wave form of the 64-tile chain step (round 3, role 6): 2 x 2 waves of 32 x 32, at most 96 VGPRs and 16 KB of LDS, so that ONE
+// such workgroup fits on a CU beside TWO resident bulk workgroups (2 x 208 of the 512 VGPRs per SIMD lane, 2 x 52 of the 128
+// LDS granules) instead of waiting for one of them to retire: the 8-wave form needs 2 x 80 VGPRs per SIMD and its launches
+// stretch from 15-25 us to 100-160 us right after a bulk launch filled the CUs (profiles/r03_timeline_8192.txt).
+__global__ __launch_bounds__(256, 5) void mfgp_gemm_nt_f64_chain4(const GemmTask* __restrict__ tasks, const double* A,
+                                                         const double* B, double* C, double* C2, int ld) {
+    __builtin_amdgcn_s_setprio(3);
+    gemm_nt_tile<64, 64, 2, 2, 1, 16, 1>(tasks[blockIdx.x], A, B, C, C2, ld);
+}
 // 32x32 chain variant: 4 waves (2 x 2, one MFMA block each), 16 KB of LDS, K-steps of 32 -- the chain's panel / in-macro update
 // launches at chain-bound sizes (planner: MFGP_CHAIN_TILE).  Those launches are latency-bound (a 64x64x128 tile is 128 MFMAs
 // per SIMD behind eight serial K-steps); as 32x32 tiles the same work spreads over four times as many workgroups and four
@@ -578,6 +641,11 @@ void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, con
                            C, C2, ld);
         return;
     }
+    if (role == 6 && tile == 64) {   // serial-chain step, 4-wave form: co-resident with TWO bulk workgroups per CU
+        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain4, dim3(ntasks), dim3(256), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
+                           C, C2, ld);
+        return;
+    }
     if (role == 3 && tile == 64) {   // serial-chain step: slim workgroups that co-reside with the bulk update
         hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain, dim3(ntasks), dim3(GEMM_THREADS), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
                            C, C2, ld);
@@ -585,8 +653,8 @@ void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, con
     }
     // roles: 0 bulk, 1 K^-1, 2 predictive variance (distinct symbols over one body); 3 = a chain step -- only its 64-tile
     // form is a kernel of its own (above), a 128-tile chain step runs the bulk kernel; 5 = the 32-tile chain step (handled
-    // by tile == 32 above).  Anything else is a planner bug: fail loudly instead of indexing past the table.
-    if ((tile != 128 && tile != 64) || role < 0 || (role > 3 && role != 5)) {
+    // by tile == 32 above); 6 = the 4-wave 64-tile chain step (above; as a 128-tile step it runs the bulk kernel).  Anything else is a planner bug: fail loudly instead of indexing past the table.
+    if ((tile != 128 && tile != 64) || role < 0 || (role > 3 && role != 5 && role != 6)) {
         fprintf(stderr, "mfgp: launch_gemm: no kernel for tile %d, role %d\n", tile, role);
         abort();
     }

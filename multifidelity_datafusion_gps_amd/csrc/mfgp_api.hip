@@ -36,7 +36,7 @@ static int upload_tasks(mfgp_handle* h) {
 }
 
 static void run_step(mfgp_handle* h, const Step& s, bool want_grad = true) {
-    hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
+    hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : (s.strm == 2 && h->stream3) ? h->stream3 : h->stream;
     if (s.wait_ev > 0) (void)hipStreamWaitEvent(st, h->evpool[s.wait_ev - 1], 0);
     if (s.kind == 0) {
         launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
@@ -98,23 +98,27 @@ static int create_body(mfgp_handle* h, int device_id) {
     // workgroups take the first CU a bulk-update workgroup vacates
     HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
     {
-        // bulk-update stream; optionally keep a few CUs out of its reach so the serial chain always finds one
+        // bulk-update stream; optionally keep MFGP_U_RESERVE CUs PER XCD out of its reach, so that the serial chain -- above all
+        // the leaf, which needs a whole CU -- always finds one.  Mask layout on this part (tools/probes/cumask.py,
+        // profiles/r03_cumask.txt): bit i = XCD i mod 8, shader engine (i / 8) mod 4, CU i / 32 of that engine -- so bits
+        // [0, 8 r) take r CUs out of EVERY XCD.  (Rounds 1-2 cleared bits r * ncu / reserve: all of them CUs of XCD 0, which
+        // then ran 1/8 of every bulk launch on 24 / 16 CUs -- the "pathological" 20-60 % they measured.)
         int reserve = 0;
         if (const char* e = getenv("MFGP_U_RESERVE")) reserve = atoi(e);
         hipDeviceProp_t pr;
         HIPCHK(h, hipGetDeviceProperties(&pr, device_id));
         const int ncu = pr.multiProcessorCount;
-        if (reserve > 0 && reserve < ncu) {
+        const int nxcd = 8;
+        if (reserve > 0 && reserve * nxcd < ncu / 2 && ncu % nxcd == 0) {
             std::vector<uint32_t> mask((ncu + 31) / 32, 0xffffffffu);
-            for (int r = 0; r < reserve; ++r) {
-                const int cu = (int)(((int64_t)r * ncu) / reserve);
-                mask[cu / 32] &= ~(1u << (cu % 32));
-            }
+            for (int b = 0; b < reserve * nxcd; ++b) mask[b / 32] &= ~(1u << (b % 32));
             HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
         } else {
             HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         }
     }
+    // column stream: what the NEXT macro panel's chain waits for, launched beside the bulk stream's work -- the chain's priority
+    HIPCHK(h, hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
     // timing events: no system-scope fence at the record either (more precise stamps, and cheaper: see build_plans)
     for (auto& ev : h->ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
     // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
@@ -166,6 +170,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
     if (h->stream2) hipStreamDestroy(h->stream2);
+    if (h->stream3) hipStreamDestroy(h->stream3);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -866,7 +871,8 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
                          int32_t K, double alpha, double beta, int32_t tile) {
     if (!h || !A || !B || !C) return fail(h, -1, "mfgp_dbg_gemm_nt: NULL");
     const bool chain = (tile == -64);   // -64: the serial-chain variant of the 64-tile kernel (mfgp_gemm_nt_f64_chain)
-    if (chain) tile = 64;
+    const bool chain4 = (tile == -63);  // -63: its 4-wave form (mfgp_gemm_nt_f64_chain4)
+    if (chain || chain4) tile = 64;
     if ((tile != 128 && tile != 64 && tile != 32) || M % tile || N % tile || K % BK || K < BK)
         return fail(h, -1, "mfgp_dbg_gemm_nt: M, N must be multiples of the tile (128, 64, 32) and K of 32");
     HIPCHK(h, hipSetDevice(h->device));
@@ -894,7 +900,7 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
         }
     HIPCHK(h, hipMalloc(&dt, ts.size() * sizeof(GemmTask)));
     HIPCHK(h, hipMemcpy(dt, ts.data(), ts.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
-    launch_gemm(h->stream, tile, dt, (int)ts.size(), dA, dB, dC, nullptr, ld, chain ? 3 : 0);
+    launch_gemm(h->stream, tile, dt, (int)ts.size(), dA, dB, dC, nullptr, ld, chain ? 3 : (chain4 ? 6 : 0));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy2D(C, (size_t)N * 8, dC, (size_t)ld * 8, (size_t)N * 8, M, hipMemcpyDeviceToHost));

@@ -101,6 +101,7 @@ struct mfgp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // bulk trailing updates of the look-ahead Cholesky
+    hipStream_t stream3 = nullptr;      // column stream (plan steps with strm == 2: the next macro panel's columns, beside the bulk launches)
     std::vector<hipEvent_t> evpool;     // cross-stream dependencies of the plan
     std::string err, info_str;
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size

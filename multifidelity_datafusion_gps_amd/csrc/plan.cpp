@@ -167,6 +167,8 @@ static void plan_potrf_rl(Plan& p) {
     // double-buffered 64-tile kernel, so they only pay where bulk updates are long enough to overlap the chain
     int chain_role = (lookahead && nb >= 48) ? 3 : 0;
     if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
+    // 4-wave form of the slim chain kernel (role 6): fits beside TWO bulk workgroups per CU (see gemm_f64.hip)
+    if (const char* e = getenv("MFGP_CHAIN_WAVES")) { if (chain_role == 3 && atoi(e) == 4) chain_role = 6; }
     auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
         // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
         const int sc = NB / T;
@@ -184,6 +186,7 @@ static void plan_potrf_rl(Plan& p) {
             }
     };
     auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
+    bool cols_used = false, rest_b_waits_colsx = false;
     std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
     int ev_rest_prev = 0;            // event after the previous macro's bulk update of the REST (bulk stream)
     for (int M0 = 0; M0 < nb; M0 += MB) {
@@ -460,7 +463,10 @@ void plan_predv(Plan& p, int rows_p) {
     const int T = pick_tile(p, nb * rb);
     const int sc = NB / T;
     const int first = (int)p.tasks.size();
-    const int BI = 8, BR = 4, ni = nb * sc, nr = rb * sc;   // super-blocks: BI rows of X  x  BR panel rows
+    int BI = 8, BR = 4;                                      // super-blocks: BI rows of X  x  BR panel rows
+    if (const char* e = getenv("MFGP_PREDV_BI")) BI = std::max(1, atoi(e));
+    if (const char* e = getenv("MFGP_PREDV_BR")) BR = std::max(1, atoi(e));
+    const int ni = nb * sc, nr = rb * sc;
     for (int i0 = ni - 1; i0 >= 0; i0 -= BI)                 // large i (= long K range) first
         for (int r0 = 0; r0 < nr; r0 += BR)
             for (int i = i0; i > std::max(-1, i0 - BI); --i)
@@ -533,6 +539,8 @@ static void plan_sweep(Plan& p) {
     // retire (N = 4096: 3.27 -> 3.03 ms).  Below ~24 blocks the bulk launches are 64-tiles themselves: no difference.
     int chain_role = nb >= 24 ? 3 : 0;
     if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
+    // 4-wave form of the slim chain kernel (role 6): fits beside TWO bulk workgroups per CU (see gemm_f64.hip)
+    if (const char* e = getenv("MFGP_CHAIN_WAVES")) { if (chain_role == 3 && atoi(e) == 4) chain_role = 6; }
     // tile edge of the chain's own launches (panel, inner).  They are latency-bound: a 64x64x128 tile is 128 dependent-ish
     // MFMAs per SIMD (5.3 us) behind 8 serial K-steps; as 32x32 tiles (4 waves, 16 KB of LDS, four times the workgroups, four
     // K-steps) the same work spreads over four times as many SIMDs (N = 1024 0.60 -> 0.53 ms, 2048 1.20 -> 1.03, 4096 2.93 -> 2.80).  Chain-bound sizes only: at N >= 6144 the chain hides behind the
@@ -545,6 +553,15 @@ static void plan_sweep(Plan& p) {
     if (const char* e = getenv("MFGP_BULK_XCD")) bulk_xcd = atoi(e) != 0;
     int bulk_every = 1;   // macro panels per bulk chunk of B / K^-1 (see "the rest" below; N = 8192, MB = 8: 14.1 / 14.6 ms at 1 / 2)
     if (const char* e = getenv("MFGP_BULK_EVERY")) bulk_every = std::max(1, atoi(e));
+    // Three streams (MFGP_COLS_STREAM=1; only with the gating column on the main stream, i.e. !shift): the launch the NEXT chain
+    // waits for -- the next macro panel's columns of A (+ the rows of X^T above this panel) -- goes to a third stream and
+    // runs BESIDE the bulk stream's work instead of in front of it: as the only launch on the GPU it is ~700 64-tiles on 512
+    // slots (1.4 rounds at 30 TFLOP/s, 16 x 95 us per evaluation at N = 8192).  The bulk launch is split for it: the rest
+    // of A's trailing update needs only the chain (starts at once), the B / K^-1 part also reads the new rows of X^T and
+    // waits for the column launch's event.
+    bool cols_stream = false;
+    if (const char* e = getenv("MFGP_COLS_STREAM")) cols_stream = atoi(e) != 0;
+    if (shift) cols_stream = false;
     int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
     int far_done = 0;   // block columns < far_done have been applied to B's columns beyond the next macro panel
     bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
@@ -637,6 +654,7 @@ static void plan_sweep(Plan& p) {
     };
     auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
 
+    bool cols_used = false, rest_b_waits_colsx = false;
     std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
     int ev_rest_prev = 0;            // event after the previous macro's last bulk launch
     bool bulk_used = false;
@@ -707,6 +725,7 @@ static void plan_sweep(Plan& p) {
         const bool last = (M1 >= nb);
         const size_t chain_last = p.steps.size() - 1;   // index of the chain's last step
         std::vector<size_t> bulk_steps;                 // bulk launches of this macro, in stream order
+        long colsx_step = -1;                           // cols_stream: this macro's launch on the third stream
         if (!last && !shift) {
             // the column that gates the next leaf stays on the MAIN stream (no event round trip on the chain); it must
             // still follow the previous macro's last bulk launch, whose A-rest part covers this column too
@@ -726,15 +745,25 @@ static void plan_sweep(Plan& p) {
             const bool have_cols = !last && lo <= hi, have_x = M0 > 0;
             const int n_cols = have_cols ? ntiles_cols(lo, hi + 1) : 0, n_x = have_x ? M0 * (M1 - M0) : 0;
             auto cols_launch = [&](int T, int first) {
-                if (!launch(T, first, 1, 0)) return;
-                bulk_steps.push_back(p.steps.size() - 1);
+                if (cols_stream && ev_rest_prev > 0 && (int)p.tasks.size() > first) {
+                    // third stream: the launch also follows the previous macro's bulk work (A's columns and the B columns that
+                    // feed the rows of X^T were last written there; on the bulk stream that was stream order): a wait-only
+                    // step.  It is enqueued -- and its barrier retired -- long before the chain event fires, so it does
+                    // not lengthen the chain -> columns -> chain path.
+                    Step w{};
+                    w.kind = 2; w.strm = 2; w.wait_ev = ev_rest_prev;
+                    p.steps.push_back(w);
+                }
+                if (!launch(T, first, cols_stream ? 2 : 1, 0)) return;
+                if (cols_stream) colsx_step = (long)p.steps.size() - 1;   // third stream: not one of the bulk stream's steps
+                else bulk_steps.push_back(p.steps.size() - 1);
                 if (have_cols) {
                     const int ev = bulk_event();
                     p.steps.back().rec_ev = ev;
                     for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
                 }
             };
-            if (merge_xpanel && have_cols && have_x) {
+            if ((merge_xpanel || cols_stream) && have_cols && have_x) {
                 const int T = pick_tile(p, n_cols + n_x);
                 const int first = (int)p.tasks.size();
                 a_update(T, lo, hi + 1, M0, M1);
@@ -751,7 +780,8 @@ static void plan_sweep(Plan& p) {
                     const int T = pick_tile(p, n_x);
                     const int first = (int)p.tasks.size();
                     for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
-                    if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
+                    if (cols_stream) cols_launch(T, first);     // (the last macro panel: rows of X^T only)
+                    else if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
                 }
             }
         }
@@ -767,54 +797,101 @@ static void plan_sweep(Plan& p) {
             const int n_a = a_lo < nb ? ntiles_cols(a_lo, nb) : 0;
             const int n_b = last ? 0 : M1 * ((chunk_now ? nb : M2) - M1);
             const int n_k = kinv_now ? M1 * (M1 + 1) / 2 : 0;
-            const int T = pick_tile(p, n_a + n_b + n_k);
+            int T = pick_tile(p, n_a + n_b + n_k);
             auto by_length = [&](int first) {   // longest K first: the launch's tail is then made of its shortest tasks;
                 std::stable_sort(p.tasks.begin() + first, p.tasks.end(),     // super-blocks stay together within a K class
                                  [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
                 if (bulk_xcd) xcd_interleave(p.tasks, first, bulk_bi * bulk_bj);
             };
-            auto common = [&]() {
+            auto common_b = [&]() {
                 if (!last) b_update(T, 0, M1, M1, M2, far_done, M1);                       // catch-up of the next macro's columns
                 if (!last && chunk_now && M2 < nb) b_update(T, 0, M1, M2, nb, far_done, M1);   // the columns beyond
+            };
+            auto common_a = [&]() {
                 if (a_lo < nb) a_update(T, a_lo, nb, M0, M1);
             };
-            const int first = (int)p.tasks.size();
-            common();
-            by_length(first);
-            const int count = (int)p.tasks.size() - first;
-            int gfirst = 0, gcount = 0;
-            if (kinv_now) {   // the gradient variant of this launch: the same tasks + the K^-1 chunk, ordered as a whole
-                gfirst = (int)p.tasks.size();
-                kinv_update(T, kinv_lo, M1);
-                common();
-                by_length(gfirst);
-                gcount = (int)p.tasks.size() - gfirst;
-                kinv_lo = M1;
-            }
-            if (chunk_now) far_done = M1;
-            if (count > 0 || gcount > 0) {
+            auto push_bulk = [&](int first, int count, int gfirst, int gcount) {
+                if (count <= 0 && gcount <= 0) return;
                 Step st{};
                 st.kind = 1; st.tile = T; st.first = first; st.count = count; st.gfirst = gfirst; st.gcount = gcount;
                 st.a = st.b = st.c = st.c2 = BUF_A;
                 st.strm = 1;
                 p.steps.push_back(st);
                 bulk_steps.push_back(p.steps.size() - 1);
+            };
+            if (cols_stream) {
+                // rest_a: A's trailing update -- needs only chain(M), starts beside the column launch
+                if (n_a > 0) {
+                    T = pick_tile(p, n_a);
+                    const int first = (int)p.tasks.size();
+                    common_a();
+                    by_length(first);
+                    push_bulk(first, (int)p.tasks.size() - first, 0, 0);
+                }
+                // rest_b: B and K^-1 -- they read the rows of X^T the column launch produces
+                T = pick_tile(p, n_b + n_k);
+                const int first = (int)p.tasks.size();
+                common_b();
+                by_length(first);
+                const int count = (int)p.tasks.size() - first;
+                int gfirst = 0, gcount = 0;
+                if (kinv_now) {
+                    gfirst = (int)p.tasks.size();
+                    kinv_update(T, kinv_lo, M1);
+                    common_b();
+                    by_length(gfirst);
+                    gcount = (int)p.tasks.size() - gfirst;
+                    kinv_lo = M1;
+                }
+                const size_t before = bulk_steps.size();
+                push_bulk(first, count, gfirst, gcount);
+                if (bulk_steps.size() > before && colsx_step >= 0) {
+                    // waits for the column launch (which waited for the chain): its event, or a fresh one if it has none
+                    Step& cx = p.steps[(size_t)colsx_step];
+                    if (cx.rec_ev == 0) cx.rec_ev = bulk_event();
+                    p.steps[bulk_steps.back()].wait_ev = cx.rec_ev;
+                    rest_b_waits_colsx = true;
+                }
+            } else {
+                const int first = (int)p.tasks.size();
+                common_b();
+                common_a();
+                by_length(first);
+                const int count = (int)p.tasks.size() - first;
+                int gfirst = 0, gcount = 0;
+                if (kinv_now) {   // the gradient variant of this launch: the same tasks + the K^-1 chunk, ordered as a whole
+                    gfirst = (int)p.tasks.size();
+                    kinv_update(T, kinv_lo, M1);
+                    common_b();
+                    common_a();
+                    by_length(gfirst);
+                    gcount = (int)p.tasks.size() - gfirst;
+                    kinv_lo = M1;
+                }
+                push_bulk(first, count, gfirst, gcount);
             }
+            if (chunk_now) far_done = M1;
         }
-        if (!bulk_steps.empty()) {
+        if (!bulk_steps.empty() || colsx_step >= 0) {
             bulk_used = true;
             const int ev_chain = new_event(p);
             bulk_order.resize(ev_chain + 1, 0);
             p.steps[chain_last].rec_ev = ev_chain;            // chain(M) complete: L[:, M], X_MM, B's in-macro part are final
-            p.steps[bulk_steps.front()].wait_ev = ev_chain;
-            if (!last) {
+            if (colsx_step >= 0) { p.steps[(size_t)colsx_step].wait_ev = ev_chain; cols_used = true; }
+            // the bulk stream's first step of this macro waits for the chain unless it already waits for the column launch
+            // (which implies the chain)
+            if (!bulk_steps.empty() && p.steps[bulk_steps.front()].wait_ev == 0) p.steps[bulk_steps.front()].wait_ev = ev_chain;
+            if (!last && !bulk_steps.empty()) {
                 ev_rest_prev = bulk_event();
                 Step& lastb = p.steps[bulk_steps.back()];
                 if (lastb.rec_ev == 0) lastb.rec_ev = ev_rest_prev; else lastb.rec_ev_final = ev_rest_prev;
+            } else if (!last) {
+                ev_rest_prev = 0;
             }
         } else if (!last) {
             ev_rest_prev = 0;
         }
+        (void)rest_b_waits_colsx;
     }
     if (nb <= MB) {
         // a single macro panel: its bulk work depends on the whole chain and nothing runs beside it -- keep it on the main
@@ -834,6 +911,18 @@ static void plan_sweep(Plan& p) {
         j.kind = 2;
         j.wait_ev = ev;
         p.steps.push_back(j);
+        if (cols_used) {   // the third stream joins as well (its last launch is normally implied by the bulk stream's last wait)
+            for (size_t i = p.steps.size(); i-- > 0;)
+                if (p.steps[i].strm == 2) {
+                    const int ev2 = new_event(p);
+                    if (p.steps[i].rec_ev == 0) p.steps[i].rec_ev = ev2; else p.steps[i].rec_ev_final = ev2;
+                    Step j2{};
+                    j2.kind = 2;
+                    j2.wait_ev = ev2;
+                    p.steps.push_back(j2);
+                    break;
+                }
+        }
     }
 }
 

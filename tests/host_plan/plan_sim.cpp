@@ -8,7 +8,7 @@
 //       and checks  L L^T = A,  X L = I,  S mirrored,  K^-1 = X^T X;
 //   (2) checks the two-stream schedule for DATA RACES: every pair of conflicting accesses (write/write, write/read) to
 //       the same 32x32 cell of the same matrix must be ordered by stream order or by an event recorded before it is
-//       waited for (vector clocks over the two streams); tasks of one launch run concurrently and must not conflict.
+//       waited for (vector clocks over the streams); tasks of one launch run concurrently and must not conflict.
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -25,7 +25,8 @@ namespace {
 
 constexpr int CELL = 32;   // granularity of the race check = the smallest tile edge the planner emits
 
-struct Clock { int t[2]; };
+constexpr int NS = 3;   // streams: 0 main (the serial chain), 1 bulk, 2 columns
+struct Clock { int t[NS]; };
 
 struct Cell {
     int w_step = -1, w_task = -1;          // last writer
@@ -193,7 +194,7 @@ extern "C" {
 // [3] = max |K^-1 - X^T X| / max |X^T X| (want_grad only), [4] = number of races, [5] = steps, [6] = tasks, [7] = events
 // numeric = 0: race check only (any size); 1: also execute.  slack = extra rows of capacity (stride = (ld + slack)^2).
 // mutate (self-test of the checker): 1 = the first bulk launch forgets to wait for the chain; 2 = the main stream forgets
-// the final join; 3 = the second macro's first leaf forgets its event wait
+// the final join; 3 = the second macro's first leaf forgets its event wait; 4 / 5 = three-stream plans (see below)
 int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double* report, char* msg, int msglen) {
     Sim s;
     s.ld = (int64_t)nblk * NB;
@@ -209,6 +210,19 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
         int seen = 0;
         for (Step& st : s.p.steps)
             if (st.strm == 0 && st.wait_ev > 0 && st.kind != 2 && ++seen == 1) { st.wait_ev = 0; break; }
+    } else if (mutate == 4) {   // three-stream plans: the second column launch forgets the chain
+        int seen = 0;
+        for (Step& st : s.p.steps)
+            if (st.strm == 2 && st.wait_ev > 0 && ++seen == 2) { st.wait_ev = 0; break; }
+    } else if (mutate == 5) {   // three-stream plans: a B / K^-1 launch forgets the column launch it reads from
+        int seen = 0;
+        for (size_t i = 0; i < s.p.steps.size(); ++i) {
+            Step& st = s.p.steps[i];
+            if (st.strm != 1 || st.wait_ev <= 0) continue;
+            bool from_cols = false;
+            for (const Step& o : s.p.steps) if (o.strm == 2 && o.rec_ev == st.wait_ev) from_cols = true;
+            if (from_cols && ++seen == 2) { st.wait_ev = 0; break; }
+        }
     }
     const Plan& p = s.p;
     s.cpr = (int)(s.ld / CELL);
@@ -237,21 +251,21 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
                 if (j / 64 <= i / 64) A[i * s.ld + j] = A0[(size_t)i * N + j];
     }
     // ---- walk the steps in enqueue order ----
-    Clock vc[2] = {{{0, 0}}, {{0, 0}}};
-    std::vector<Clock> evclock(p.n_events + 1, Clock{{-1, -1}});
+    Clock vc[NS] = {};
+    std::vector<Clock> evclock(p.n_events + 1, Clock{{-1, -1, -1}});
     s.step_clock.resize(p.steps.size());
     s.step_strm.resize(p.steps.size());
     // the K build (one launch on the main stream, before every step) wrote the lower 64-tiles of A: model it as step -1
     // by leaving the cells without a writer -- every plan step is ordered after it by stream order / the chain events
     for (size_t si = 0; si < p.steps.size(); ++si) {
         const Step& st = p.steps[si];
-        const int strm = st.strm == 1 ? 1 : 0;
+        const int strm = (st.strm >= 0 && st.strm < NS) ? st.strm : 0;
         if (st.wait_ev > 0) {
             if (evclock[st.wait_ev].t[0] < 0) {
                 snprintf(msg, msglen, "step %zu waits for event %d before it is recorded", si, st.wait_ev);
                 return -1;
             }
-            for (int k = 0; k < 2; ++k) vc[strm].t[k] = std::max(vc[strm].t[k], evclock[st.wait_ev].t[k]);
+            for (int k = 0; k < NS; ++k) vc[strm].t[k] = std::max(vc[strm].t[k], evclock[st.wait_ev].t[k]);
         }
         vc[strm].t[strm] += 1;
         s.step_clock[si] = vc[strm];
@@ -286,8 +300,8 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
     }
     // everything must be visible to the main stream at the end (solve / gradient kernels follow there)
     for (size_t si = 0; si < p.steps.size(); ++si)
-        if (s.step_strm[si] == 1 && vc[0].t[1] < s.step_clock[si].t[1]) {
-            snprintf(msg, msglen, "bulk step %zu is not joined into the main stream at the end of the plan", si);
+        if (s.step_strm[si] != 0 && vc[0].t[s.step_strm[si]] < s.step_clock[si].t[s.step_strm[si]]) {
+            snprintf(msg, msglen, "step %zu of stream %d is not joined into the main stream at the end of the plan", si, s.step_strm[si]);
             return -3;
         }
     if (want_grad && !p.kinv_streamed && numeric) {   // the stand-alone K^-1 launch

@@ -13,7 +13,13 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = [{}, {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "recursive"}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"},
             {"MFGP_KINV_STREAM": "0"}, {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2", "MFGP_XPANEL_MERGE": "1"},
-            {"MFGP_CHAIN_SLIM": "1", "MFGP_T128_MIN": "8"}, {"MFGP_BULK_XCD": "0", "MFGP_BULK_BI": "2", "MFGP_BULK_BJ": "3"}]
+            {"MFGP_CHAIN_SLIM": "1", "MFGP_T128_MIN": "8"}, {"MFGP_BULK_XCD": "0", "MFGP_BULK_BI": "2", "MFGP_BULK_BJ": "3"},
+            # round 3: the column launch on a third stream beside a split bulk launch; the 4-wave chain kernel; CUs kept out
+            # of the bulk stream's mask
+            {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "2"},
+            {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "3", "MFGP_CHAIN_SLIM": "1", "MFGP_CHAIN_WAVES": "4",
+             "MFGP_CHAIN_TILE": "64", "MFGP_T128_MIN": "8"},
+            {"MFGP_U_RESERVE": "1", "MFGP_CHAIN_SLIM": "1", "MFGP_CHAIN_WAVES": "4", "MFGP_CHAIN_TILE": "64"}]
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")

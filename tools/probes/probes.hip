@@ -554,6 +554,31 @@ int32_t mfgp_probe_placement(int32_t device, int32_t G, int32_t lds_bytes, int32
     hipFree(d);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+// the same on a stream created with hipExtStreamCreateWithCUMask(nwords x 32 bits): which CUs does a mask leave to the queue?
+int32_t mfgp_probe_placement_masked(int32_t device, int32_t G, int32_t lds_bytes, int32_t hold_us, int32_t nwords,
+                                    const uint32_t* mask, uint32_t* out, double* ms_out) {
+    if (!out || !mask || hipSetDevice(device) != hipSuccess) return -1;
+    unsigned* d = nullptr;
+    if (hipMalloc(&d, (size_t)G * 8) != hipSuccess) return -2;
+    hipStream_t s;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask) != hipSuccess) { hipFree(d); return -3; }
+    hipFuncSetAttribute(reinterpret_cast<const void*>(mfgp::mfgp_probe_placement), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfgp::mfgp_probe_placement, dim3(G), dim3(256), (size_t)lds_bytes, s, d, (long long)hold_us * 100);   // warm
+    hipEventRecord(e0, s);
+    hipLaunchKernelGGL(mfgp::mfgp_probe_placement, dim3(G), dim3(256), (size_t)lds_bytes, s, d, (long long)hold_us * 100);
+    hipEventRecord(e1, s);
+    hipStreamSynchronize(s);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms;
+    hipMemcpy(out, d, (size_t)G * 8, hipMemcpyDeviceToHost);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipStreamDestroy(s);
+    hipFree(d);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 // out32: see tools/probes/probes.py (fp64_shapes) for the layout
 int32_t mfgp_probe_fp64_shapes(int32_t device, double* out32) {
     if (!out32 || hipSetDevice(device) != hipSuccess) return -1;
