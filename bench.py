@@ -235,6 +235,45 @@ def _rate(num, ms):
     return num / (ms * 1e-3) if ms > 0 else 0.0
 
 
+def start_power_watch():
+    """rocm-smi sampled by a CHILD process (tools/power_watch.py --until-eof) beside the run: socket power against its cap and
+    the shader clock the power management holds.  Best effort: None where the tool is missing."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "power_watch.py")
+    if not os.path.exists(tool):
+        return None
+    try:
+        return subprocess.Popen([sys.executable, tool, "--period", "0.1", "--until-eof"], stdin=subprocess.PIPE,
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except OSError:
+        return None
+
+
+def stop_power_watch(proc, wall0, wall1):
+    """-> summary of the samples that fall into the timed region [wall0, wall1] (unix seconds), or None"""
+    try:
+        out, _ = proc.communicate(input="", timeout=20)
+        d = json.loads(out.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001 - diagnostic only
+        try:
+            proc.kill()
+        except OSError:
+            pass
+        return None
+    rows = [r for r in d.get("samples", []) if wall0 <= r[0] <= wall1]
+    if not rows:
+        return None
+    med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
+    pw, ck = [r[1] for r in rows], [r[2] for r in rows]
+    hot = [r for r in rows if d.get("cap_w") and r[1] >= 0.93 * d["cap_w"]]
+    return {"source": "rocm-smi sampled every ~0.1 s by a child process over the timed region (tools/power_watch.py)",
+            "cap_w": d.get("cap_w"), "samples": len(rows), "socket_w_median": med(pw), "socket_w_max": max(pw),
+            "sclk_mhz_median": med(ck), "sclk_mhz_min": min(ck), "junction_c_max": max(r[3] for r in rows),
+            "fraction_of_samples_within_7pct_of_cap": round(len(hot) / len(rows), 3),
+            "note": "with the concurrent restarts in flight the socket sits at its power cap and the clock is managed down; "
+                    "a bare v_mfma_f64_4x4x4_4b loop holds 71 TFLOP/s at 2.40 GHz and ~1130 W (profiles/r03_sustained_mfma_probe.json)"}
+
+
 EXIT_PEER_LOST = 4    # a rank whose peer vanished mid-collective (the launcher reports the rank that vanished, not this one)
 
 
@@ -305,6 +344,7 @@ def main():
     ap.add_argument("--concurrency", type=int, default=2,
                     help="randomized restarts in flight beside the main run (auxiliary engine handles per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (socket power, sclk) beside the timed region")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0; RCCL is made to accept that by giving every rank its own "
                          "NCCL_HOSTID (a real N-rank communicator over RCCL's socket transport on loopback)")
@@ -320,6 +360,9 @@ def main():
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     # No PyTorch: the host side needs a rendezvous and a few tiny object gathers (sharding.SocketComm, TCP on
     # MASTER_ADDR), the device collectives are RCCL inside libmfgp_hip.so on the engine's own stream.
+    power_proc = None
+    if rank == 0 and not args.no_power:
+        power_proc = start_power_watch()       # a child that samples rocm-smi; started BEFORE this process touches HIP
     from multifidelity_datafusion_gps_amd import sharding
     if world > 1 and args.single_device:
         os.environ.update(sharding.rehearsal_env(rank))      # before librccl is loaded (lazily, by attach_engine)
@@ -362,12 +405,15 @@ def main():
         e.counters(reset=True)
     barrier()
     t0 = time.perf_counter()
+    wall0 = time.time()
     phases = []
     for _ in range(args.steps):
         mean, var, model = one_step(args, comm, engines, data)
         phases.append(model.phase)
     barrier()
     dt = max(comm.allgather_object(time.perf_counter() - t0))     # max over ranks
+    wall1 = time.time()
+    power = stop_power_watch(power_proc, wall0, wall1) if power_proc is not None else None
     ms_per_step = dt * 1e3 / args.steps
 
     # outside the timed region: the row-block K build + RCCL all-gather layout of north_star,
@@ -486,6 +532,8 @@ def main():
             out["roofline_kinv"] = {"kernel": "mfgp_kinv_syrk_f64 (stand-alone K^-1 launch)", "bound": "mfma",
                                     "achieved": round(kinv_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(kinv_tf / FP64_PEAK_TFLOPS, 4)}
+        if power is not None:
+            out["power"] = power
         if rowblock is not None:
             out["rowblock_allgather"] = rowblock
         if world == 1 and not args.no_cpu_baseline:

@@ -1,6 +1,8 @@
 """Run a command and sample rocm-smi beside it (socket power, sclk, junction temperature): is a sustained run power-managed?
 usage: python tools/power_watch.py [--period 0.2] -- <command ...>     (the child is started as a plain subprocess; this
-process never touches HIP).  Prints the child's output, then one JSON line with the samples' summary."""
+process never touches HIP).  Prints the child's output, then one JSON line with the samples' summary.
+       python tools/power_watch.py [--period 0.2] --until-eof          samples until its stdin closes, then prints ONE JSON
+line {"cap": ..., "samples": [[unix time, W, sclk MHz, junction C], ...]} (bench.py starts it this way, before it touches HIP)."""
 import json
 import subprocess
 import sys
@@ -23,6 +25,30 @@ def main():
     if argv and argv[0] == "--period":
         period = float(argv[1])
         argv = argv[2:]
+    if argv and argv[0] == "--until-eof":
+        cap = subprocess.run(["rocm-smi", "-d", "0", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        try:
+            cap_w = float(json.loads(cap)["card0"]["Max Graphics Package Power (W)"])
+        except Exception:  # noqa: BLE001
+            cap_w = None
+        rows, stop = [], threading.Event()
+
+        def loop_eof():
+            while not stop.is_set():
+                try:
+                    s_ = sample()
+                    rows.append([round(time.time(), 3), s_["power_w"], s_["sclk_mhz"], s_["temp_c"]])
+                except Exception:  # noqa: BLE001
+                    pass
+                stop.wait(period)
+
+        th = threading.Thread(target=loop_eof, daemon=True)
+        th.start()
+        sys.stdin.read()            # returns when the parent closes the pipe (or dies)
+        stop.set()
+        th.join(timeout=10)
+        print(json.dumps({"cap_w": cap_w, "samples": rows}), flush=True)
+        return
     if argv and argv[0] == "--":
         argv = argv[1:]
     cap = subprocess.run(["rocm-smi", "-d", "0", "--showmaxpower", "--json"], capture_output=True, text=True).stdout.strip()
