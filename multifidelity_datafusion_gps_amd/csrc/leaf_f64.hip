@@ -425,8 +425,42 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     leaf_body_v3(smem, A, Lout, S, ld, blk, logdet_part, info, stamps);
 }
 
+// TIMING PLACEBO (MFGP_LEAF_PLACEBO = bytes of LDS; results are garbage, for schedule experiments only): a workgroup of the
+// leaf's shape -- 8 waves, ~the same registers -- that holds `bytes` of LDS for the 27 us the real leaf takes alone and
+// copies the block through.  Answers "what would the evaluation take if the leaf fitted beside ONE resident bulk
+// workgroup (<= 97 KB) instead of needing a whole CU (138 KB)" before anyone rewrites the leaf for it.
+__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_placebo(const double* __restrict__ A, double* Lout, double* S, int ld,
+                                                                     int blk, double* logdet_part, long long hold_ticks) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int e = tid; e < NB * NB; e += LEAF_THREADS) {
+        const int r = e / NB, c = e % NB;
+        const double v = (c <= r) ? A[g0 + (int64_t)r * ld + c] : 0.0;
+        smem[(e * 7) % 4096] = v;
+        Lout[g0 + (int64_t)r * ld + c] = (r == c) ? 1.0 : 0.0;     // identity factor: everything downstream stays finite
+        S[g0 + (int64_t)r * ld + c] = (r == c) ? 1.0 : 0.0;
+    }
+    if (tid == 0) logdet_part[blk] = smem[5] * 0.0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps) {
+    static const int placebo = getenv("MFGP_LEAF_PLACEBO") ? atoi(getenv("MFGP_LEAF_PLACEBO")) : 0;
+    if (placebo > 0) {
+        static std::once_flag once_p[MFGP_MAX_DEVICES];
+        int devp = 0;
+        (void)hipGetDevice(&devp);
+        std::call_once(once_p[devp & (MFGP_MAX_DEVICES - 1)], [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_placebo), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      placebo);
+        });
+        hipLaunchKernelGGL(mfgp_leaf_placebo, dim3(1), dim3(LEAF_THREADS), (size_t)placebo, s, A, Lout, S, ld, blk, logdet_part,
+                           (long long)2700);   // 27 us in 100 MHz ticks
+        return;
+    }
     constexpr size_t lds = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
     static std::once_flag attr_once[MFGP_MAX_DEVICES];   // per device, thread-safe (see launch_gemm)
     int dev = 0;
