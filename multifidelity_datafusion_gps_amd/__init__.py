@@ -7,10 +7,11 @@ symlink to it.)
 from .abstractMFGP import AbstractMFGP
 from .MFDataFusion import MultifidelityDataFusion
 from .models import GPDF, GPDFC, NARGP
-from . import engine, gpc, sharding
-from .adaptation_maximizers import AbstractMaximizer, DIRECT1Maximizer, ScipyDirectMaximizer
+from . import adaptation_maximizers, engine, gpc, sharding
+from .adaptation_maximizers import AbstractMaximizer, DIRECT1Maximizer, PanelMaximizer, ScipyDirectMaximizer
 from .augm_iterators import AbstractAugmIterator, BackwardAugmentation, EvenAugmentation
 
 __all__ = ["AbstractMFGP", "MultifidelityDataFusion", "NARGP", "GPDF", "GPDFC", "engine", "gpc", "sharding",
-           "AbstractMaximizer", "DIRECT1Maximizer", "ScipyDirectMaximizer", "AbstractAugmIterator",
+           "AbstractMaximizer", "DIRECT1Maximizer", "PanelMaximizer", "ScipyDirectMaximizer", "adaptation_maximizers",
+           "AbstractAugmIterator",
            "BackwardAugmentation", "EvenAugmentation"]

@@ -255,6 +255,49 @@ def test_cfg5_adaptation_with_refit_and_add_noise_counts_evaluations():
     model.close()
 
 
+def test_cfg5_candidate_panel_acquisitions_n65536():
+    """cfg5 in the form BASELINE.json words it -- "predictive-variance panels" (a candidate panel of N* = 65536
+    Sobol points per acquisition): every acquisition is ONE two-level predictive panel of 65536 rows (low-fidelity stencil
+    means -> augmented rows -> high-fidelity variance), the new row a rank-1 append.  The panel's variances are checked
+    against the oracle at the current hyper-parameters on a sample of candidates AND at the oracle's own argmax, and the
+    acquired point must be the oracle's choice."""
+    import time
+    import multifidelity_datafusion_gps_amd as mf
+    model, rng = _cfg5_model(4096, seed=8, evals=6, restarts=1)
+    mx = mf.adaptation_maximizers.PanelMaximizer(n_candidates=65536, seed=11)
+    model.adapt_maximizer = mx
+    model.data_driven_lf_approach = False
+    model.fit(rng.uniform(size=(500, 4)))
+    model.predict(rng.uniform(size=(2, 4)))                 # add_noise: sigma_n^2 := 1e-6 from here on
+    C = mx.candidates(model.lower_bound, model.upper_bound)
+    # the panel as the acquisition sees it, against the oracle (HF level at the current hyper-parameters; the augmented rows
+    # come from the model's own -- device-chained -- low-fidelity means)
+    t0 = time.perf_counter()
+    mean, var = model.predict(C)
+    t_panel = time.perf_counter() - t0
+    parts, theta, noise = _theta_noise(model)
+    st = orc.inference(parts, theta, noise, model.hf_model.X, model.hf_Y[:, 0], want_grad=False)
+    Ca = model._augment_data(C)
+    mu_o, var_o = orc.predict_stable(parts, theta, noise, model.hf_model.X, st, Ca)
+    np.testing.assert_allclose(var[:, 0], var_o, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(mean[:, 0], mu_o, rtol=0, atol=1e-6 * max(1.0, np.abs(model.hf_Y).max()))
+    k_o = int(np.argmax(var_o))
+    evals0 = model.hf_model.n_evals
+    t0 = time.perf_counter()
+    model.adapt(12, reoptimize=False)                       # 500 -> 512: the last append crosses the 128-row boundary
+    t_adapt = (time.perf_counter() - t0) / 12
+    pts = np.array(model.acquired_points).reshape(12, 4)
+    assert var[k_o, 0] >= var[:, 0].max() - 1e-6            # the oracle's argmax is (within tolerance) the panel's maximum here
+    assert np.abs(pts[0] - C[int(np.argmax(var[:, 0]))]).max() == 0.0
+    assert all((np.abs(C - p).sum(axis=1) == 0).any() for p in pts) and len(np.unique(pts, axis=0)) == 12
+    assert mx.last_info == {"evaluations": 65536, "panels": 1, "argmax": mx.last_info["argmax"]}
+    assert model.hf_model.n_evals <= evals0 + 1 and len(model.hf_X) == 512
+    _against_oracle(model, rng, atol=1e-6)
+    print("cfg5 panel form: one 65536-row two-level panel at N_hf = 500 (N_lf = 4096): %.1f ms; acquisition + append: %.1f ms"
+          % (t_panel * 1e3, t_adapt * 1e3))
+    model.close()
+
+
 def test_cfg5_at_its_stated_size_512_to_8192(engine_cls):
     """BASELINE.json config 5 at size: N_lf = 16384 (data-driven low-fidelity GP), the high-fidelity set grown from 512 to
     8192 rows by the entropy-reduction loop (src/abstractMFGP.py:317-359) with add_noise=True (src/MFDataFusion.py:154-155:

@@ -42,8 +42,13 @@ def _model_run(comm, conc):
     mean, var = model.predict(rng.uniform(size=(333, 2)))
     theta = np.array([p.value for p in model.hf_model.parameters()])
     evals = model.hf_model.n_evals
+    # cfg5's panel form: one predictive-variance panel per acquisition, its rows sharded over the ranks and gathered; every
+    # rank must acquire the same point
+    model.adapt_maximizer = mf.adaptation_maximizers.PanelMaximizer(n_candidates=4096, seed=5)
+    model.adapt(2, reoptimize=False)
+    acquired = np.array(model.acquired_points).reshape(2, 2)
     model.close()
-    return dict(theta=theta, mean=mean, var=var, evals=evals)
+    return dict(theta=theta, mean=mean, var=var, evals=evals, acquired=acquired)
 
 
 def _rowblock_run(comm):
@@ -95,6 +100,7 @@ def test_two_processes_on_one_gpu_with_the_hip_engine():
             np.testing.assert_allclose(got["mean"], ref["mean"], rtol=0, atol=1e-7)
             np.testing.assert_allclose(got["var"], ref["var"], rtol=0, atol=1e-7)
             np.testing.assert_array_equal(got["mean"], out[0][key]["mean"])
+            np.testing.assert_array_equal(got["acquired"], ref["acquired"])     # sharded panels: the single process's picks
         assert out[r]["seq"]["evals"] < ref["evals"]
         # e3: K built by two ranks' row blocks + gathered = the fused evaluation, bit for bit (same kernels, same order)
         (f0, g0), (f1, g1) = out[r]["rowblock"]
@@ -165,6 +171,7 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
         np.testing.assert_allclose(m["mean"], ref["mean"], rtol=0, atol=1e-7)
         np.testing.assert_allclose(m["var"], ref["var"], rtol=0, atol=1e-7)
         np.testing.assert_array_equal(m["mean"], out[0]["model"]["mean"])
+        np.testing.assert_array_equal(m["acquired"], ref["acquired"])           # panel rows over RCCL: the same acquisitions
         assert m["evals"] < ref["evals"]
 
 

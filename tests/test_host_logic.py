@@ -97,6 +97,56 @@ def test_maximizers_return_negated_variance_like_the_reference():
         assert fopt == pytest.approx(-1.0, abs=2e-2)
 
 
+def test_panel_maximizer_one_predictive_panel_per_acquisition():
+    """the candidate-panel form of BASELINE.json configuration 5 (N* = 65536 Sobol / uniform points per
+    acquisition): ONE model_predict call per maximisation, the reference's return convention, a reproducible panel"""
+    from multifidelity_datafusion_gps_amd.adaptation_maximizers import PanelMaximizer
+    centre = np.array([0.3, 0.8, 0.55])
+    calls = []
+
+    def model_predict(X):
+        calls.append(X.shape)
+        v = np.exp(-20 * np.sum((X - centre) ** 2, axis=1))[:, None]
+        return np.zeros_like(v), v
+    mx = PanelMaximizer(n_candidates=1 << 14, seed=3)
+    x, fopt = mx.maximize(model_predict, np.zeros(3), np.ones(3))
+    assert calls == [(1 << 14, 3)] and mx.last_info["panels"] == 1
+    assert np.abs(x - centre).max() < 0.05 and -1.0 <= fopt < -0.9          # (x_opt, -max variance)
+    x2, f2 = PanelMaximizer(n_candidates=1 << 14, seed=3).maximize(model_predict, np.zeros(3), np.ones(3))
+    assert np.array_equal(x, x2) and f2 == fopt                              # same seed, same panel, same pick
+    C = mx.candidates(np.array([-1.0, 2.0, 0.0]), np.array([1.0, 3.0, 10.0]))
+    assert C.shape == (1 << 14, 3) and (C >= [-1, 2, 0]).all() and (C <= [1, 3, 10]).all() and len(np.unique(C, axis=0)) == 1 << 14
+    u = PanelMaximizer(n_candidates=1000, sampler="uniform", seed=1, resample=True)
+    a, b = u.candidates(np.zeros(2), np.ones(2)), u.candidates(np.zeros(2), np.ones(2))
+    assert a.shape == (1000, 2) and (a != b).any()                           # resample: a fresh panel per call
+    with pytest.raises(ValueError):
+        PanelMaximizer(sampler="halton")
+
+
+def test_adaptation_with_the_panel_maximizer_on_the_oracle_double():
+    """the adaptation loop (src/abstractMFGP.py:317-359) driven by panel acquisitions: each step costs one predictive panel,
+    the acquired points are candidates of the panel, none is taken twice, and the error on held-out points drops"""
+    import multifidelity_datafusion_gps_amd as mf
+    from multifidelity_datafusion_gps_amd.adaptation_maximizers import PanelMaximizer
+    from tests.oracle_engine import OracleEngine
+    hf = lambda x: (np.sin(2.2 * np.pi * x[:, 0]) * np.sin(np.pi * x[:, 1]))[:, None]
+    lf = lambda x: hf(x) - 1.2 * (np.sin(0.1 * np.pi * x[:, :1]) + np.sin(0.1 * np.pi * x[:, 1:2]))
+    rng = np.random.default_rng(2)
+    mx = PanelMaximizer(n_candidates=2048, seed=7)
+    model = mf.NARGP(2, hf, lf, seed=1, adapt_maximizer=mx, engines={"hf": OracleEngine(), "lf": OracleEngine()})
+    model.first_run_max_iters = model.restart_max_iters = 30
+    model.num_restarts = 1
+    model.fit(rng.uniform(size=(12, 2)))
+    Xt = rng.uniform(size=(200, 2))
+    before = model.get_mse(Xt, hf(Xt))
+    model.adapt(6)                          # the reference's loop: refit after every acquisition (the double has no append)
+    pts = np.array(model.acquired_points).reshape(6, 2)
+    C = mx.candidates(model.lower_bound, model.upper_bound)
+    assert all((np.abs(C - p).sum(axis=1) == 0).any() for p in pts)          # every acquisition is a panel candidate
+    assert len(np.unique(pts, axis=0)) == 6
+    assert model.get_mse(Xt, hf(Xt)) < before
+
+
 def test_split_rows_covers_everything_once():
     for n in (0, 1, 7, 8192, 8195):
         for size in (1, 2, 3, 8):

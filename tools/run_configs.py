@@ -103,4 +103,25 @@ m.adapt(steps, reoptimize=False)
 t2 = time.perf_counter()
 print("cfg5 adaptation 4-D N_lf=%d N_hf=%d->%d: %d steps with refit %.0f ms/step; %d steps with rank-1 append %.1f ms/step (DIRECT evals/step ~%d)"
       % (n_lf, n0, len(m.hf_X), steps, (t1 - t0) * 1e3 / steps, steps, (t2 - t1) * 1e3 / steps, m.adapt_maximizer.last_info["nf"]))
+# the same in the candidate-panel form BASELINE.json words it ("predictive-variance panels"): one two-level panel of N* = 65536
+# Sobol points per acquisition, at the start of the growth and at its end (N_hf = 8192)
+n_star = 4096 if args.quick else 65536
+m.adapt_maximizer = mf.PanelMaximizer(n_candidates=n_star, seed=1)
+m.adapt(1, reoptimize=False)          # warm-up: draws the panel, sizes the device buffers
+t0 = time.perf_counter()
+m.adapt(steps, reoptimize=False)
+t1 = time.perf_counter()
+line = "cfg5 panel form N*=%d: N_hf=%d acquisition + rank-1 append %.1f ms/step" % (n_star, len(m.hf_X), (t1 - t0) * 1e3 / steps)
+if not args.quick:
+    m.eval_cap = m.lf_max_iters = m.first_run_max_iters = m.restart_max_iters = 2     # a token fit: the panel is what is timed
+    m.num_restarts = 1
+    m.fit(rng.uniform(size=(8192, 4)))
+    m.adapt(1, reoptimize=False)
+    t0 = time.perf_counter()
+    m.adapt(steps, reoptimize=False)
+    t1 = time.perf_counter()
+    Np = 8192 + 128
+    line += "; N_hf=%d %.1f ms/step (variance product %.1f TFLOP/s incl. everything else)" % (
+        len(m.hf_X), (t1 - t0) * 1e3 / steps, float(Np) * Np * n_star / ((t1 - t0) / steps) / 1e12)
+print(line)
 m.close()
