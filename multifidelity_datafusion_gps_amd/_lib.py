@@ -84,6 +84,14 @@ def load_library(path=None):
         raise EngineUnavailable(
             "%s not found: build it with `python -m multifidelity_datafusion_gps_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues per priority (ROCm's default: 4).  A fit keeps up to
+    # four engine handles busy (low-fidelity level, high-fidelity level, two concurrent restarts), each with a high-priority
+    # chain stream and a low-priority bulk stream; measured with those eight streams (tools/gpu_r03_queues.sh,
+    # profiles/r03_hw_queues.txt): 2 queues per priority beat the default 4 -- cfg3's chain-bound HF level (N = 4096) 404 -> 345 ms
+    # per fit, the N = 8192 bench 1777 -> 1765 ms -- 3 are worse (500 / 1820), 1 serialises the evaluations (bench 1962),
+    # 8 and 12 equal 4; one evaluation alone does not care.  Only a default: the caller's own setting wins, and it must be in the
+    # environment before the HIP runtime initialises (the first library call), hence here.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MFGP_HW_QUEUES", "2"))
     try:
         lib = ctypes.CDLL(p)
     except OSError as e:  # missing ROCm runtime etc.

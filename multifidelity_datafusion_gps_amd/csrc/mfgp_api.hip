@@ -117,8 +117,9 @@ static int create_body(mfgp_handle* h, int device_id) {
             HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         }
     }
-    // column stream: what the NEXT macro panel's chain waits for, launched beside the bulk stream's work -- the chain's priority
-    HIPCHK(h, hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
+    // (the column stream of the three-stream plans is created when a plan first asks for it: build_plans.  Every HIP stream
+    // beyond the runtime's few hardware queues shares one with another stream -- an idle extra stream per handle cost the
+    // four-handle bench configuration 1 % and cfg3's chain-bound HF level 40 %)
     // timing events: no system-scope fence at the record either (more precise stamps, and cheaper: see build_plans)
     for (auto& ev : h->ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
     // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
@@ -178,6 +179,15 @@ int32_t mfgp_destroy(mfgp_handle* h) {
 
 static int build_plans(mfgp_handle* h) {
     build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap);
+    if (!h->stream3) {
+        bool wants3 = false;
+        for (const Step& st : h->pl.steps) wants3 = wants3 || st.strm == 2;
+        if (wants3) {   // column stream: what the NEXT macro panel's chain waits for -- the chain's priority
+            int prio_lo = 0, prio_hi = 0;
+            HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            HIPCHK(h, hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
+        }
+    }
     while ((int)h->evpool.size() < h->pl.n_events) {
         hipEvent_t e;
         // the plan's events order kernels of ONE device across the handle's two streams: no system-scope fence (cache
