@@ -96,6 +96,18 @@ static int create_body(mfgp_handle* h, int device_id) {
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     // the main stream carries the serial chain (leaf -> panel -> narrow update): most urgent, so that its
     // workgroups take the first CU a bulk-update workgroup vacates
+    {   // experiment switches: MFGP_PRIO_CHAIN / MFGP_PRIO_BULK = hi | normal | lo (defaults: chain hi, bulk lo)
+        auto pick = [&](const char* name, int dflt) {
+            const char* e = getenv(name);
+            if (!e) return dflt;
+            if (!strcmp(e, "hi")) return prio_hi;
+            if (!strcmp(e, "lo")) return prio_lo;
+            return (prio_hi + prio_lo) / 2;
+        };
+        const int pc = pick("MFGP_PRIO_CHAIN", prio_hi), pb = pick("MFGP_PRIO_BULK", prio_lo);
+        prio_hi = pc;
+        prio_lo = pb;
+    }
     HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
     {
         // bulk-update stream; optionally keep MFGP_U_RESERVE CUs PER XCD out of its reach, so that the serial chain -- above all
