@@ -19,7 +19,7 @@ class BudgetNARGP(mf.NARGP):
     """fixed evaluation budget per L-BFGS-B run; a subclass because the data-driven LF level is fitted in the constructor"""
     lf_max_iters = first_run_max_iters = restart_max_iters = E
     eval_cap = E
-    restart_concurrency = 2
+    restart_concurrency = int(os.environ.get("MFGP_RESTART_CONC", "2"))
 
 
 def col(f):
