@@ -91,7 +91,9 @@ def load_library(path=None):
     # per fit, the N = 8192 bench 1777 -> 1765 ms -- 3 are worse (500 / 1820), 1 serialises the evaluations (bench 1962),
     # 8 and 12 equal 4; one evaluation alone does not care.  Only a default: the caller's own setting wins, and it must be in the
     # environment before the HIP runtime initialises (the first library call), hence here.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MFGP_HW_QUEUES", "2"))
+    # MFGP_HW_QUEUES=0 leaves the runtime's own default alone (a host application with its own stream-heavy HIP work).
+    if os.environ.get("MFGP_HW_QUEUES", "2") != "0":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MFGP_HW_QUEUES", "2"))
     try:
         lib = ctypes.CDLL(p)
     except OSError as e:  # missing ROCm runtime etc.
