@@ -1,0 +1,86 @@
+"""Randomised parity soak on the GPU box: random sizes (block-count boundaries of the planner included), random kernel
+structures (single / composite, RBF / Matern-3/2 / -5/2, isotropic / ARD), random hyper-parameters and noise levels; the HIP
+engine against the numpy/LAPACK oracle on NLML, gradient, alpha (through K^-1 y), predictive mean and variance -- and, every few
+cases, a rank-1 append against a fresh factorisation.  usage: fuzz_parity.py [seconds=120] [seed=0] [nmax=3000]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from multifidelity_datafusion_gps_amd._lib import Engine  # noqa: E402
+from oracle import gp_oracle as orc  # noqa: E402
+from tests import cases  # noqa: E402
+
+BOUNDARY_NB = [1, 2, 3, 4, 5, 8, 12, 13, 14, 15, 23, 24, 25, 26]       # planner defaults change around these block counts
+
+
+def random_case(rng, nmax):
+    if rng.uniform() < 0.5:
+        nb = int(rng.choice([b for b in BOUNDARY_NB if b * 128 <= nmax + 127]))
+        N = int(np.clip(nb * 128 - rng.integers(0, 3) * rng.integers(0, 127), 1, nmax))
+    else:
+        N = int(rng.integers(1, nmax + 1))
+    d = int(rng.integers(1, 6))
+    types = [cases.RBF, cases.M32, cases.M52]
+    ard = lambda: cases.ARD if rng.uniform() < 0.3 else 0   # noqa: E731
+    if rng.uniform() < 0.5:
+        parts = [(int(rng.choice(types)) | ard(), 0, d, 0)]
+        D = d
+    else:
+        c = int(rng.integers(1, 4))
+        parts = [(int(rng.choice(types)) | ard(), d, d + c, 0), (int(rng.choice(types)) | ard(), 0, d, 0),
+                 (int(rng.choice(types)) | ard(), 0, d, 1)]
+        D = d + c
+    npar = orc.layout(parts)[1]
+    theta = np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=npar))
+    X = rng.uniform(size=(N, D))
+    Y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.standard_normal(N)
+    noise = float(np.exp(rng.uniform(np.log(1e-4), np.log(0.3)))) * max(Y.var(), 1e-3)
+    Xs = rng.uniform(size=(int(rng.integers(1, 200)), D))
+    return dict(N=N, D=D, parts=parts, theta=theta, noise=noise, X=X, Y=Y, Xs=Xs)
+
+
+def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
+    """-> (number of cases, list of mismatches, worst relative errors)"""
+    rng = np.random.default_rng(seed)
+    e, fresh = Engine(0), Engine(0)
+    t0, n, worst = time.time(), 0, dict(nlml=0.0, grad=0.0, mean=0.0, var=0.0, append=0.0)
+    bad = []
+    while time.time() - t0 < seconds and (max_cases is None or n < max_cases):
+        c = random_case(rng, nmax)
+        st = orc.inference(c["parts"], c["theta"], c["noise"], c["X"], c["Y"])
+        mu, var = orc.predict_stable(c["parts"], c["theta"], c["noise"], c["X"], st, c["Xs"])
+        e.set_data(c["X"], c["Y"]); e.set_kernel(c["parts"])
+        nlml, grad = e.eval(c["theta"], c["noise"], 1e-8)
+        m, v = e.predict(c["Xs"])
+        gs = max(1.0, np.abs(st["grad"]).max())
+        err = dict(nlml=abs(nlml - st["nlml"]) / max(1.0, abs(st["nlml"])), grad=np.abs(grad - st["grad"]).max() / gs,
+                   mean=np.abs(m - mu).max() / max(1.0, np.abs(c["Y"]).max()), var=np.abs(v - var).max(), append=0.0)
+        if n % 4 == 0 and c["N"] >= 2:          # rank-1 append of the last row against the fused evaluation of all rows
+            fresh.set_data(c["X"][:-1], c["Y"][:-1]); fresh.set_kernel(c["parts"])
+            fresh.eval(c["theta"], c["noise"], 1e-8, want_grad=False)
+            if fresh.append_row(c["X"][-1], float(c["Y"][-1])):
+                m2, v2 = fresh.predict(c["Xs"])
+                err["append"] = max(np.abs(m2 - m).max() / max(1.0, np.abs(c["Y"]).max()), np.abs(v2 - v).max())
+        tol = dict(nlml=1e-9, grad=1e-7, mean=1e-7, var=1e-7, append=1e-7)
+        for k in worst:
+            worst[k] = max(worst[k], float(err[k]))
+        if any(not (err[k] <= tol[k]) for k in tol):
+            bad.append((n, c["N"], c["D"], c["parts"], [float(x) for x in c["theta"]], c["noise"], {k: float(x) for k, x in err.items()}))
+            if verbose:
+                print("MISMATCH", bad[-1], flush=True)
+        n += 1
+        if verbose and n % 25 == 0:
+            print("%d cases, %.0f s, worst so far %s" % (n, time.time() - t0, {k: "%.1e" % x for k, x in worst.items()}), flush=True)
+    e.close(); fresh.close()
+    if verbose:
+        print("fuzz_parity: %d cases in %.0f s (seed %d, N <= %d), %d mismatches; worst relative errors %s"
+              % (n, time.time() - t0, seed, nmax, len(bad), {k: "%.2e" % x for k, x in worst.items()}))
+    return n, bad, worst
+
+
+if __name__ == "__main__":
+    _, _bad, _ = run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                     int(sys.argv[3]) if len(sys.argv) > 3 else 3000)
+    sys.exit(1 if _bad else 0)
