@@ -12,7 +12,7 @@ from multifidelity_datafusion_gps_amd._lib import Engine  # noqa: E402
 from oracle import gp_oracle as orc  # noqa: E402
 from tests import cases  # noqa: E402
 
-BOUNDARY_NB = [1, 2, 3, 4, 5, 8, 12, 13, 14, 15, 23, 24, 25, 26]       # planner defaults change around these block counts
+BOUNDARY_NB = [1, 2, 3, 4, 5, 8, 12, 13, 14, 15, 23, 24, 25, 26, 47, 48, 49, 55, 56, 57]   # planner defaults change around these block counts
 
 
 def random_case(rng, nmax):
