@@ -74,6 +74,8 @@ def one_step(args, comm, engines, data):
         restart_max_iters = args.evals
         num_restarts = args.restarts
         restart_concurrency = args.concurrency
+        restart_aux = args.aux if args.aux > 0 else None
+        restart_lend_main = bool(args.lend_main)
         eval_cap = args.evals          # exact: scipy's maxfun alone lets a run overshoot by a line search
 
     t0 = time.perf_counter()
@@ -343,6 +345,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--concurrency", type=int, default=2,
                     help="randomized restarts in flight beside the main run (auxiliary engine handles per rank)")
+    ap.add_argument("--aux", type=int, default=0, help="auxiliary engine handles of the concurrent restarts (0: --concurrency of them)")
+    ap.add_argument("--aux-order", default="natural", choices=["natural", "reversed"])
+    ap.add_argument("--lend-main", type=int, default=0, help="1: the main engine joins the restarts' pool after restart 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (socket power, sclk) beside the timed region")
     ap.add_argument("--single-device", action="store_true",
@@ -377,7 +382,11 @@ def main():
         local_rank = 0
         first = Engine(0)
     engines = {"lf": first, "hf": Engine(local_rank)}
-    for j in range(1, args.concurrency + 1 if args.concurrency > 1 else 1):
+    # creation ORDER matters: HIP maps the handles' streams onto its hardware queues by creation, and handles that share a queue
+    # serialise (tools/queue_pairs.py: of four handles created back to back, 0 + 3 and 1 + 2 share).  --aux-order reversed creates
+    # hf#2 before hf#1, so that the first auxiliary handle lands on the lane the main handle (hf) is NOT on.
+    js = list(range(1, args.concurrency + 1 if args.concurrency > 1 else 1))
+    for j in (reversed(js) if args.aux_order == "reversed" else js):
         engines["hf#%d" % j] = Engine(local_rank)
     collectives = "none (1 rank)"
     if world > 1:

@@ -36,6 +36,8 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     lf_max_iters = 1000         # lf_model.optimize() default budget (src/abstractMFGP.py:103)
     eval_cap = None             # hard cap on objective evaluations per L-BFGS-B run (benchmarks: exact budgets)
     restart_concurrency = 1     # >1: that many randomized restarts run concurrently with the first run / restart 0
+    restart_lend_main = False   # the main engine joins the restarts' pool once its sequential runs are through
+    restart_aux = None          # auxiliary engine handles of the concurrent restarts (None: restart_concurrency of them)
     diagonal_points = 1000      # resolution of the box diagonal the adaptation loop predicts on every step (:318)
 
     @abc.abstractmethod
@@ -212,9 +214,11 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         handle = None
         if mine_bg:
             tag = self._level_of(model)
-            aux = [self._engine("%s#%d" % (tag, j)) for j in range(1, min(conc, len(mine_bg)) + 1)]
+            n_aux = self.restart_aux if self.restart_aux is not None else conc
+            aux = [self._engine("%s#%d" % (tag, j)) for j in range(1, min(n_aux, len(mine_bg)) + 1)]
             handle = model.start_background_restarts(mine_bg, aux, free=list(model.parameters()),   # all free during restarts
-                                                     rand_gen=self._restart_rng(), max_iters=self.restart_max_iters)
+                                                     rand_gen=self._restart_rng(), max_iters=self.restart_max_iters,
+                                                     spare=1 if self.restart_lend_main else 0)
         runs = []
         if rank == 0:
             model.optimize(max_iters=self.first_run_max_iters)
@@ -224,6 +228,10 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             if r0 is not None:
                 runs.append((r0.f_opt, r0.x_opt, 0))
         if handle is not None:
+            if self.restart_lend_main:
+                # this rank's sequential share is through (rank 0: first run -> restart 0; the others had none): its main engine
+                # joins the pool, so that the last restarts do not run alone on one auxiliary handle
+                model.lend_engine(handle)
             runs += handle.result()
         if size > 1:
             runs = [r for part in self.comm.allgather_object(runs) for r in part]

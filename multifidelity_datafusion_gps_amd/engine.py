@@ -630,13 +630,15 @@ class GPRegression:
 
         return f_fp
 
-    def start_background_restarts(self, indices, engines, free=None, rand_gen=None, max_iters=1000):
+    def start_background_restarts(self, indices, engines, free=None, rand_gen=None, max_iters=1000, spare=0):
         """Run the randomized restarts `indices` (each: N(0,1) start in optimizer space, L-BFGS-B with
         maxfun = maxiter = max_iters) on the given auxiliary engines, one thread per engine; returns a handle
         whose .result() gives [(f_opt, x_opt, index), ...].  `free` = the parameters that are free DURING the
         restarts (default: all).  The restarts of the reference recipe do not depend on the run that precedes
         them (paramz randomizes every free parameter), so they may overlap it; with two or three evaluations
-        in flight the GPU's idle phases (the serial Cholesky chain) of one are filled by the bulk work of another."""
+        in flight the GPU's idle phases (the serial Cholesky chain) of one are filled by the bulk work of another.
+        `spare`: worker threads beyond the engines given now -- for engines lent later (`handle.lend(engine)`: the caller's own
+        main engine once its sequential runs are through, so that the tail of the restarts does not run alone)."""
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
@@ -675,16 +677,37 @@ class GPRegression:
             finally:
                 pool_q.put(eng)
 
-        ex = ThreadPoolExecutor(max_workers=len(engines))
+        ex = ThreadPoolExecutor(max_workers=len(engines) + max(0, int(spare)))
         futs = [ex.submit(one, i) for i in indices]
+        model = self
 
         class _Handle:
+            def lend(self_inner, eng):
+                """one more engine for the restarts still waiting (its data / kernel are set here; whatever state it held is gone)"""
+                if all(f.done() for f in futs):
+                    return False
+                eng.set_data(model.X, model.Y[:, 0])
+                eng.set_kernel(model._parts)
+                pool_q.put(eng)
+                return True
+
             def result(self_inner):
                 try:
                     return [f.result() for f in futs]
                 finally:
                     ex.shutdown(wait=True)
         return _Handle()
+
+    def lend_engine(self, handle):
+        """lend this model's OWN engine to its background restarts (after the model's sequential runs): the factorisation it
+        holds is given up -- the next use of the model refactorises at the then-current parameters."""
+        if handle is None or not hasattr(handle, "lend"):
+            return False
+        if handle.lend(self._engine):
+            self._dirty = True
+            self._have_grad = False
+            return True
+        return False
 
     def optimize_restarts(self, num_restarts=10, robust=False, verbose=True, parallel=False, num_processes=None,
                           rand_gen=None, comm=None, **kwargs):

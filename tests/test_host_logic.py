@@ -147,6 +147,25 @@ def test_adaptation_with_the_panel_maximizer_on_the_oracle_double():
     assert model.get_mse(Xt, hf(Xt)) < before
 
 
+def test_lending_the_main_engine_to_the_restarts_changes_nothing_but_the_schedule():
+    """restart_lend_main: after its sequential runs (first run -> restart 0) the model's own engine joins the pool of the
+    background restarts, with ONE auxiliary handle beside it (restart_aux = 1: two evaluations in flight throughout).  Same runs,
+    same winner, same predictions as the sequential recipe; every restart ran exactly once."""
+    from multifidelity_datafusion_gps_amd.sharding import LocalComm
+    from tests.test_sharding_gloo import _run_model
+    import multifidelity_datafusion_gps_amd as mf
+    seq = _run_model(LocalComm(), 1)
+    saved = (mf.AbstractMFGP.restart_lend_main, mf.AbstractMFGP.restart_aux)
+    mf.AbstractMFGP.restart_lend_main, mf.AbstractMFGP.restart_aux = True, 1
+    try:
+        lent = _run_model(LocalComm(), 2)
+    finally:
+        mf.AbstractMFGP.restart_lend_main, mf.AbstractMFGP.restart_aux = saved
+    np.testing.assert_allclose(lent["theta"], seq["theta"], rtol=1e-12)
+    np.testing.assert_allclose(lent["mean"], seq["mean"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(lent["var"], seq["var"], rtol=0, atol=1e-10)
+
+
 def test_split_rows_covers_everything_once():
     for n in (0, 1, 7, 8192, 8195):
         for size in (1, 2, 3, 8):
