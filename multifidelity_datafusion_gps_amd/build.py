@@ -53,8 +53,11 @@ def build_probes(force=False, verbose=False):
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
+    # MFGP_BUILD_DEFINES: extra -D switches of LAB builds on the GPU box (e.g. "-DMFGP_LAB_PLACEBO=1", tools/gpu_r03_placebo.sh);
+    # the library the repository ships is built without any
+    extra = os.environ.get("MFGP_BUILD_DEFINES", "").split()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-result", "-Wno-unused-value"] + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

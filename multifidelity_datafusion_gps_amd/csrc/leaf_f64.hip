@@ -425,6 +425,10 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
     leaf_body_v3(smem, A, Lout, S, ld, blk, logdet_part, info, stamps);
 }
 
+#ifndef MFGP_LAB_PLACEBO
+#define MFGP_LAB_PLACEBO 0     // 1 only in lab builds (tools/gpu_r03_placebo.sh): the shipped library has no placebo in it
+#endif
+#if MFGP_LAB_PLACEBO
 // TIMING PLACEBO (MFGP_LEAF_PLACEBO = bytes of LDS; results are garbage, for schedule experiments only): a workgroup of the
 // leaf's shape -- 8 waves, ~the same registers -- that holds `bytes` of LDS for the 27 us the real leaf takes alone and
 // copies the block through.  Answers "what would the evaluation take if the leaf fitted beside ONE resident bulk
@@ -446,8 +450,11 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_placebo(const doubl
     while (__builtin_amdgcn_s_memrealtime() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+#endif   // MFGP_LAB_PLACEBO
+
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, unsigned long long* stamps) {
+#if MFGP_LAB_PLACEBO
     static const int placebo = getenv("MFGP_LEAF_PLACEBO") ? atoi(getenv("MFGP_LEAF_PLACEBO")) : 0;
     if (placebo > 0) {
         static std::once_flag once_p[MFGP_MAX_DEVICES];
@@ -461,6 +468,7 @@ void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld
                            (long long)2700);   // 27 us in 100 MHz ticks
         return;
     }
+#endif
     constexpr size_t lds = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
     static std::once_flag attr_once[MFGP_MAX_DEVICES];   // per device, thread-safe (see launch_gemm)
     int dev = 0;

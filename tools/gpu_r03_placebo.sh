@@ -3,6 +3,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 tag=${1:-pl}; out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
+# lab build: the placebo exists only under -DMFGP_LAB_PLACEBO=1 (this box's copy of the tree is thrown away afterwards)
+MFGP_BUILD_DEFINES="-DMFGP_LAB_PLACEBO=1" python -m multifidelity_datafusion_gps_amd.build --force > $out/lab_build.log 2>&1 || exit 1
 for cfg in "0 8 0" "141312 8 0" "97280 8 0" "97280 4 0" "97280 4 1" "30720 8 0" "30720 4 0" "30720 4 1"; do
   set -- $cfg
   echo "LEAF_PLACEBO=$1 CHAIN_WAVES=$2 COLS_STREAM=$3"; MFGP_LEAF_PLACEBO=$1 MFGP_CHAIN_WAVES=$2 MFGP_COLS_STREAM=$3 python tools/time_eval.py 4096 6144 8192 16384 2>&1 | cut -c1-100
