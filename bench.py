@@ -365,6 +365,9 @@ def main():
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     # No PyTorch: the host side needs a rendezvous and a few tiny object gathers (sharding.SocketComm, TCP on
     # MASTER_ADDR), the device collectives are RCCL inside libmfgp_hip.so on the engine's own stream.
+    # dmabuf IPC only on these hosts (RCCL across processes); under torch.distributed.run this process IS a rank and inherits
+    # the caller's environment: make sure of it before the HIP runtime initialises
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     power_proc = None
     if rank == 0 and not args.no_power:
         power_proc = start_power_watch()       # a child that samples rocm-smi; started BEFORE this process touches HIP
