@@ -36,7 +36,8 @@ def random_case(rng, nmax):
     theta = np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=npar))
     X = rng.uniform(size=(N, D))
     Y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.standard_normal(N)
-    noise = float(np.exp(rng.uniform(np.log(1e-4), np.log(0.3)))) * max(Y.var(), 1e-3)
+    lo = float(os.environ.get("FUZZ_NOISE_LO", "1e-4"))      # 1e-6 .. : the add_noise regime (cond(Ky) up to ~1e9)
+    noise = float(np.exp(rng.uniform(np.log(lo), np.log(0.3)))) * max(Y.var(), 1e-3)
     Xs = rng.uniform(size=(int(rng.integers(1, 200)), D))
     return dict(N=N, D=D, parts=parts, theta=theta, noise=noise, X=X, Y=Y, Xs=Xs)
 
@@ -63,7 +64,8 @@ def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
             if fresh.append_row(c["X"][-1], float(c["Y"][-1])):
                 m2, v2 = fresh.predict(c["Xs"])
                 err["append"] = max(np.abs(m2 - m).max() / max(1.0, np.abs(c["Y"]).max()), np.abs(v2 - v).max())
-        tol = dict(nlml=1e-9, grad=1e-7, mean=1e-7, var=1e-7, append=1e-7)
+        scale = float(os.environ.get("FUZZ_TOL_SCALE", "1"))
+        tol = {k: v * scale for k, v in dict(nlml=1e-9, grad=1e-7, mean=1e-7, var=1e-7, append=1e-7).items()}
         for k in worst:
             worst[k] = max(worst[k], float(err[k]))
         if any(not (err[k] <= tol[k]) for k in tol):
