@@ -35,7 +35,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     num_restarts = 6            # src/MFDataFusion.py:100
     lf_max_iters = 1000         # lf_model.optimize() default budget (src/abstractMFGP.py:103)
     eval_cap = None             # hard cap on objective evaluations per L-BFGS-B run (benchmarks: exact budgets)
-    restart_concurrency = 1     # >1: that many randomized restarts run concurrently with the first run / restart 0
+    restart_concurrency = 1     # 1: the reference's sequential order (the default: this layer then drives the engine call for call like the reference); >1: that many randomized restarts run concurrently with the first run / restart 0 -- same runs, same winner, 1.7-2 x faster fits at N = 256 .. 2048 (tools/midsize_fit.py)
     restart_lend_main = False   # the main engine joins the restarts' pool once its sequential runs are through
     restart_aux = None          # auxiliary engine handles of the concurrent restarts (None: restart_concurrency of them)
     diagonal_points = 1000      # resolution of the box diagonal the adaptation loop predicts on every step (:318)
