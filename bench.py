@@ -106,38 +106,72 @@ def _blas_info():
 
 
 def _pick_blas_threads():
-    """OpenBLAS on a box whose CPU share is smaller than its core count (16 of 64 here) is slowest at the default of one
-    thread per visible core: time dpotrf + dpotri at N = 3072 under 8 / 16 / 32 / all threads once and keep the best."""
+    """OpenBLAS on a box whose CPU share is smaller than its core count (16 of 256 visible) is slowest at the default of one
+    thread per visible core: time dpotrf + dpotri at N = 4096 under 8 / 16 / 32 / all threads once and keep the best.
+    Same protocol as _lapack_share (Fortran-ordered operand, one untimed call per setting, best of 2, info checked), so that the
+    rates of the two are comparable."""
     try:
         from scipy.linalg import lapack
         from threadpoolctl import threadpool_limits
     except Exception:  # noqa: BLE001
         return None, {}
     rng = np.random.default_rng(0)
-    n = 3072
+    n = 4096
     M = rng.standard_normal((n, n))
-    A = M.dot(M.T) + n * np.eye(n)
+    A = np.asfortranarray(M.dot(M.T) + n * np.eye(n))
     ncpu = os.cpu_count() or 1
     tried = {}
     for t in sorted({min(t, ncpu) for t in (8, 16, 32, ncpu)}):
         with threadpool_limits(limits=t, user_api="blas"):
             best = np.inf
-            for _ in range(2):
+            for rep in range(3):
                 t0 = time.perf_counter()
-                L, _ = lapack.dpotrf(A, lower=1)
-                lapack.dpotri(L, lower=1)
-                best = min(best, time.perf_counter() - t0)
+                L, i1 = lapack.dpotrf(A, lower=1, overwrite_a=0)
+                _, i2 = lapack.dpotri(L, lower=1, overwrite_c=0)
+                if rep > 0 and i1 == 0 and i2 == 0:
+                    best = min(best, time.perf_counter() - t0)
         tried[t] = round(n ** 3 / best / 1e9, 1)      # dpotrf n^3/3 + dpotri 2 n^3/3
     return max(tried, key=tried.get), tried
 
 
-def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=45.0):
-    """the oracle (numpy + LAPACK dpotrf / dtrtri / dpotri / dpotrs = the routines GPy calls) on the host cores of this
-    box: a BOUNDED sample of the workload -- objective+gradient evaluations of each level at full size (a warm-up and up to
-    three timed ones per level where they fit the time budget, at least one) + the predict products -- EXTRAPOLATED to the
-    evaluations the GPU run issued (`kind` says so; the measured and the extrapolated seconds are separate fields)."""
-    from oracle import gp_oracle as orc
+def _lapack_share(Ky, reps=2):
+    """dpotrf / dtrtri / dpotri (the O(N^3) part of one evaluation) on Ky, each on a FORTRAN-ordered operand prepared outside the
+    timer (f2py otherwise copies a C-ordered N^2 array inside the call), after one untimed call (thread pool, page faults), best
+    of `reps`, `info` checked -> seconds and GFLOP/s per routine"""
     from scipy.linalg import lapack
+    n = float(Ky.shape[0])
+    Kf = np.asfortranarray(Ky)
+    L, info = lapack.dpotrf(Kf, lower=1, clean=1, overwrite_a=0)        # (also the warm-up)
+    if info != 0:
+        return {"error": "dpotrf info = %d" % info}
+    L = np.asfortranarray(L)
+    out, total = {}, 0.0
+    for name, fn, flops in (("dpotrf", lambda: lapack.dpotrf(Kf, lower=1, clean=1, overwrite_a=0), n ** 3 / 3),
+                            ("dtrtri", lambda: lapack.dtrtri(L, lower=1, overwrite_c=0), n ** 3 / 3),
+                            ("dpotri", lambda: lapack.dpotri(L, lower=1, overwrite_c=0), 2 * n ** 3 / 3)):
+        best = np.inf
+        for rep in range(reps + (0 if name == "dpotrf" else 1)):         # dtrtri / dpotri: their first call is the warm-up
+            t0 = time.perf_counter()
+            res = fn()
+            dt = time.perf_counter() - t0
+            if res[-1] != 0:
+                return {"error": "%s info = %d" % (name, res[-1])}
+            if name == "dpotrf" or rep > 0:
+                best = min(best, dt)
+        out[name + "_s"] = round(best, 3)
+        out[name + "_gflops"] = round(flops / best / 1e9, 1)
+        total += best
+    out["gflops"] = round(n ** 3 * (4.0 / 3) / total / 1e9, 1)
+    out["note"] = "Fortran-ordered operands, one untimed call first, best of %d, info == 0 checked" % reps
+    return out
+
+
+def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=170.0):
+    """the oracle (numpy + LAPACK dpotrf / dtrtri / dpotri / dpotrs = the routines GPy calls) on the host cores of this
+    box, as BASELINE.md section 2 words it: per level ONE WARM-UP evaluation, then the best of (up to) three timed
+    objective+gradient evaluations at full size, + the predict products -- a bounded sample, EXTRAPOLATED to the evaluations
+    the GPU run issued (`kind` says so; the measured and the extrapolated seconds are separate fields)."""
+    from oracle import gp_oracle as orc
     X_lf, Y_lf, X_hf, X_st = data
     threads, tried = _pick_blas_threads()
     limiter = None
@@ -147,24 +181,22 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=45.0):
     blas = _blas_info()
     t_start = time.perf_counter()
 
-    def timed_evals(parts, th, nz, X, Y, share):
-        """-> (timed seconds per evaluation, state, warmed): one warm-up + best of up to 3 when the level's share of the
-        budget allows, otherwise the single evaluation that was affordable"""
-        t0 = time.perf_counter()
-        st = orc.inference(parts, th, nz, X, Y, want_grad=True)
-        first = time.perf_counter() - t0
-        if 2.0 * first > share:
-            return [first], st, False
+    def timed_evals(parts, th, nz, X, Y, deadline):
+        """-> (timed seconds per evaluation, state): one warm-up, then at least one and at most three timed evaluations (the
+        second and third only while the deadline allows)"""
+        st = orc.inference(parts, th, nz, X, Y, want_grad=True)             # warm-up: never timed
         ts = []
-        while len(ts) < 3 and (len(ts) + 2) * first <= share:
+        while len(ts) < 3:
             t0 = time.perf_counter()
             st = orc.inference(parts, th, nz, X, Y, want_grad=True)
             ts.append(time.perf_counter() - t0)
-        return ts, st, True
+            if time.perf_counter() + ts[-1] > deadline:
+                break
+        return ts, st
 
     parts_lf = [(orc.RBF, 0, 4, 0)]
     th_lf, nz_lf = np.array([1.0, 1.0]), 1.0
-    lf_ts, st_lf, lf_warm = timed_evals(parts_lf, th_lf, nz_lf, X_lf, Y_lf, 0.4 * budget_s)
+    lf_ts, st_lf = timed_evals(parts_lf, th_lf, nz_lf, X_lf, Y_lf, t_start + 0.45 * budget_s)
     t0 = time.perf_counter()
     aug_hf = orc.cov(parts_lf, th_lf, X_lf, X_hf).T.dot(st_lf["alpha"])      # LF posterior mean at X_hf and X* (mean only)
     aug_st = orc.cov(parts_lf, th_lf, X_lf, X_st).T.dot(st_lf["alpha"])
@@ -175,38 +207,33 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=45.0):
     th_hf = np.ones(6)
     Y_hf = hf_4d(X_hf)
     nz_hf = 0.01 * Y_hf.var()
-    hf_ts, st_hf, hf_warm = timed_evals(parts_hf, th_hf, nz_hf, Xa, Y_hf, budget_s - (time.perf_counter() - t_start))
+    hf_ts, st_hf = timed_evals(parts_hf, th_hf, nz_hf, Xa, Y_hf, t_start + 0.9 * budget_s)
     t0 = time.perf_counter()
     orc.predict(parts_hf, th_hf, nz_hf, Xa, st_hf, Xsa)
     hf_predict_s = time.perf_counter() - t0
     # how much of one evaluation is LAPACK (the O(N^3) part) and at what rate this host runs it
-    Ky = st_hf["K"] + (nz_hf + 1e-8) * np.eye(len(Xa))
-    lap = {}
-    for name, fn in (("dpotrf", lambda: lapack.dpotrf(Ky, lower=1)), ("dtrtri", lambda: lapack.dtrtri(st_hf["L"], lower=1)),
-                     ("dpotri", lambda: lapack.dpotri(st_hf["L"], lower=1))):
-        t0 = time.perf_counter()
-        fn()
-        lap[name + "_s"] = round(time.perf_counter() - t0, 3)
-    n = float(len(Xa))
-    lap["gflops"] = round((n ** 3) * (1.0 / 3 + 1.0 / 3 + 2.0 / 3) / max(sum(v for k, v in lap.items() if k.endswith("_s")), 1e-9) / 1e9, 1)
+    lap = _lapack_share(st_hf["K"] + (nz_hf + 1e-8) * np.eye(len(Xa)))
     measured = time.perf_counter() - t_start
     if limiter is not None:
         limiter.restore_original_limits()
     lf_eval_s, hf_eval_s = min(lf_ts), min(hf_ts)
+    if "error" not in lap:
+        lap["seconds_of_one_hf_eval"] = round(lap["dpotrf_s"] + lap["dtrtri_s"] + lap["dpotri_s"], 3)
+        lap["share_of_one_hf_eval"] = round(lap["seconds_of_one_hf_eval"] / hf_eval_s, 3)
     total_s = n_lf_evals * lf_eval_s + n_hf_evals * hf_eval_s + lf_means_s + hf_predict_s
     return {"value": round(total_s * 1e3, 1), "unit": "ms", "cores": int(blas["threads"]), "kind": "port-extrapolated",
             "blas": blas, "blas_threads_tried_gflops": tried, "measured_s": round(measured, 2),
             "extrapolated_s": round(total_s, 1),
             "lf_eval_s": [round(t, 2) for t in lf_ts], "hf_eval_s": [round(t, 2) for t in hf_ts],
-            "warmed_up": {"lf": lf_warm, "hf": hf_warm},
+            "warmed_up": {"lf": True, "hf": True},
             "lf_means_s": round(lf_means_s, 2), "hf_predict_s": round(hf_predict_s, 2), "lapack_share_of_one_hf_eval": lap,
             "sample": "oracle (numpy + LAPACK, the GPy algorithm) at full size on this host with %d BLAS threads (best of %s "
-                      "GFLOP/s on a 3072^2 dpotrf + dpotri): %d LF and %d HF objective+gradient evaluations timed%s (best %.2f s / "
-                      "%.2f s), LF means %.2f s, HF predict %.2f s = %.1f s measured; value = those times EXTRAPOLATED to the "
-                      "%d LF + %d HF evaluations the GPU run issued + the predicts"
-                      % (int(blas["threads"]), tried, len(lf_ts), len(hf_ts),
-                         " after a warm-up" if (lf_warm and hf_warm) else " (no warm-up fitted the budget where the list has one entry)",
-                         lf_eval_s, hf_eval_s, lf_means_s, hf_predict_s, measured, n_lf_evals, n_hf_evals)}
+                      "GFLOP/s on a 4096^2 dpotrf + dpotri): per level one untimed warm-up evaluation, then %d LF and %d HF "
+                      "objective+gradient evaluations timed after a warm-up (best %.2f s / %.2f s), LF means %.2f s, HF predict "
+                      "%.2f s = %.1f s measured; value = those times EXTRAPOLATED to the %d LF + %d HF evaluations the GPU run "
+                      "issued + the predicts"
+                      % (int(blas["threads"]), tried, len(lf_ts), len(hf_ts), lf_eval_s, hf_eval_s, lf_means_s, hf_predict_s,
+                         measured, n_lf_evals, n_hf_evals)}
 
 
 PMC_FILE = os.path.join("profiles", "r03_pmc.json")

@@ -118,11 +118,23 @@ int32_t mfgp_set_kernel(mfgp_handle* h, const mfgp_kern_part* parts, int32_t n_p
  * (ExactGaussianInference.inference behind src/abstractMFGP.py:103,132-137; src/MFDataFusion.py:93-100):
  *   Ky = K(theta) + (noise + jitter) I ; L = chol(Ky) ; alpha = Ky^-1 y ; logdet ;
  *   nlml = 0.5*(N log 2pi + logdet + y^T alpha) ;
- *   want_grad: grad[2f], grad[2f+1] = dNLML/d variance_f, d lengthscale_f ; grad[2*n_parts] = dNLML/d noise.
- * theta has 2*n_parts entries.  GPy adds 1e-8 to the diagonal itself; pass it (plus any jitchol
+ *   want_grad: grad[0 .. P) = dNLML/d theta in theta's own layout (mfgp_kern_part above: per factor its variance, then its
+ *   lengthscale(s)); grad[P] = dNLML/d noise -- P + 1 doubles, P = mfgp_num_params().
+ * theta has P entries.  GPy adds 1e-8 to the diagonal itself; pass it (plus any jitchol
  * retry jitter) as `jitter`.  Returns >0 (pivot index) when Ky is not positive definite. */
 int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitter,
                   int32_t want_grad, double* nlml, double* grad);
+
+/* B evaluations of mfgp_eval at once: the same data and kernel structure at B hyper-parameter points -- what the independent
+ * restarts of optimize_restarts(6, ...) (src/abstractMFGP.py:137) ask for between them, one evaluation per run and round.
+ * thetas is (B, P) row-major, noises / jitters are (B); nlml (B), grads (B, P + 1) row-major (may be NULL when want_grad == 0),
+ * status (B): 0, or the pivot index of an evaluation whose Ky is not positive definite (its nlml / gradient are then
+ * undefined; the others are unaffected).  The return value covers the call as a whole (0, or < 0 for an argument / HIP error).
+ * One pass of the factorisation plan carries the B matrix sets side by side (1 <= B <= 16; 4 Np^2 doubles of device memory
+ * per set, kept by the handle), each evaluation's arithmetic is mfgp_eval's tile for tile: results are bitwise those of B
+ * mfgp_eval calls.  The handle's own factorisation (what mfgp_predict / mfgp_nlml read) is left untouched. */
+int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const double* noises, const double* jitters,
+                        int32_t want_grad, double* nlml, double* grads, int32_t* status);
 
 /* Row-block form of the K build for the multi-GPU layout of SURVEY 8(e3) / north_star: each rank builds rows
  * [row_begin, row_end) (multiples of 64, within the padded size) of Ky = K + (noise+jitter) I -- all columns --
@@ -205,7 +217,8 @@ int32_t mfgp_device_synchronize(mfgp_handle* h);
 
 /* ---- kernel-level test hooks (tests/ only) -------------------------------------------------------- */
 /* C = alpha * A B^T + beta * C on Mp x Np x Kp host matrices (multiples of 128) through the MFMA
- * tile-GEMM kernel; tile = 128 or 64, -64 for the serial-chain variant of the 64-tile kernel, 32 for the 32x32 chain kernel. */
+ * tile-GEMM kernel; tile = 128 or 64, -64 for the serial-chain variant of the 64-tile kernel, 32 for the 32x32 chain kernel.
+ * Any other tile is reported as an error (status < 0): the library never terminates the host process. */
 int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, double* C, int32_t M,
                          int32_t N, int32_t K, double alpha, double beta, int32_t tile);
 /* Cholesky + inverse of one SPD 128x128 block through the leaf kernel: Lout, Xout are 128x128. */

@@ -25,7 +25,7 @@ def num_params(parts):
 # every symbol include/mfgp.h declares (tests check the .so exports each of them)
 EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
-    "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
+    "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_eval_batch", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters", "mfgp_device_synchronize",
@@ -110,6 +110,7 @@ def load_library(path=None):
         "mfgp_set_kernel": (i32, [H, ctypes.POINTER(KernPart), i32]),
         "mfgp_num_params": (i32, [ctypes.POINTER(KernPart), i32]),
         "mfgp_eval": (i32, [H, dp, f64, f64, i32, dp, dp]),
+        "mfgp_eval_batch": (i32, [H, i32, dp, dp, dp, i32, dp, dp, ctypes.POINTER(i32)]),
         "mfgp_kbuild_rows": (i32, [H, dp, f64, f64, i64, i64]),
         "mfgp_dev_matrix": (i32, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(i64)]),
         "mfgp_eval_prebuilt": (i32, [H, i32, dp, dp]),
@@ -246,6 +247,27 @@ class Engine:
                                  ctypes.byref(nlml), _dptr(grad))
         self._check(rc, "mfgp_eval")
         return (nlml.value, grad) if want_grad else nlml.value
+
+    MAX_BATCH = 16
+
+    def eval_batch(self, thetas, noises, jitters=1e-8, want_grad=True):
+        """B evaluations at once (mfgp_eval_batch): thetas (B, P), noises (B,), jitters (B,) or one value ->
+        (nlml (B,), grads (B, P + 1) or None, status (B,) int: 0 or the failed pivot's index).  Bitwise the results of B eval()
+        calls; the handle's own factorisation is left alone."""
+        thetas = _c64(thetas)
+        if thetas.ndim != 2 or thetas.shape[1] != self.n_params:
+            raise ValueError("thetas must be (B, %d)" % self.n_params)
+        B = thetas.shape[0]
+        noises = _c64(np.broadcast_to(np.asarray(noises, dtype=np.float64), (B,)))
+        jitters = _c64(np.broadcast_to(np.asarray(jitters, dtype=np.float64), (B,)))
+        nlml = np.empty(B)
+        grads = np.zeros((B, self.n_params + 1)) if want_grad else None
+        status = np.zeros(B, dtype=np.int32)
+        rc = self._lib.mfgp_eval_batch(self._h, B, _dptr(thetas), _dptr(noises), _dptr(jitters), int(bool(want_grad)),
+                                       _dptr(nlml), _dptr(grads) if want_grad else None,
+                                       status.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        self._check(rc, "mfgp_eval_batch")
+        return nlml, grads, status
 
     # -- row-block K build + all-gather (multi-GPU layout of SURVEY 8(e3)) ---------------------------
     def _theta(self, theta):

@@ -36,6 +36,13 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     lf_max_iters = 1000         # lf_model.optimize() default budget (src/abstractMFGP.py:103)
     eval_cap = None             # hard cap on objective evaluations per L-BFGS-B run (benchmarks: exact budgets)
     restart_concurrency = 1     # 1: the reference's sequential order (the default: this layer then drives the engine call for call like the reference); >1: that many randomized restarts run concurrently with the first run / restart 0 -- same runs, same winner, 1.7-2 x faster fits at N = 256 .. 2048 (tools/midsize_fit.py)
+    restart_lockstep = True     # the 1 + num_restarts runs of a fit as LOCK-STEPPED runs on one engine handle: every round one
+                                # batched pass evaluates all of them (engine.LockstepEvaluator, mfgp_eval_batch) -- same runs, same
+                                # steps bit for bit, same winner; takes precedence over restart_concurrency where the engine has
+                                # eval_batch (the HIP engine has; a double without it gets the reference's sequential order)
+    lockstep_width = None       # live slots per round (None: half this rank's runs, rounded up -- 4 for the recipe's 1 + 6 runs: the
+                                # sequential pair first run -> restart 0 in one slot, the five randomized restarts 2 + 2 + 1 in three
+                                # more, so every round carries 3-4 evaluations instead of 6 for one half of the fit and 1 for the other)
     restart_lend_main = False   # the main engine joins the restarts' pool once its sequential runs are through
     restart_aux = None          # auxiliary engine handles of the concurrent restarts (None: restart_concurrency of them)
     diagonal_points = 1000      # resolution of the box diagonal the adaptation loop predicts on every step (:318)
@@ -197,6 +204,9 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         N(0,1) draws and so do not depend on the first run) execute on auxiliary engine handles in background
         threads WHILE the main thread does the first run and restart 0; same runs, same winner rule."""
         self._pin_noise(model)
+        if self.restart_lockstep and num_restarts >= 2 and hasattr(model._engine, "eval_batch"):
+            self._ard_lockstep(model, num_restarts)
+            return
         if int(self.restart_concurrency) <= 1:
             model.optimize(max_iters=self.first_run_max_iters)
             self._free_noise(model)
@@ -204,6 +214,50 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
                                     rand_gen=self._restart_rng(), comm=self.comm)
             return
         self._ard_concurrent(model, num_restarts, int(self.restart_concurrency))
+
+    def _ard_lockstep(self, model, num_restarts):
+        """The recipe's runs in lock step on the model's own engine handle.  Slot 0 (rank 0 only) is the sequential piece --
+        first run (noise pinned), then restart 0, which continues from it -- the other slots are this rank's randomized
+        restarts (as in _ard_concurrent: `assign_restarts`); every round is one batched pass over the live slots."""
+        rank, size = self.comm.rank, self.comm.size
+        mine_bg = self.assign_restarts(num_restarts, size)[rank]
+        own = 1 if rank == 0 else 0
+        n_runs = len(mine_bg) + 2 * own
+        width = int(self.lockstep_width) if self.lockstep_width else (n_runs + 1) // 2
+        n_bg_slots = min(len(mine_bg), max(width - own, 1 if mine_bg else 0))
+        n_slots = n_bg_slots + own
+        lockstep = gp.LockstepEvaluator(model._engine, n_slots) if n_slots else None
+        handle = None
+        if mine_bg:
+            handle = model.start_lockstep_restarts(mine_bg, lockstep, slots=list(range(1, n_bg_slots + 1)),
+                                                   free=list(model.parameters()),      # all free during the restarts
+                                                   rand_gen=self._restart_rng(), max_iters=self.restart_max_iters)
+        runs = []
+        try:
+            if rank == 0:
+                model._eval_hook = lambda th, nz, jit: lockstep.evaluate(0, th, nz, jit)
+                model.optimize(max_iters=self.first_run_max_iters)
+            self._free_noise(model)
+            if rank == 0:
+                r0 = model.optimize(max_iters=self.restart_max_iters)   # restart 0 continues from the current point
+                if r0 is not None:
+                    runs.append((r0.f_opt, r0.x_opt, 0))
+        finally:
+            if rank == 0:
+                lockstep.retire(0)
+                model._eval_hook = None
+                model._dirty = True        # the handle's own factorisation was never at the points the batches evaluated
+                model._have_grad = False
+        if handle is not None:
+            runs += handle.result()
+        self.last_lockstep = lockstep
+        if size > 1:
+            runs = [r for part in self.comm.allgather_object(runs) for r in part]
+        if runs:
+            best = min(runs, key=lambda r: (r[0], r[2]))
+            model.optimizer_array = best[1]
+        elif size > 1:
+            model.optimizer_array = self.comm.bcast_object(model.optimizer_array if rank == 0 else None, src=0)
 
     def _ard_concurrent(self, model, num_restarts, conc):
         # Rank 0 owns the only sequential piece (first run -> restart 0, which continues from it); the randomized

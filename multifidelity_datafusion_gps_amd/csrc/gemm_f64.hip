@@ -25,19 +25,13 @@
 // 16-byte-chunk XOR swizzle (chunk ^= row & 15) so that the MFMA fragment reads (16 rows x 2 k per
 // 32-lane group, ds_read_b64) are bank-conflict free without padding -> MFMA.  LDS is double
 // buffered: the global loads of K-step t+1 are in flight while step t is on the matrix cores.
-#include <cstdio>
-#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include "mfgp_internal.h"
 
 namespace mfgp {
 
-#ifndef MFGP_MFMA_444
-#define MFGP_MFMA_444 1   // 0: the v_mfma_f64_16x16x4 body of rounds 1-2 (kept for A/B measurements and cross-checks)
-#endif
-
-template <int BM, int BN, int WM, int WN, int NBUF = 2, int KT = BK, int AH = 0>   // AH > 0: register-lean form, AH A row blocks held at once
+template <int BM, int BN, int WM, int WN, int NBUF = 2, int KT = BK>
 __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, const double* B, double* C, double* C2,
                                              int ld) {
     constexpr int NT = 64 * WM * WN;      // threads per workgroup (wave grid WM x WN)
@@ -67,14 +61,10 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
     const int a_lo_shift = t.klen - BM, b_lo_shift = t.klen - BN;
 
     d2_t ra[NA], rb[NBC];
-#if MFGP_MFMA_444
     // acc[mi][ni][s]: rotation s of the 16x16 block (mi, ni); this lane's element is
     //   row 16 mi + 4 ((cb + s) & 3) + q,  column 16 ni + fr      (q = lane >> 4, cb = (lane >> 2) & 3, fr = lane & 15)
     double acc[TM][TN][4];
     const int cb = (lane >> 2) & 3;
-#else
-    d4_t acc[TM][TN];
-#endif
     // Accumulating tasks (beta != 0: the trailing updates C -= A B^T) start from the output tile itself: acc = (beta/alpha) C is
     // loaded HERE, its latency hidden behind the first operand loads, instead of a read-modify-write epilogue that every
     // workgroup pays exposed at the end (a 128x128 tile is 128 KB in and 128 KB out at ~25 GB/s per CU: ~5 us each way
@@ -89,11 +79,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
             if (preload) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#if MFGP_MFMA_444
                     const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb + r) & 3) + q;
-#else
-                    const int row = wm * (BM / WM) + mi * 16 + q + 4 * r;
-#endif
                     const int col = wn * (BN / WN) + ni * 16 + fr;
                     acc[mi][ni][r] = c_scale * Cp[(int64_t)row * ld + col];
                 }
@@ -107,20 +93,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
     // (task-uniform flags; most tasks carry none) are applied when the registers are written to LDS, after the compute
     // phase.  (Rounds 1-2 masked right after the load: every K-step then waited for its NEXT operands before it started.)
     const bool any_mask = (t.flags & (TF_A_LOWER | TF_A_UPPER | TF_B_LOWER | TF_B_UPPER)) != 0;
-    // register-lean form: ONE 32-bit lane offset shared by both operands on top of the task-uniform (scalar) bases instead of
-    // a 64-bit lane pointer per 16-byte load
-    const unsigned lane_off = (unsigned)(tid / CPR) * (unsigned)ld + 2u * (unsigned)(tid % CPR);
     auto load_tiles = [&](int kt) {
-        if constexpr (AH > 0) {
-            static_assert(NT % CPR == 0, "a thread's chunks must share one column slot");
-#pragma unroll
-            for (int u = 0; u < NA; ++u)
-                ra[u] = *reinterpret_cast<const d2_t*>(Ap + (lane_off + (unsigned)((NT / CPR) * u * ld + kt * KT)));
-#pragma unroll
-            for (int u = 0; u < NBC; ++u)
-                rb[u] = *reinterpret_cast<const d2_t*>(Bp + (lane_off + (unsigned)((NT / CPR) * u * ld + kt * KT)));
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int g = tid + NT * u;
@@ -185,7 +158,6 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
             *reinterpret_cast<d2_t*>(bs + row * KT + ((c ^ (row & SWM)) << 1)) = rb[u];
         }
     };
-#if MFGP_MFMA_444
     auto compute = [&](int buf) {
         const double* as = As + buf * (BM * KT) + (wm * (BM / WM)) * KT;
         const double* bs = Bs + buf * (BN * KT) + (wn * (BN / WN) + fr) * KT;
@@ -194,47 +166,6 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
         // a step's four k-slots are then columns 8 g + {0, 2, 4, 6} (resp. {1, 3, 5, 7}), the same for both operands.
         // (Bank check, ds_read_b128 lane groups {0-3,12-15,20-27} ...: 8 lanes of slot q on rows R, 8 of slot q + 1 on the
         // complement of R mod 16; chunk ^ row maps them to 16 distinct 16-byte slots for KT = 32 and for KT = 16.)
-        if constexpr (AH > 0) {
-            // register-lean form (the 4-wave chain kernel: 96 VGPRs in all): the 8-column groups are NOT unrolled -- one set of
-            // fragment addresses, group g reached by flipping byte-offset bit 6 (chunk (4 g + q) ^ s = (q ^ s) ^ 4 g) -- and
-            // the A fragments are taken AH row blocks at a time
-            int a_ad[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = (fr + 4 * r) & 15;
-                a_ad[r] = (row * KT + ((q ^ (row & SWM)) << 1)) * 8;
-            }
-            const int b_ad = ((q ^ (fr & SWM)) << 1) * 8;
-            const char* asb = reinterpret_cast<const char*>(as);
-            const char* bsb = reinterpret_cast<const char*>(bs);
-#pragma unroll 1
-            for (int g = 0; g < KT / 8; ++g) {
-                const int gx = g << 6;
-                d2_t b[TN];
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const d2_t*>(bsb + ni * 16 * KT * 8 + (b_ad ^ gx));
-#pragma unroll
-                for (int m0 = 0; m0 < TM; m0 += AH) {
-                    d2_t a[AH][4];
-#pragma unroll
-                    for (int mi = 0; mi < AH; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            a[mi][r] = *reinterpret_cast<const d2_t*>(asb + (m0 + mi) * 16 * KT * 8 + (a_ad[r] ^ gx));
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int mi = 0; mi < AH; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    acc[m0 + mi][ni][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[mi][r][h], b[ni][h],
-                                                                                             acc[m0 + mi][ni][r], 0, 0, 0);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int g = 0; g < KT / 8; ++g) {
             d2_t a[TM][4], b[TN];
@@ -259,27 +190,6 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
                             acc[mi][ni][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[mi][r][h], b[ni][h], acc[mi][ni][r], 0, 0, 0);
         }
     };
-#else
-    auto compute = [&](int buf) {
-        const double* as = As + buf * (BM * KT) + (wm * (BM / WM) + fr) * KT + (q & 1);
-        const double* bs = Bs + buf * (BN * KT) + (wn * (BN / WN) + fr) * KT + (q & 1);
-#pragma unroll
-        for (int kk = 0; kk < KT / 4; ++kk) {
-            // lane (fr, q) supplies element [row fr][k = 4*kk + q]: 16-byte chunk 2*kk + (q>>1), half q&1
-            const int sw = ((2 * kk + (q >> 1)) ^ (fr & SWM)) << 1;
-            double a[TM], b[TN];
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) a[mi] = as[mi * 16 * KT + sw];
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) b[ni] = bs[ni * 16 * KT + sw];
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-    };
-#endif
 
     load_tiles(0);
     store_tiles(0, 0);
@@ -309,7 +219,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
         }
     }
 
-    // epilogue.  v_mfma_f64_16x16x4 C/D layout: D[row = q + 4*reg][col = fr]; the 4x4x4 form: see acc above
+    // epilogue (this lane's elements: see acc above)
     const double alpha = t.alpha;
     const bool mirror = (t.c2_off >= 0);
     double* C2p = C2 + (mirror ? t.c2_off : 0);
@@ -319,11 +229,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmTask t, const double* A, 
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#if MFGP_MFMA_444
                 const int row = wm * (BM / WM) + mi * 16 + 4 * ((cb + r) & 3) + q;
-#else
-                const int row = wm * (BM / WM) + mi * 16 + q + 4 * r;
-#endif
                 const int col = wn * (BN / WN) + ni * 16 + fr;
                 const double v = alpha * acc[mi][ni][r];
                 Cp[(int64_t)row * ld + col] = v;
@@ -556,16 +462,22 @@ constexpr int GEMM_THREADS = 64 * GW_M * GW_N;
 // two bulk waves per SIMD must leave 64 VGPRs (of 512) for a wave of the chain's kernels: see gemm_nt_dma's `group`
 constexpr int BULK_THREADS = 256;                 // bulk tile kernels: 4 waves (2 x 2), two workgroups per CU (gemm_nt_dma)    // the fp64 MFMA pipe busy (probe: 140 vs ~103 cycles per MFMA)
 
+// Batched evaluations (mfgp_eval_batch): blockIdx.y = b selects matrix set b, `bstride` elements further on in the handle's batch
+// slab -- the same task list serves every set (all four operand bases move by the same offset); a single evaluation is the
+// launch with gridDim.y = 1.  Workgroups are dispatched x-fastest, so set b's tasks keep their XCD-aware order among themselves.
+//
 // Named entry points over the same tile body, so that a kernel trace separates the roles:
 //   mfgp_gemm_nt_f64_t128 / _t64 : the many launches of the recursive Cholesky + inverse
 //   mfgp_kinv_syrk_f64           : the ONE launch per evaluation that forms K^-1 = L^-T L^-1 (N^3/3 flops)
 //   mfgp_predvar_f64             : the predictive-variance product V = K(X*,X) L^-T
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_gemm_nt_f64_t128(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld) {
+        const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<128, 128, 2, 2, 16, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_gemm_nt_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld) {
+        const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<64, 64, 2, 2, 32, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 // chain variant: the GEMM steps on the serial Cholesky chain (panel, column update).  16 KB of LDS (one buffer, K-steps of
@@ -573,18 +485,10 @@ __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_gemm_nt_f64_t64(const Ge
 // other stream (160 KB per CU, allocated in 1280-byte granules: 32 KB would miss by 768 bytes) instead of waiting
 // ~60 us for one to retire; raised wave priority so its MFMAs issue first.
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_chain(const GemmTask* __restrict__ tasks, const double* A,
-                                                                 const double* B, double* C, double* C2, int ld) {
+                                                                 const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     __builtin_amdgcn_s_setprio(3);
     gemm_nt_tile<64, 64, GW_M, GW_N, 1, 16>(tasks[blockIdx.x], A, B, C, C2, ld);
-}
-// 4-wave form of the 64-tile chain step (round 3, role 6): 2 x 2 waves of 32 x 32, at most 96 VGPRs and 16 KB of LDS, so that ONE
-// such workgroup fits on a CU beside TWO resident bulk workgroups (2 x 208 of the 512 VGPRs per SIMD lane, 2 x 52 of the 128
-// LDS granules) instead of waiting for one of them to retire: the 8-wave form needs 2 x 80 VGPRs per SIMD and its launches
-// stretch from 15-25 us to 100-160 us right after a bulk launch filled the CUs (profiles/r03_timeline_8192.txt).
-__global__ __launch_bounds__(256, 5) void mfgp_gemm_nt_f64_chain4(const GemmTask* __restrict__ tasks, const double* A,
-                                                         const double* B, double* C, double* C2, int ld) {
-    __builtin_amdgcn_s_setprio(3);
-    gemm_nt_tile<64, 64, 2, 2, 1, 16, 1>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 // 32x32 chain variant: 4 waves (2 x 2, one MFMA block each), 16 KB of LDS, K-steps of 32 -- the chain's panel / in-macro update
 // launches at chain-bound sizes (planner: MFGP_CHAIN_TILE).  Those launches are latency-bound (a 64x64x128 tile is 128 MFMAs
@@ -592,35 +496,42 @@ __global__ __launch_bounds__(256, 5) void mfgp_gemm_nt_f64_chain4(const GemmTask
 // K-steps: panel launch 12 -> 9.5 us, in-macro update 13-20 -> 10-17 us (N = 4096), one evaluation at N = 2048 1.20 -> 1.03 ms.
 // (Measured beside it: K-steps of 16, single- and double-buffered: 1.07 / 1.08 ms.)
 __global__ __launch_bounds__(256, 5) void mfgp_gemm_nt_f64_chain32(const GemmTask* __restrict__ tasks, const double* A,
-                                                          const double* B, double* C, double* C2, int ld) {
+                                                          const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     __builtin_amdgcn_s_setprio(3);
     gemm_nt_tile<32, 32, 2, 2, 1, 32>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_kinv_syrk_f64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld) {
+        const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<128, 128, 2, 2, 16, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_kinv_syrk_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld) {
+        const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<64, 64, 2, 2, 32, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_predvar_f64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld) {
+        const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<128, 128, 2, 2, 16, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_predvar_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld) {
+        const double* B, double* C, double* C2, int ld, long long bstride) {
+    A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<64, 64, 2, 2, 32, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 
 // bulk kernels: two stages of (tile + tile) rows x 16 columns (128-tiles) or x 32 columns (64-tiles): 64 KB / 32 KB
 size_t gemm_lds_bytes(int tile) { return (size_t)2 * (tile + tile) * (tile == 128 ? 16 : 32) * sizeof(double); }
 
-typedef void (*gemm_kernel_t)(const GemmTask*, const double*, const double*, double*, double*, int);
+typedef void (*gemm_kernel_t)(const GemmTask*, const double*, const double*, double*, double*, int, long long);
 
-void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
-                 const double* B, double* C, double* C2, int ld, int role) {
-    if (ntasks <= 0) return;
+// -> 0, or -1 when the planner asked for a (tile, role) pair no kernel exists for (a planner bug: reported through the
+// C-ABI's status like every other error, never by terminating the host process)
+int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
+                const double* B, double* C, double* C2, int ld, int role, int nbatch, long long bstride) {
+    if (ntasks <= 0) return 0;
     static const gemm_kernel_t table[3][2] = {{mfgp_gemm_nt_f64_t128, mfgp_gemm_nt_f64_t64},
                                               {mfgp_kinv_syrk_f64, mfgp_kinv_syrk_f64_t64},
                                               {mfgp_predvar_f64, mfgp_predvar_f64_t64}};
@@ -636,30 +547,24 @@ void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, con
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)gemm_lds_bytes(t == 0 ? 128 : 64));
     });
+    const dim3 grid(ntasks, nbatch > 0 ? nbatch : 1);
     if (tile == 32) {                // chain step at chain-bound sizes: 32x32 tiles, 4 waves, 16 KB
-        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain32, dim3(ntasks), dim3(256), (size_t)(32 + 32) * 32 * sizeof(double), s, tasks, A, B,
-                           C, C2, ld);
-        return;
-    }
-    if (role == 6 && tile == 64) {   // serial-chain step, 4-wave form: co-resident with TWO bulk workgroups per CU
-        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain4, dim3(ntasks), dim3(256), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
-                           C, C2, ld);
-        return;
+        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain32, grid, dim3(256), (size_t)(32 + 32) * 32 * sizeof(double), s, tasks, A, B,
+                           C, C2, ld, bstride);
+        return 0;
     }
     if (role == 3 && tile == 64) {   // serial-chain step: slim workgroups that co-reside with the bulk update
-        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain, dim3(ntasks), dim3(GEMM_THREADS), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
-                           C, C2, ld);
-        return;
+        hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain, grid, dim3(GEMM_THREADS), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
+                           C, C2, ld, bstride);
+        return 0;
     }
     // roles: 0 bulk, 1 K^-1, 2 predictive variance (distinct symbols over one body); 3 = a chain step -- only its 64-tile
     // form is a kernel of its own (above), a 128-tile chain step runs the bulk kernel; 5 = the 32-tile chain step (handled
-    // by tile == 32 above); 6 = the 4-wave 64-tile chain step (above; as a 128-tile step it runs the bulk kernel).  Anything else is a planner bug: fail loudly instead of indexing past the table.
-    if ((tile != 128 && tile != 64) || role < 0 || (role > 3 && role != 5 && role != 6)) {
-        fprintf(stderr, "mfgp: launch_gemm: no kernel for tile %d, role %d\n", tile, role);
-        abort();
-    }
+    // by tile == 32 above)
+    if ((tile != 128 && tile != 64) || role < 0 || (role > 3 && role != 5)) return -1;
     const gemm_kernel_t k = table[role >= 3 ? 0 : role][tile == 128 ? 0 : 1];
-    hipLaunchKernelGGL(k, dim3(ntasks), dim3(BULK_THREADS), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld);
+    hipLaunchKernelGGL(k, grid, dim3(BULK_THREADS), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld, bstride);
+    return 0;
 }
 
 // ---- skinny predictive-variance product (N* <= 64 rows: the DIRECT callback / acquisition case) -----

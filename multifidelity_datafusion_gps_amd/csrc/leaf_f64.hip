@@ -141,59 +141,11 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
     if (bad != 0 && lane == 0 && *info == 0) *info = pivot0 + __ffsll((long long)bad);
 }
 
-// 16x16x16 block products.  MFGP_LEAF_444 = 1: on v_mfma_f64_4x4x4_4b_f64 (the shape the tile GEMM moved to in round 3);
-// 0 (default): four v_mfma_f64_16x16x4 on one accumulator, as in rounds 1-2.  MEASURED (round 3, profiles/r03_plan_ab.txt): the
-// 4x4x4 form makes the leaf SLOWER, 27 -> 36 us alone -- the block products are not what bounds the leaf: wave 0's
-// micro-Cholesky is, it shares SIMD 0 with a worker wave, and four times as many MFMA issues on that SIMD stretch its VALU
-// chain ("a latency-critical VALU chain must not share a SIMD with MFMA-bound waves").  Kept for the record.
-#ifndef MFGP_LEAF_444
-#define MFGP_LEAF_444 0
-#endif
-//
-// The 4x4x4 form:  The 4x4x4 form multiplies the four block diagonals of a 16x16x4 product (gemm_f64.hip has
-// the measurement and the layout); with the A fragment read in its four row rotations a block product is four INDEPENDENT
-// chains of four 16-cycle instructions, interleaved.  Lane (q = lane >> 4, cb = (lane >> 2) & 3, fr = lane & 15) supplies
-// A[(fr + 4 r) & 15][k = 4 s + q] for rotation r and B^T[fr][k], and owns C[4 ((cb + r) & 3) + q][fr] of rotation r.
-// (Pitch-130 rows: the rotation only permutes rows among the lanes of a 32-lane group, the reads stay conflict-free.)
-__device__ __forceinline__ double mfma444(double a, double b, double c) {
-    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
+// 16x16x16 block products: four v_mfma_f64_16x16x4 on one accumulator.  (The v_mfma_f64_4x4x4_4b form the tile GEMM moved to in
+// round 3 makes the leaf SLOWER, 27 -> 36 us alone: the block products are not what bounds the leaf -- wave 0's micro-Cholesky is,
+// it shares SIMD 0 with a worker wave, and four times as many MFMA issues on that SIMD stretch its VALU chain.  Retired:
+// tools/gemm_lab/RETIRED.md.)
 
-#if MFGP_LEAF_444
-// rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
-template <int YP = LP>
-__device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const int cb = (fr >> 2) & 3;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const double bv = Y[fr * YP + 4 * s + q];   // B[k][n] = Y[n][k]
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[r] = mfma444(sL[(ib * 16 + ((fr + 4 * r) & 15)) * LP + jb * 16 + 4 * s + q], bv, acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sL[(ib * 16 + 4 * ((cb + r) & 3) + q) * LP + jb * 16 + fr] = acc[r];
-}
-
-// C[ib][kb] -= L[ib][jb] L[kb][jb]^T on 16x16 blocks of the LDS matrix
-__device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb, int fr, int q) {
-    double acc[4];
-    const int cb = (fr >> 2) & 3;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = sL[(ib * 16 + 4 * ((cb + r) & 3) + q) * LP + kb * 16 + fr];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const double bv = sL[(kb * 16 + fr) * LP + jb * 16 + 4 * s + q];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[r] = mfma444(-sL[(ib * 16 + ((fr + 4 * r) & 15)) * LP + jb * 16 + 4 * s + q], bv, acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sL[(ib * 16 + 4 * ((cb + r) & 3) + q) * LP + kb * 16 + fr] = acc[r];
-}
-
-#else
 // rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
 template <int YP = LP>
 __device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
@@ -223,7 +175,6 @@ __device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb,
     for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + kb * 16 + fr] = acc[r];
 }
 
-#endif
 
 // ---- leaf v3: the inverse rides on the factorisation --------------------------------------------------------------------
 // Same block-in-LDS, 16-column-panel factorisation as v2, but the inverse is no longer a second phase: it is produced by
@@ -239,23 +190,6 @@ constexpr int SY_SIZE = 2 * 16 * YP16;       // TWO of them (panel jb's, and the
                                              // panel jb's solves, first touches and output are through -- 138 KB of LDS in all, so
                                              // that a 16 KB chain workgroup of another evaluation still fits on the CU beside the leaf
 
-#if MFGP_LEAF_444
-// first touch of row jb of B:  B[jb, J] = -Y_jj^T L[J, jb]^T
-__device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb, int J, int fr, int q) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const int cb = (fr >> 2) & 3;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const double bv = sL[(J * 16 + fr) * LP + jb * 16 + 4 * s + q];      // B[k][n = fr] = L[J*16 + fr][jb*16 + k]
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[r] = mfma444(-Y[(4 * s + q) * YP16 + ((fr + 4 * r) & 15)], bv, acc[r]);   // A[row][k] = Y^T[row][k] = Y[k][row]
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sL[(jb * 16 + 4 * ((cb + r) & 3) + q) * LP + J * 16 + fr] = acc[r];
-}
-
-#else
 // first touch of row jb of B:  B[jb, J] = -Y_jj^T L[J, jb]^T
 __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb, int J, int fr, int q) {
     d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -269,10 +203,9 @@ __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb
     for (int r = 0; r < 4; ++r) sL[(jb * 16 + q + 4 * r) * LP + J * 16 + fr] = acc[r];
 }
 
-#endif
 
 __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restrict__ A, double* Lout, double* S, int ld, int blk,
-                                             double* logdet_part, int* info, unsigned long long* stamps) {
+                                             double* logdet_part, int* info) {
     double* sL = smem;                       // 128 x LP: lower = A -> L, strictly upper 16-blocks = B -> X^T
     double* sY = smem + 128 * LP;            // 2 x (16 x YP16): Y_jj = L_jj^-1, slot jb & 1
     double* sc = sY + SY_SIZE;               // scratch
@@ -283,8 +216,6 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
     const int fr = lane & 15;
     const int q = lane >> 4;
     const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;  // offset of the diagonal block
-#define STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-    STAMP(0);
     // load: only the 16-blocks on and below the diagonal (the upper part of the input is never used: that triangle of the
     // LDS block holds B).  Wave 0 takes the first diagonal tile alone and starts its micro-Cholesky at once, the other seven
     // waves bring in the remaining 35 tiles meanwhile.
@@ -300,7 +231,6 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             const int e = lane + 64 * u;
             *reinterpret_cast<d2_t*>(sL + (e >> 3) * LP + 2 * (e & 7)) = v[u];
         }
-        STAMP(1);
         micro_chol16<YP16>(sL, sY, lane, info, blk * NB, sc + 16);    // (same wave wrote the tile: LDS program order suffices)
     } else {
         // the 35 other tiles of the lower block triangle (tile tl = I(I+1)/2 + J, J <= I), 128 pairs of doubles each
@@ -327,7 +257,6 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             if (off[u] >= 0) *reinterpret_cast<d2_t*>(sL + off[u]) = v[u];
     }
     __syncthreads();
-    STAMP(2);
     // output of panel jb by `nthr` threads (t = 0 .. nthr-1): L[:, 16jb:16jb+16] with zeros above the diagonal, and the
     // mirrored inverse S[r][c] = X[max(r,c)][min(r,c)] for max(r,c) in block jb: X[hi][lo] = X^T[lo][hi] sits in the UPPER part
     // of sL, the diagonal 16-block in sY
@@ -362,14 +291,12 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         // panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb]
         if (wave != jb) solve_block<YP16>(sL, Yj, wave, jb, fr, q);
         __syncthreads();
-        if (jb == 0) STAMP(3);
         if (jb == 7) break;
         {   // priority: block column jb+1 of A gets panel jb's update first (one block per wave)
             const int ib = jb + 1 + wave;
             if (ib < 8) update_block(sL, ib, jb + 1, jb, fr, q);
         }
         __syncthreads();
-        if (jb == 0) STAMP(4);
         if (wave == 0) {
             // the next diagonal block is factorised (and inverted) while waves 1-7 finish panel jb's updates
             micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + ((jb + 1) & 1) * 16 * YP16, lane, info,
@@ -396,9 +323,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             write_panel(jb, tid - 64, 448);
         }
         __syncthreads();
-        if (jb == 0) STAMP(5);
     }
-    STAMP(6);
     // ---- the last panel's share of the output and the half log-determinant ----
     write_panel(7, tid, LEAF_THREADS);
     {
@@ -409,66 +334,25 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         __syncthreads();
         if (tid == 0) logdet_part[blk] = sc[SC_RED] + sc[SC_RED + 1];  // rows live in waves 0 and 1
     }
-    STAMP(7);
-    STAMP(8);
-    STAMP(9);
     __syncthreads();
-    STAMP(10);
-#undef STAMP
 }
 
+// One workgroup per matrix set: blockIdx.x = b selects set b of a batched evaluation (mfgp_eval_batch: the sets lie `bstride`
+// elements apart, their log-det partials `ldstride` apart, their pivot status words `istride` ints apart); a single evaluation
+// is the batch of one.
 __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const double* __restrict__ A,
                                                                          double* Lout, double* S, int ld, int blk,
-                                                                         double* logdet_part, int* info,
-                                                                         unsigned long long* stamps) {
+                                                                         double* logdet_part, int* info, long long bstride,
+                                                                         int ldstride, int istride) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    leaf_body_v3(smem, A, Lout, S, ld, blk, logdet_part, info, stamps);
+    const long long off = (long long)blockIdx.x * bstride;
+    leaf_body_v3(smem, A + off, Lout + off, S + off, ld, blk, logdet_part + (int)blockIdx.x * ldstride,
+                 info + (int)blockIdx.x * istride);
 }
 
-#ifndef MFGP_LAB_PLACEBO
-#define MFGP_LAB_PLACEBO 0     // 1 only in lab builds (tools/gpu_r03_placebo.sh): the shipped library has no placebo in it
-#endif
-#if MFGP_LAB_PLACEBO
-// TIMING PLACEBO (MFGP_LEAF_PLACEBO = bytes of LDS; results are garbage, for schedule experiments only): a workgroup of the
-// leaf's shape -- 8 waves, ~the same registers -- that holds `bytes` of LDS for the 27 us the real leaf takes alone and
-// copies the block through.  Answers "what would the evaluation take if the leaf fitted beside ONE resident bulk
-// workgroup (<= 97 KB) instead of needing a whole CU (138 KB)" before anyone rewrites the leaf for it.
-__global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_placebo(const double* __restrict__ A, double* Lout, double* S, int ld,
-                                                                     int blk, double* logdet_part, long long hold_ticks) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;
-    const long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (int e = tid; e < NB * NB; e += LEAF_THREADS) {
-        const int r = e / NB, c = e % NB;
-        const double v = (c <= r) ? A[g0 + (int64_t)r * ld + c] : 0.0;
-        smem[(e * 7) % 4096] = v;
-        Lout[g0 + (int64_t)r * ld + c] = (r == c) ? 1.0 : 0.0;     // identity factor: everything downstream stays finite
-        S[g0 + (int64_t)r * ld + c] = (r == c) ? 1.0 : 0.0;
-    }
-    if (tid == 0) logdet_part[blk] = smem[5] * 0.0;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-#endif   // MFGP_LAB_PLACEBO
 
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
-                 double* logdet_part, int* info, unsigned long long* stamps) {
-#if MFGP_LAB_PLACEBO
-    static const int placebo = getenv("MFGP_LEAF_PLACEBO") ? atoi(getenv("MFGP_LEAF_PLACEBO")) : 0;
-    if (placebo > 0) {
-        static std::once_flag once_p[MFGP_MAX_DEVICES];
-        int devp = 0;
-        (void)hipGetDevice(&devp);
-        std::call_once(once_p[devp & (MFGP_MAX_DEVICES - 1)], [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_placebo), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      placebo);
-        });
-        hipLaunchKernelGGL(mfgp_leaf_placebo, dim3(1), dim3(LEAF_THREADS), (size_t)placebo, s, A, Lout, S, ld, blk, logdet_part,
-                           (long long)2700);   // 27 us in 100 MHz ticks
-        return;
-    }
-#endif
+                 double* logdet_part, int* info, int nbatch, long long bstride, int ldstride, int istride) {
     constexpr size_t lds = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
     static std::once_flag attr_once[MFGP_MAX_DEVICES];   // per device, thread-safe (see launch_gemm)
     int dev = 0;
@@ -477,8 +361,8 @@ void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfgp_leaf_cholinv_f64),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
-    hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(1), dim3(LEAF_THREADS), lds, s, A, Lout, S, ld, blk, logdet_part, info,
-                       stamps);
+    hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(nbatch > 0 ? nbatch : 1), dim3(LEAF_THREADS), lds, s, A, Lout, S, ld, blk,
+                       logdet_part, info, bstride, ldstride, istride);
 }
 
 }  // namespace mfgp

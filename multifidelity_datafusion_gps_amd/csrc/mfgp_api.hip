@@ -35,24 +35,36 @@ static int upload_tasks(mfgp_handle* h) {
     return 0;
 }
 
-static void run_step(mfgp_handle* h, const Step& s, bool want_grad = true) {
-    hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : (s.strm == 2 && h->stream3) ? h->stream3 : h->stream;
+// One step of a plan.  nbatch > 0: over the handle's batch sets (mfgp_eval_batch) instead of its own slab -- the same launch
+// with one more grid dimension.  -> 0, or -1 when the planner asked for a kernel that does not exist (h->err says which).
+static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nbatch = 0) {
+    hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
+    const bool batched = nbatch > 0;
+    const long long bstride = batched ? 4LL * h->cap * h->cap : 0;
+    auto base = [&](int k) { return batched ? h->bslab + (size_t)k * h->cap * h->cap : h->buf[k]; };
     if (s.wait_ev > 0) (void)hipStreamWaitEvent(st, h->evpool[s.wait_ev - 1], 0);
     if (s.kind == 0) {
-        launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
+        if (batched)
+            launch_leaf(st, base(BUF_A), base(BUF_L), base(BUF_S), (int)h->Np, s.blk, h->blogdet,
+                        reinterpret_cast<int*>(h->bdres + 30), nbatch, bstride, (int)(h->cap / NB), 256);
+        else
+            launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
         h->launches++;
     } else if (s.kind == 1) {
         // a launch that carries a chunk of the K^-1 accumulation has a second task list for gradient evaluations
         const bool g = want_grad && s.gcount > 0;
         const int n = g ? s.gcount : s.count;
         if (n > 0) {
-            launch_gemm(st, s.tile, h->dtasks + (g ? s.gfirst : s.first), n, h->buf[s.a], h->buf[s.b], h->buf[s.c],
-                        s.c2 >= 0 ? h->buf[s.c2] : nullptr, (int)h->Np, s.role);
+            if (launch_gemm(st, s.tile, h->dtasks + (g ? s.gfirst : s.first), n, base(s.a), base(s.b), base(s.c),
+                            s.c2 >= 0 ? base(s.c2) : nullptr, (int)h->Np, s.role, batched ? nbatch : 1, bstride) != 0)
+                return fail(h, -1, "planner bug: no tile-GEMM kernel for tile " + std::to_string(s.tile) + ", role " +
+                                       std::to_string(s.role));
             h->launches++;
         }
     }   // kind 2: join -- the wait above is all there is
     if (s.rec_ev > 0) (void)hipEventRecord(h->evpool[s.rec_ev - 1], st);
     if (s.rec_ev_final > 0) (void)hipEventRecord(h->evpool[s.rec_ev_final - 1], st);
+    return 0;
 }
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) {
@@ -96,42 +108,10 @@ static int create_body(mfgp_handle* h, int device_id) {
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     // the main stream carries the serial chain (leaf -> panel -> narrow update): most urgent, so that its
     // workgroups take the first CU a bulk-update workgroup vacates
-    {   // experiment switches: MFGP_PRIO_CHAIN / MFGP_PRIO_BULK = hi | normal | lo (defaults: chain hi, bulk lo)
-        auto pick = [&](const char* name, int dflt) {
-            const char* e = getenv(name);
-            if (!e) return dflt;
-            if (!strcmp(e, "hi")) return prio_hi;
-            if (!strcmp(e, "lo")) return prio_lo;
-            return (prio_hi + prio_lo) / 2;
-        };
-        const int pc = pick("MFGP_PRIO_CHAIN", prio_hi), pb = pick("MFGP_PRIO_BULK", prio_lo);
-        prio_hi = pc;
-        prio_lo = pb;
-    }
     HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
-    {
-        // bulk-update stream; optionally keep MFGP_U_RESERVE CUs PER XCD out of its reach, so that the serial chain -- above all
-        // the leaf, which needs a whole CU -- always finds one.  Mask layout on this part (tools/probes/cumask.py,
-        // profiles/r03_cumask.txt): bit i = XCD i mod 8, shader engine (i / 8) mod 4, CU i / 32 of that engine -- so bits
-        // [0, 8 r) take r CUs out of EVERY XCD.  (Rounds 1-2 cleared bits r * ncu / reserve: all of them CUs of XCD 0, which
-        // then ran 1/8 of every bulk launch on 24 / 16 CUs -- the "pathological" 20-60 % they measured.)
-        int reserve = 0;
-        if (const char* e = getenv("MFGP_U_RESERVE")) reserve = atoi(e);
-        hipDeviceProp_t pr;
-        HIPCHK(h, hipGetDeviceProperties(&pr, device_id));
-        const int ncu = pr.multiProcessorCount;
-        const int nxcd = 8;
-        if (reserve > 0 && reserve * nxcd < ncu / 2 && ncu % nxcd == 0) {
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0xffffffffu);
-            for (int b = 0; b < reserve * nxcd; ++b) mask[b / 32] &= ~(1u << (b % 32));
-            HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
-        } else {
-            HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
-        }
-    }
-    // (the column stream of the three-stream plans is created when a plan first asks for it: build_plans.  Every HIP stream
-    // beyond the runtime's few hardware queues shares one with another stream -- an idle extra stream per handle cost the
-    // four-handle bench configuration 1 % and cfg3's chain-bound HF level 40 %)
+    // bulk-update stream: least urgent.  (Measured and retired -- tools/gemm_lab/RETIRED.md: other priority pairs move nothing;
+    // a CU mask that keeps CUs out of this stream's reach for the leaf gives the leaf its CU and costs the bulk stream as much.)
+    HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
     // timing events: no system-scope fence at the record either (more precise stamps, and cheaper: see build_plans)
     for (auto& ev : h->ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
     // the scalar results (quadratic form, log-det, gradient, pivot status) are written by the kernels straight into
@@ -154,7 +134,19 @@ static int create_body(mfgp_handle* h, int device_id) {
 
 const char* mfgp_device_info(mfgp_handle* h) { return h ? h->info_str.c_str() : ""; }
 
+static void free_batch(mfgp_handle* h) {
+    for (double** p : {&h->bslab, &h->bz, &h->balpha, &h->blogdet, &h->bpart}) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    if (h->bhres) hipHostFree(h->bhres);
+    h->bhres = h->bdres = nullptr;
+    h->bsets = 0;
+    h->bsets_cap = 0;
+}
+
 static void free_mats(mfgp_handle* h) {
+    free_batch(h);       // (its layout follows the slab's capacity)
     if (h->slab) hipFree(h->slab);
     h->slab = nullptr;
     for (auto& b : h->buf) b = nullptr;
@@ -183,7 +175,6 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : h->evpool) hipEventDestroy(ev);
     if (h->stream2) hipStreamDestroy(h->stream2);
-    if (h->stream3) hipStreamDestroy(h->stream3);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -191,23 +182,12 @@ int32_t mfgp_destroy(mfgp_handle* h) {
 
 static int build_plans(mfgp_handle* h) {
     build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap);
-    if (!h->stream3) {
-        bool wants3 = false;
-        for (const Step& st : h->pl.steps) wants3 = wants3 || st.strm == 2;
-        if (wants3) {   // column stream: what the NEXT macro panel's chain waits for -- the chain's priority
-            int prio_lo = 0, prio_hi = 0;
-            HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-            HIPCHK(h, hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
-        }
-    }
     while ((int)h->evpool.size() < h->pl.n_events) {
         hipEvent_t e;
         // the plan's events order kernels of ONE device across the handle's two streams: no system-scope fence (cache
         // write-back / invalidate for the host and for other devices) when they are recorded -- ~2 % of an evaluation at
-        // N = 3072 .. 6144 (MFGP_EVENT_SYSTEM_FENCE=1 restores it); results reach the host behind hipStreamSynchronize
-        unsigned flags = hipEventDisableTiming;
-        if (!(getenv("MFGP_EVENT_SYSTEM_FENCE") && atoi(getenv("MFGP_EVENT_SYSTEM_FENCE")) != 0)) flags |= hipEventDisableSystemFence;
-        HIPCHK(h, hipEventCreateWithFlags(&e, flags));
+        // N = 3072 .. 6144; results reach the host behind hipStreamSynchronize
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
         h->evpool.push_back(e);
     }
     return upload_tasks(h);
@@ -350,14 +330,15 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
     const bool stages = h->stage_timing;   // an event record costs 6-8 us of stream time: per-stage stamps only where that is noise
     if (stages) HIPCHK(h, hipEventRecord(h->ev[1], s));
     const bool stream_kinv = want_grad && h->pl.kinv_streamed;
-    for (const Step& st : h->pl.steps) run_step(h, st, stream_kinv);
+    for (const Step& st : h->pl.steps)
+        if (run_step(h, st, stream_kinv) != 0) return -1;
     if (stages) HIPCHK(h, hipEventRecord(h->ev[2], s));
     launch_rowdot(s, h->buf[BUF_S], (int)h->Np, h->dY, h->dz, (int)h->Np, (int)h->Np, 0);       // z = X y
     launch_alpha_finish(s, h->buf[BUF_S], (int)h->Np, h->dz, h->dalpha, (int)h->Np, h->dlogdet, h->nblk, h->dres);   // alpha = X^T z; z^T z, log-det
     h->launches += 2;
     if (stages || (!want_grad && h->timing)) HIPCHK(h, hipEventRecord(h->ev[3], s));
     if (want_grad) {
-        if (!stream_kinv) run_step(h, h->pl.kinv_step);   // (streamed plans have accumulated K^-1 behind the chain already)
+        if (!stream_kinv && run_step(h, h->pl.kinv_step) != 0) return -1;   // (streamed plans have accumulated K^-1 behind the chain already)
         if (stages) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 64);
@@ -433,6 +414,124 @@ int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitt
     if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
     if (want_grad && grad)
         for (int i = 0; i < h->spec.np + 1; ++i) grad[i] = h->grad[i];
+    return 0;
+}
+
+// ---- batched evaluation ------------------------------------------------------------------------------------------
+#define MFGP_MAX_BATCH_SETS 16
+
+static int ensure_batch(mfgp_handle* h, int B) {
+    if (B <= h->bsets && h->bsets_cap == h->cap) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int want = std::max(B, h->bsets_cap == h->cap ? h->bsets : 0);
+    free_batch(h);
+    const size_t cap = (size_t)h->cap;
+    HIPCHK(h, hipMalloc(&h->bslab, (size_t)want * 4 * cap * cap * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->bz, (size_t)want * cap * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->balpha, (size_t)want * cap * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->blogdet, (size_t)want * (cap / NB) * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->bpart, (size_t)want * grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1) * sizeof(double)));
+    HIPCHK(h, hipHostMalloc(&h->bhres, (size_t)want * 128 * sizeof(double), hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->bdres), h->bhres, 0));
+    memset(h->bhres, 0, (size_t)want * 128 * sizeof(double));
+    h->bsets = want;
+    h->bsets_cap = h->cap;
+    return 0;
+}
+
+// B independent objective(+gradient) evaluations on the SAME data and kernel structure at B hyper-parameter points, as ONE
+// pass of the plan: every launch of the sweep carries the B matrix sets side by side (leaf: B workgroups; tile GEMMs: the
+// task list x B), so the serial Cholesky chain -- which leaves most of the GPU idle at N <= 4096 -- is paid once for all
+// of them, and the bulk launches are B times fuller.  Each evaluation's arithmetic is the single evaluation's, tile for
+// tile: results are bitwise those of mfgp_eval at the same point.
+int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const double* noises, const double* jitters,
+                        int32_t want_grad, double* nlml, double* grads, int32_t* status) {
+    int rc = check_ready(h, "mfgp_eval_batch");
+    if (rc) return rc;
+    if (!thetas || !noises || !jitters || !nlml || !status || (want_grad && !grads))
+        return fail(h, -1, "mfgp_eval_batch: NULL argument");
+    if (B < 1 || B > MFGP_MAX_BATCH_SETS) return fail(h, -1, "mfgp_eval_batch: 1 <= B <= 16");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int np = h->spec.np;
+    std::vector<KernSpecDev> specs((size_t)B, h->spec);
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < np; ++i) {
+            const double v = thetas[(size_t)b * np + i];
+            if (!(v > 0.0) || !isfinite(v)) return fail(h, -1, "mfgp_eval_batch: parameters must be positive and finite");
+            specs[b].theta[i] = v;
+        }
+        if (!(noises[b] >= 0.0) || !(jitters[b] >= 0.0)) return fail(h, -1, "mfgp_eval_batch: noise and jitter must be >= 0");
+        specs[b].theta[np] = noises[b];
+        specs[b].theta[np + 1] = jitters[b];
+        specs[b].D = h->D;
+    }
+    rc = ensure_batch(h, B);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    const size_t cap = (size_t)h->cap, set = 4 * cap * cap;
+    const int Np = (int)h->Np;
+    const bool grad = want_grad != 0;
+    h->launches = 0;
+    for (int b = 0; b < B; ++b) *reinterpret_cast<int*>(h->bhres + (size_t)b * 128 + 30) = 0;   // (the previous call synchronised)
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], s));
+    for (int b = 0; b < B; ++b)
+        launch_kbuild_tri(s, specs[b], h->dX, (int)h->N, Np, h->bslab + b * set, Np);
+    h->launches += B;
+    if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[1], s));
+    const bool stream_kinv = grad && h->pl.kinv_streamed;
+    for (const Step& st : h->pl.steps)
+        if (run_step(h, st, stream_kinv, B) != 0) return -1;
+    if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[2], s));
+    for (int b = 0; b < B; ++b) {
+        double* S_b = h->bslab + b * set + (size_t)BUF_S * cap * cap;
+        launch_rowdot(s, S_b, Np, h->dY, h->bz + b * cap, Np, Np, 0);                       // z = X y
+        launch_alpha_finish(s, S_b, Np, h->bz + b * cap, h->balpha + b * cap, Np, h->blogdet + b * (cap / NB), h->nblk,
+                            h->bdres + (size_t)b * 128);
+    }
+    h->launches += 2 * B;
+    if (grad) {
+        if (!stream_kinv && run_step(h, h->pl.kinv_step, true, B) != 0) return -1;
+        const size_t npart = (size_t)grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1);
+        for (int b = 0; b < B; ++b)
+            launch_grad(s, specs[b], h->dX, h->bslab + b * set, Np, h->balpha + b * cap, (int)h->N, Np, h->bpart + b * npart,
+                        h->bdres + (size_t)b * 128 + 64);
+        h->launches += 2 * B;
+    }
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    // accounting: B evaluations, timed as one pass
+    const double npd = (double)h->Np;
+    mfgp_timings& t = h->tm;
+    memset(&t, 0, sizeof t);
+    if (h->stage_timing) {
+        t.kbuild_ms = ev_ms(h->ev[0], h->ev[1]);
+        t.cholinv_ms = ev_ms(h->ev[1], h->ev[2]);
+    }
+    if (h->timing) t.total_ms = ev_ms(h->ev[0], h->ev[5]);
+    t.timed = h->stage_timing ? 3 : (h->timing ? 1 : 0);
+    t.kbuild_bytes = B * 4.0 * npd * (npd + 64.0);
+    t.kinv_flops = (grad && !stream_kinv) ? B * npd * npd * npd / 3.0 : 0.0;
+    t.cholinv_flops = B * (stream_kinv ? 3.0 : 2.0) * npd * npd * npd / 3.0;
+    t.n_launches = h->launches;
+    if (h->timing) h->cum.timed_evals += B;
+    h->cum.evals += B;
+    h->cum.grad_evals += grad ? B : 0;
+    h->cum.kbuild_ms += t.kbuild_ms;
+    h->cum.cholinv_ms += t.cholinv_ms;
+    h->cum.total_ms += t.total_ms;
+    h->cum.kbuild_bytes += t.kbuild_bytes;
+    h->cum.kinv_flops += t.kinv_flops;
+    h->cum.cholinv_flops += t.cholinv_flops;
+    for (int b = 0; b < B; ++b) {
+        const double* r = h->bhres + (size_t)b * 128;
+        const int info = *reinterpret_cast<const int*>(r + 30);
+        status[b] = info;
+        nlml[b] = 0.5 * ((double)h->N * 1.8378770664093453 + r[1] + r[0]);
+        if (grad)
+            for (int i = 0; i < np + 1; ++i) grads[(size_t)b * (np + 1) + i] = r[64 + i];
+    }
     return 0;
 }
 
@@ -549,7 +648,7 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
     if (!h->grad_valid) {
         hipStream_t s = h->stream;
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], s));
-        run_step(h, h->pl.kinv_step);
+        if (run_step(h, h->pl.kinv_step) != 0) return -1;
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[4], s));
         launch_grad(s, h->spec, h->dX, h->buf[BUF_A], (int)h->Np, h->dalpha, (int)h->N, (int)h->Np,
                     h->dpart, h->dres + 64);
@@ -614,7 +713,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         h->kinv_valid = false;  // V overwrites the K^-1 storage
         const int vrows = skinny ? 16 * rows16 : rows_p;
         if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
-        else run_step(h, h->pl.predv_step);
+        else if (run_step(h, h->pl.predv_step) != 0) return -1;
         launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
         launch_finish_var(s, h->spec, h->dvec2, var_dev, vrows, include_noise ? h->noise : 0.0);
         h->launches += 2;
@@ -893,8 +992,7 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
                          int32_t K, double alpha, double beta, int32_t tile) {
     if (!h || !A || !B || !C) return fail(h, -1, "mfgp_dbg_gemm_nt: NULL");
     const bool chain = (tile == -64);   // -64: the serial-chain variant of the 64-tile kernel (mfgp_gemm_nt_f64_chain)
-    const bool chain4 = (tile == -63);  // -63: its 4-wave form (mfgp_gemm_nt_f64_chain4)
-    if (chain || chain4) tile = 64;
+    if (chain) tile = 64;
     if ((tile != 128 && tile != 64 && tile != 32) || M % tile || N % tile || K % BK || K < BK)
         return fail(h, -1, "mfgp_dbg_gemm_nt: M, N must be multiples of the tile (128, 64, 32) and K of 32");
     HIPCHK(h, hipSetDevice(h->device));
@@ -922,7 +1020,8 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
         }
     HIPCHK(h, hipMalloc(&dt, ts.size() * sizeof(GemmTask)));
     HIPCHK(h, hipMemcpy(dt, ts.data(), ts.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
-    launch_gemm(h->stream, tile, dt, (int)ts.size(), dA, dB, dC, nullptr, ld, chain ? 3 : (chain4 ? 6 : 0));
+    if (launch_gemm(h->stream, tile, dt, (int)ts.size(), dA, dB, dC, nullptr, ld, chain ? 3 : 0) != 0)
+        return fail(h, -1, "mfgp_dbg_gemm_nt: no kernel for this tile");
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy2D(C, (size_t)N * 8, dC, (size_t)ld * 8, (size_t)N * 8, M, hipMemcpyDeviceToHost));
@@ -940,22 +1039,8 @@ int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xou
     HIPCHK(h, hipMalloc(&dl, 8)); HIPCHK(h, hipMalloc(&di, 4));
     HIPCHK(h, hipMemcpy(dA, A, bytes, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(di, 0, 4));
-    unsigned long long* dst = nullptr;
-    HIPCHK(h, hipMalloc(&dst, 16 * sizeof(unsigned long long)));
-    launch_leaf(h->stream, dA, dL, dS, NB, 0, dl, di, dst);
+    launch_leaf(h->stream, dA, dL, dS, NB, 0, dl, di);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    {
-        unsigned long long st[16];
-        HIPCHK(h, hipMemcpy(st, dst, sizeof st, hipMemcpyDeviceToHost));
-        hipFree(dst);
-        if (getenv("MFGP_LEAF_STAMPS")) {
-            static const char* names[] = {"first tile load", "micro0 || block load", "solve0", "prio0",
-                                          "micro1 || update0 + output0", "panels 1-7", "output7 + logdet", "-", "-", "drain"};
-            fprintf(stderr, "leaf stamps (shader cycles):");
-            for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%llu", names[i], st[i + 1] - st[i]);
-            fprintf(stderr, " total=%llu\n", st[10] - st[0]);
-        }
-    }
     HIPCHK(h, hipGetLastError());
     int info = 0;
     HIPCHK(h, hipMemcpy(Lout, dL, bytes, hipMemcpyDeviceToHost));

@@ -37,9 +37,11 @@ constexpr int MFGP_MAX_GROUPS = 3;
 // ---- launchers (implemented in the .hip files) -------------------------------------------------
 // tile: 128 or 64.  tasks = device pointer to ntasks GemmTask.
 // role: 0 = recursion GEMMs, 1 = the K^-1 SYRK launch, 2 = predictive-variance product (distinct kernel symbols),
-//       3 = a step on the serial Cholesky chain (64-tile only: mfgp_gemm_nt_f64_chain)
-void launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
-                 const double* B, double* C, double* C2, int ld, int role = 0);
+//       3 = a step on the serial Cholesky chain (64-tile only: mfgp_gemm_nt_f64_chain), 5 = its 32-tile form
+// nbatch / bstride: the same task list over nbatch matrix sets lying bstride elements apart (mfgp_eval_batch); 1 / 0 otherwise
+// -> 0, or -1 for a (tile, role) pair no kernel exists for
+int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
+                const double* B, double* C, double* C2, int ld, int role = 0, int nbatch = 1, long long bstride = 0);
 size_t gemm_lds_bytes(int tile);
 // skinny variance product for <= 64 test rows: V[0 .. 16*rows16) = W X^T (X = L^-1 from the mirrored S); rows16 in {1, 2, 4}
 void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const double* S, double* V, int ld, int Np);
@@ -47,8 +49,9 @@ void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const doubl
 // leaf: Cholesky + inverse of the 128x128 diagonal block `blk` of A (ld), in LDS.
 //   L block (zeros above diag) -> Lout[blk,blk];  X = L^-1 -> S[blk,blk] stored mirrored (X + X^T - diag)
 //   half log-det partial -> logdet_part[blk];  first failing pivot (1-based global index) -> info (atomicMin style)
+//   batched: nbatch workgroups, set b at A + b * bstride (and Lout, S), logdet_part + b * ldstride, info + b * istride
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
-                 double* logdet_part, int* info, unsigned long long* stamps = nullptr);
+                 double* logdet_part, int* info, int nbatch = 1, long long bstride = 0, int ldstride = 0, int istride = 0);
 
 // covariance builders
 //   tri: lower-triangle 64x64 tiles of Ky = K + (noise+jitter) I over padded Np (identity padding)
@@ -101,7 +104,6 @@ struct mfgp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // bulk trailing updates of the look-ahead Cholesky
-    hipStream_t stream3 = nullptr;      // column stream (plan steps with strm == 2: the next macro panel's columns, beside the bulk launches)
     std::vector<hipEvent_t> evpool;     // cross-stream dependencies of the plan
     std::string err, info_str;
     int64_t N = 0, Np = 0, cap = 0;  // cap: allocated padded size
@@ -145,6 +147,15 @@ struct mfgp_handle {
     int comm_rank = 0, comm_size = 1;
     double* dstage = nullptr;            // device staging of mfgp_allgather_host
     size_t stage_cap = 0;
+    // batched evaluation (mfgp_eval_batch): bsets matrix sets A | L | S | W of cap^2 each (the plan's task offsets apply to
+    // every set: set b lies b * 4 cap^2 elements further on), their solve vectors, log-det partials, gradient partials and
+    // 128-double result blocks in pinned, device-mapped memory (as hres for a single evaluation).  Separate from the handle's
+    // own slab: the factorisation mfgp_predict works from survives a batch.
+    int bsets = 0;
+    int64_t bsets_cap = 0;               // the padded capacity (h->cap) the sets were allocated for
+    double* bslab = nullptr;
+    double *bz = nullptr, *balpha = nullptr, *blogdet = nullptr, *bpart = nullptr;
+    double *bhres = nullptr, *bdres = nullptr;
 };
 
 #define HIPCHK(h, call)                                                                         \

@@ -9,6 +9,15 @@
 
 namespace mfgp {
 
+// The planner's switches (environment, read when a handle plans; DESIGN.md "Planner switches").  Only those a GPU test runs
+// (tests/test_gpu_plans.py VARIANTS) and the CPU plan checker covers: MFGP_PLAN, MFGP_MACRO, MFGP_SHIFT, MFGP_KINV_STREAM,
+// MFGP_CHAIN_SLIM, MFGP_T128_MIN.  Everything else the earlier rounds measured is a constant here (the measured best); the
+// variants that lost their A/B live on in tools/gemm_lab/RETIRED.md.
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // planner
 // ------------------------------------------------------------------------------------------------
@@ -133,42 +142,27 @@ static void plan_cholinv(Plan& p, int b0, int b1) {
 static int new_event(Plan& p) { return ++p.n_events; }   // 1-based
 
 static void plan_potrf_rl(Plan& p) {
-    // Blocked Cholesky with macro panels of MB leaf blocks and look-ahead over two streams.
+    // Blocked Cholesky with macro panels of MB leaf blocks and look-ahead over two streams (round 1's schedule: MFGP_PLAN=levels).
     //   main stream (the serial chain), for every block column c of a macro panel [M0, M1):
     //       leaf(c)     : L_cc, X_cc = L_cc^-1
     //       panel(c)    : L[i,c] = A[i,c] X_cc^T, i > c
-    //       inner(c)    : A[i,j] -= L[i,c] L[j,c]^T for the macro's later columns j in (c, M1), K = 128 (right-looking
-    //                     inside the macro; MFGP_INNER_RIGHT=0: left-looking colupdate(c) before leaf(c) instead)
+    //       inner(c)    : A[i,j] -= L[i,c] L[j,c]^T for the macro's later columns j in (c, M1), K = 128: right-looking inside the
+    //                     macro (a step on the chain costs launch + K-depth, and K = 128 three times beats 128 + 256 + 384:
+    //                     N = 8192: 11.28 -> 11.04 ms, 4096: 3.57 -> 3.43, 2048: 1.46 -> 1.36 against the left-looking form)
     //   bulk stream, after the macro's chain: A[i,j] -= L[i,M0:M1] L[j,M0:M1]^T (K = MB*128), first the block
-    //       columns of the NEXT macro panel one by one (each releases the chain step that needs it), then the rest,
+    //       columns of the NEXT macro panel in one launch (it releases the chain steps that need them), then the rest,
     //       which overlaps the next macro's chain.
     const int64_t ld = p.ld;
     const int nb = p.nblk;
-    int MB = 4;   // 2 is ~1.5 % faster for one evaluation alone, 4 is ~5 % faster with evaluations in flight (bench)
-    if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
-    bool lookahead = true;
-    if (const char* e = getenv("MFGP_LOOKAHEAD")) lookahead = atoi(e) != 0;
-    // inside a macro panel: right-looking (after panel(c), column c's K = 128 contribution to the macro's later columns)
-    // instead of left-looking (before leaf(c), the K <= (MB-1)*128 contribution of the macro's earlier columns to
-    // column c): a step on the chain costs launch + K-depth, and K = 128 three times beats 128 + 256 + 384
-    // (N = 8192: 11.28 -> 11.04 ms, 4096: 3.57 -> 3.43, 2048: 1.46 -> 1.36)
-    bool inner_right = true;
-    if (const char* e = getenv("MFGP_INNER_RIGHT")) inner_right = atoi(e) != 0;
+    const int MB = std::max(1, env_int("MFGP_MACRO", 4));   // 2 is ~1.5 % faster for one evaluation alone, 4 is ~5 % faster with evaluations in flight
     // `shift`: the chain's K = 128 inner updates also cover the NEXT macro panel's first column, so that no K = MB*128
     // step (and no wait for the previous macro's bulk update) gates its first leaf.  Pays where the factorisation is
     // chain-bound throughout (N = 4096: 3.42 -> 3.28 ms, 2048: 1.37 -> 1.28); neutral at N = 8192, where the first half
     // is bound by the bulk updates and the gating step's slack is worth as much as its latency.
-    bool shift = nb < 48;
-    if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
-    shift = shift && lookahead && inner_right;
-    bool merge_cols = true;
-    if (const char* e = getenv("MFGP_MERGE_COLS")) merge_cols = atoi(e) != 0;
+    const bool shift = env_int("MFGP_SHIFT", nb < 48) != 0;
     // slim chain workgroups (role 3) co-reside with the bulk update's workgroups; alone they are ~30 % slower than the
     // double-buffered 64-tile kernel, so they only pay where bulk updates are long enough to overlap the chain
-    int chain_role = (lookahead && nb >= 48) ? 3 : 0;
-    if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
-    // 4-wave form of the slim chain kernel (role 6): fits beside TWO bulk workgroups per CU (see gemm_f64.hip)
-    if (const char* e = getenv("MFGP_CHAIN_WAVES")) { if (chain_role == 3 && atoi(e) == 4) chain_role = 6; }
+    const int chain_role = env_int("MFGP_CHAIN_SLIM", nb >= 48) ? 3 : 0;
     auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
         // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
         const int sc = NB / T;
@@ -186,7 +180,6 @@ static void plan_potrf_rl(Plan& p) {
             }
     };
     auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
-    bool cols_used = false, rest_b_waits_colsx = false;
     std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
     int ev_rest_prev = 0;            // event after the previous macro's bulk update of the REST (bulk stream)
     for (int M0 = 0; M0 < nb; M0 += MB) {
@@ -194,22 +187,10 @@ static void plan_potrf_rl(Plan& p) {
         const int M2 = std::min(M1 + MB, nb);
         int main_waited_ev = 0;   // the merged column launch signals ONE event for several columns: wait for it once
         for (int c = M0; c < M1; ++c) {
-            bool waited = false;
-            if (c > M0 && !inner_right) {   // left-looking update of block column c with the macro's finished columns
-                const int T = 64;  // latency-bound, on the serial chain: many small tiles
-                const int first = (int)p.tasks.size();
-                syrk_tasks(T, c, c + 1, M0, c);
-                add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
-                p.steps.back().role = chain_role;
-                if (lookahead && ev_col[c] > 0) {
-                    if (ev_col[c] != main_waited_ev) p.steps.back().wait_ev = main_waited_ev = ev_col[c];
-                    waited = true;   // (an event wait costs ~6 us on the chain even when already signalled)
-                }
-            }
             Step s{};
             s.kind = 0;
             s.blk = c;
-            if (lookahead && !waited && ev_col[c] > 0 && ev_col[c] != main_waited_ev) s.wait_ev = main_waited_ev = ev_col[c];
+            if (ev_col[c] > 0 && ev_col[c] != main_waited_ev) s.wait_ev = main_waited_ev = ev_col[c];   // (an event wait costs ~6 us on the chain even when already signalled)
             p.steps.push_back(s);
             const int rem = nb - 1 - c;
             if (rem == 0) break;
@@ -236,24 +217,16 @@ static void plan_potrf_rl(Plan& p) {
             // right-looking inside the macro: column c -> the macro's later columns, K = 128.  `shift`: also -> the first
             // column of the NEXT macro panel, so that no K = MB*128 step gates its first leaf
             const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
-            if (inner_right && c + 1 < inner_hi) {
+            if (c + 1 < inner_hi) {
                 const int first = (int)p.tasks.size();
                 syrk_tasks(64, c + 1, inner_hi, c, c + 1);
                 add_gemm(p, p.steps, 64, first, BUF_L, BUF_L, BUF_A, -1);
                 p.steps.back().role = chain_role;
                 const int e = ev_col[c + 1];
-                if (lookahead && e > 0 && e != main_waited_ev) p.steps.back().wait_ev = main_waited_ev = e;
+                if (e > 0 && e != main_waited_ev) p.steps.back().wait_ev = main_waited_ev = e;
             }
         }
         if (M1 >= nb) break;
-        if (!lookahead) {
-            const int r = nb - M1;
-            const int T = pick_tile(p, r * (r + 1) / 2);
-            const int first = (int)p.tasks.size();
-            syrk_tasks(T, M1, nb, M0, M1);
-            add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
-            continue;
-        }
         const int ev_chain = new_event(p);
         p.steps.back().rec_ev = ev_chain;   // chain(M) complete: every L[:, M0:M1] panel is final
         bool first_bulk = true;
@@ -302,19 +275,17 @@ static void plan_potrf_rl(Plan& p) {
             // the other block columns of the next macro panel: ONE launch on the bulk stream (each is needed one chain
             // step later than the previous; a launch per column left the GPU at ~140 workgroups three times in a row)
             const int cols = M2 - (M1 + 1);
-            const int T = merge_cols ? pick_tile(p, cols * (nb - M1 - 1)) : 64;
-            for (int c = M1 + 1; c < M2; c += merge_cols ? cols : 1) {
-                const int first = (int)p.tasks.size();
-                syrk_tasks(merge_cols ? T : pick_tile(p, nb - c), c, merge_cols ? M2 : c + 1, M0, M1);
-                add_gemm(p, p.steps, merge_cols ? T : pick_tile(p, nb - c), first, BUF_L, BUF_L, BUF_A, -1);
-                Step& st = p.steps.back();
-                st.strm = 1;
-                if (first_bulk) st.wait_ev = ev_chain;
-                first_bulk = false;
-                const int ev = new_event(p);
-                st.rec_ev = ev;
-                for (int cc = c; cc < (merge_cols ? M2 : c + 1); ++cc) ev_col[cc] = ev;
-            }
+            const int T = pick_tile(p, cols * (nb - M1 - 1));
+            const int first = (int)p.tasks.size();
+            syrk_tasks(T, M1 + 1, M2, M0, M1);
+            add_gemm(p, p.steps, T, first, BUF_L, BUF_L, BUF_A, -1);
+            Step& st = p.steps.back();
+            st.strm = 1;
+            st.wait_ev = ev_chain;
+            first_bulk = false;
+            const int ev = new_event(p);
+            st.rec_ev = ev;
+            for (int cc = M1 + 1; cc < M2; ++cc) ev_col[cc] = ev;
         }
         if (M2 < nb) {   // the rest of the trailing matrix: overlaps the next macro panel's chain
             const int T = pick_tile(p, ntiles_cols(M2, nb));
@@ -405,9 +376,8 @@ static void plan_trtri_levels(Plan& p) {
 // round-robin would give XCD 0 the longest run of every round) and the per-XCD sequences interleaved, so that XCD x executes whole
 // runs back to back.  Pure reordering: every tile's arithmetic (and the result bits) is unchanged.
 static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group) {
-    static const bool on = !(getenv("MFGP_XCD_ORDER") && atoi(getenv("MFGP_XCD_ORDER")) == 0);
     const int n = (int)tasks.size() - first;
-    if (!on || n < 8 * group) return;
+    if (n < 8 * group) return;
     std::vector<GemmTask> lists[8];
     int g = 0;
     for (int t0 = 0; t0 < n; t0 += group, ++g)
@@ -422,7 +392,7 @@ static void xcd_interleave(std::vector<GemmTask>& tasks, int first, int group) {
 static void plan_kinv(Plan& p) {
     const int64_t ld = p.ld;
     const int nb = p.nblk;
-    static const int kinv_t128_min = getenv("MFGP_KINV_T128_MIN") ? atoi(getenv("MFGP_KINV_T128_MIN")) : 600;   // N = 4096: 0.65 -> 0.54 ms, N = 3072: 0.48 -> 0.25 ms
+    const int kinv_t128_min = 600;   // N = 4096: 0.65 -> 0.54 ms, N = 3072: 0.48 -> 0.25 ms as 64-tiles
     const int T = nb * (nb + 1) / 2 >= kinv_t128_min ? 128 : 64;
     const int sc = NB / T;
     const int first = (int)p.tasks.size();
@@ -430,9 +400,7 @@ static void plan_kinv(Plan& p) {
     // small i (= long K range) first.  Measured at N = 8192 (tools/sweep_kinv_order.sh): 1x8 3.73 ms / 3.05 GB fetched,
     // 4x8 3.85 ms / 2.28 GB, row-major without XCD placement 3.9 ms / 3.69 GB -- the launch is FMA-bound, so the
     // finer run (better balance over the XCDs) wins over the larger one (fewer panel re-reads).
-    int BI = 1, BJ = 8;
-    if (const char* e = getenv("MFGP_KINV_BI")) BI = std::max(1, atoi(e));
-    if (const char* e = getenv("MFGP_KINV_BJ")) BJ = std::max(1, atoi(e));
+    const int BI = 1, BJ = 8;
     const int nt = nb * sc;
     for (int i0 = 0; i0 < nt; i0 += BI)
         for (int j0 = 0; j0 <= std::min(nt - 1, i0 + BI - 1); j0 += BJ)
@@ -463,9 +431,8 @@ void plan_predv(Plan& p, int rows_p) {
     const int T = pick_tile(p, nb * rb);
     const int sc = NB / T;
     const int first = (int)p.tasks.size();
-    int BI = 8, BR = 4;                                      // super-blocks: BI rows of X  x  BR panel rows
-    if (const char* e = getenv("MFGP_PREDV_BI")) BI = std::max(1, atoi(e));
-    if (const char* e = getenv("MFGP_PREDV_BR")) BR = std::max(1, atoi(e));
+    const int BI = 8, BR = 4;                                // super-blocks: BI rows of X  x  BR panel rows (traffic 13.5-15.1 GB
+                                                             // over the shapes tried at N = N* = 8192, time unchanged)
     const int ni = nb * sc, nr = rb * sc;
     for (int i0 = ni - 1; i0 >= 0; i0 -= BI)                 // large i (= long K range) first
         for (int r0 = 0; r0 < nr; r0 += BR)
@@ -531,45 +498,23 @@ static void plan_sweep(Plan& p) {
     //   6144 6.02 / 6.21 / 6.22 / 6.24 / 6.29;  8192 12.27 / 12.05 / 11.80 / 11.92 / 12.00 / 12.35 / 13.5;
     //   12288 - / - / 34.50 / 34.48 / 34.66 / 36.0 / 37.2;  16384 - / - / 75.9 / 75.7 / 77.6 / 77.9 / 81.7
     // (rounds 1-2 had 2 / 3 / 4 / 6 / 8 / 16 from 14 / 33 / 41 / 52 / 64 / 96 block columns up).
-    int MB = nb >= 80 ? 5 : (nb >= 56 ? 4 : (nb >= 25 ? 2 : (nb > 13 ? 3 : nb)));
-    if (const char* e = getenv("MFGP_MACRO")) MB = std::max(1, atoi(e));
-    bool shift = nb < 48;      // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
-    if (const char* e = getenv("MFGP_SHIFT")) shift = atoi(e) != 0;
+    const int MB = std::max(1, env_int("MFGP_MACRO", nb >= 80 ? 5 : (nb >= 56 ? 4 : (nb >= 25 ? 2 : (nb > 13 ? 3 : nb)))));
+    const bool shift = env_int("MFGP_SHIFT", nb < 48) != 0;   // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     // slim (16 KB LDS) chain workgroups fit on a CU beside a 128 KB bulk workgroup; the 64 KB kernel would wait for one to
     // retire (N = 4096: 3.27 -> 3.03 ms).  Below ~24 blocks the bulk launches are 64-tiles themselves: no difference.
-    int chain_role = nb >= 24 ? 3 : 0;
-    if (const char* e = getenv("MFGP_CHAIN_SLIM")) chain_role = atoi(e) ? 3 : 0;
-    // 4-wave form of the slim chain kernel (role 6): fits beside TWO bulk workgroups per CU (see gemm_f64.hip)
-    if (const char* e = getenv("MFGP_CHAIN_WAVES")) { if (chain_role == 3 && atoi(e) == 4) chain_role = 6; }
+    const int chain_role = env_int("MFGP_CHAIN_SLIM", nb >= 24) ? 3 : 0;
     // tile edge of the chain's own launches (panel, inner).  They are latency-bound: a 64x64x128 tile is 128 dependent-ish
     // MFMAs per SIMD (5.3 us) behind 8 serial K-steps; as 32x32 tiles (4 waves, 16 KB of LDS, four times the workgroups, four
     // K-steps) the same work spreads over four times as many SIMDs (N = 1024 0.60 -> 0.53 ms, 2048 1.20 -> 1.03, 4096 2.93 -> 2.80).  Chain-bound sizes only: at N >= 6144 the chain hides behind the
     // bulk stream and fewer, larger workgroups disturb it less.
-    int CT = nb < 48 ? 32 : 64;
-    if (const char* e = getenv("MFGP_CHAIN_TILE")) CT = atoi(e) == 32 ? 32 : 64;
+    const int CT = nb < 48 ? 32 : 64;
     const int chain_role_ct = CT == 32 ? 5 : chain_role;
-    p.kinv_streamed = !(getenv("MFGP_KINV_STREAM") && atoi(getenv("MFGP_KINV_STREAM")) == 0);
-    bool bulk_xcd = true;   // deal the super-blocks of a bulk launch to the 8 XCDs (workgroup p runs on XCD p mod 8)
-    if (const char* e = getenv("MFGP_BULK_XCD")) bulk_xcd = atoi(e) != 0;
-    int bulk_every = 1;   // macro panels per bulk chunk of B / K^-1 (see "the rest" below; N = 8192, MB = 8: 14.1 / 14.6 ms at 1 / 2)
-    if (const char* e = getenv("MFGP_BULK_EVERY")) bulk_every = std::max(1, atoi(e));
-    // Three streams (MFGP_COLS_STREAM=1; only with the gating column on the main stream, i.e. !shift): the launch the NEXT chain
-    // waits for -- the next macro panel's columns of A (+ the rows of X^T above this panel) -- goes to a third stream and
-    // runs BESIDE the bulk stream's work instead of in front of it: as the only launch on the GPU it is ~700 64-tiles on 512
-    // slots (1.4 rounds at 30 TFLOP/s, 16 x 95 us per evaluation at N = 8192).  The bulk launch is split for it: the rest
-    // of A's trailing update needs only the chain (starts at once), the B / K^-1 part also reads the new rows of X^T and
-    // waits for the column launch's event.
-    bool cols_stream = false;
-    if (const char* e = getenv("MFGP_COLS_STREAM")) cols_stream = atoi(e) != 0;
-    if (shift) cols_stream = false;
+    p.kinv_streamed = env_int("MFGP_KINV_STREAM", 1) != 0;
     int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
-    int far_done = 0;   // block columns < far_done have been applied to B's columns beyond the next macro panel
-    bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
-    if (const char* e = getenv("MFGP_XPANEL_MERGE")) merge_xpanel = atoi(e) != 0;
+    const bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
     // One macro panel (nothing runs beside the chain): K^-1 is accumulated column by column in the chain's own K = 128 launches
     // instead of one long-K launch at the end (N = 1024: 136 64-tiles of K <= 1024, 58 us on 136 CUs)
-    bool kinv_on_chain = p.kinv_streamed && nb <= MB;
-    if (const char* e = getenv("MFGP_KINV_ON_CHAIN")) kinv_on_chain = kinv_on_chain && atoi(e) != 0;
+    const bool kinv_on_chain = p.kinv_streamed && nb <= MB;
     auto at = [&](int buf, int64_t row, int64_t col) { return (int64_t)buf * bs + row * ld + col; };
     auto push = [&](int64_t a, int64_t b, int64_t c, int64_t c2, int klen, int flags, double alpha, double beta) {
         GemmTask t{};
@@ -580,9 +525,7 @@ static void plan_sweep(Plan& p) {
     // Tiles are enumerated in SUPER-BLOCKS of bulk_bi x bulk_bj output tiles (bi row panels + bj column panels feed
     // bi*bj tiles): after the XCD-aware deal below the workgroups that run side by side on one XCD (own L2) share their
     // operand panels instead of each streaming its own pair from HBM / Infinity Cache.
-    int bulk_bi = 4, bulk_bj = 4;
-    if (const char* e = getenv("MFGP_BULK_BI")) bulk_bi = std::max(1, atoi(e));
-    if (const char* e = getenv("MFGP_BULK_BJ")) bulk_bj = std::max(1, atoi(e));
+    const int bulk_bi = 4, bulk_bj = 4;   // (sweep fetch 22.8 -> 17.9 -> 16.8 GB from row-major over 4x4 super-blocks to the XCD-aware deal)
     auto in_blocks = [&](int ilo, int ihi, int jlo, int jhi, auto&& fn) {   // fn(i, j) over [ilo,ihi) x [jlo,jhi)
         for (int i0 = ilo; i0 < ihi; i0 += bulk_bi)
             for (int j0 = jlo; j0 < jhi; j0 += bulk_bj)
@@ -654,7 +597,6 @@ static void plan_sweep(Plan& p) {
     };
     auto ntiles_cols = [&](int jlo, int jhi) { int n = 0; for (int j = jlo; j < jhi; ++j) n += nb - j; return n; };
 
-    bool cols_used = false, rest_b_waits_colsx = false;
     std::vector<int> ev_col(nb, 0);  // event after the previous macro's bulk update reached block column c
     int ev_rest_prev = 0;            // event after the previous macro's last bulk launch
     bool bulk_used = false;
@@ -725,7 +667,6 @@ static void plan_sweep(Plan& p) {
         const bool last = (M1 >= nb);
         const size_t chain_last = p.steps.size() - 1;   // index of the chain's last step
         std::vector<size_t> bulk_steps;                 // bulk launches of this macro, in stream order
-        long colsx_step = -1;                           // cols_stream: this macro's launch on the third stream
         if (!last && !shift) {
             // the column that gates the next leaf stays on the MAIN stream (no event round trip on the chain); it must
             // still follow the previous macro's last bulk launch, whose A-rest part covers this column too
@@ -745,25 +686,15 @@ static void plan_sweep(Plan& p) {
             const bool have_cols = !last && lo <= hi, have_x = M0 > 0;
             const int n_cols = have_cols ? ntiles_cols(lo, hi + 1) : 0, n_x = have_x ? M0 * (M1 - M0) : 0;
             auto cols_launch = [&](int T, int first) {
-                if (cols_stream && ev_rest_prev > 0 && (int)p.tasks.size() > first) {
-                    // third stream: the launch also follows the previous macro's bulk work (A's columns and the B columns that
-                    // feed the rows of X^T were last written there; on the bulk stream that was stream order): a wait-only
-                    // step.  It is enqueued -- and its barrier retired -- long before the chain event fires, so it does
-                    // not lengthen the chain -> columns -> chain path.
-                    Step w{};
-                    w.kind = 2; w.strm = 2; w.wait_ev = ev_rest_prev;
-                    p.steps.push_back(w);
-                }
-                if (!launch(T, first, cols_stream ? 2 : 1, 0)) return;
-                if (cols_stream) colsx_step = (long)p.steps.size() - 1;   // third stream: not one of the bulk stream's steps
-                else bulk_steps.push_back(p.steps.size() - 1);
+                if (!launch(T, first, 1, 0)) return;
+                bulk_steps.push_back(p.steps.size() - 1);
                 if (have_cols) {
                     const int ev = bulk_event();
                     p.steps.back().rec_ev = ev;
                     for (int cc = lo; cc <= hi; ++cc) ev_col[cc] = ev;
                 }
             };
-            if ((merge_xpanel || cols_stream) && have_cols && have_x) {
+            if (merge_xpanel && have_cols && have_x) {
                 const int T = pick_tile(p, n_cols + n_x);
                 const int first = (int)p.tasks.size();
                 a_update(T, lo, hi + 1, M0, M1);
@@ -780,118 +711,66 @@ static void plan_sweep(Plan& p) {
                     const int T = pick_tile(p, n_x);
                     const int first = (int)p.tasks.size();
                     for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
-                    if (cols_stream) cols_launch(T, first);     // (the last macro panel: rows of X^T only)
-                    else if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
+                    if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
                 }
             }
         }
-        {   // the rest: A's trailing update beyond the columns already done; B: the NEXT macro's columns are brought up to
-            // date (they are consumed right after the next chain), the columns beyond in chunks of bulk_every macro panels;
-            // and -- gradient only -- K^-1 in the same chunks and after the last panel.  Chunks of K >= 2048 where the bulk
-            // stream is the bottleneck: long-K tasks run the matrix pipe ~10 % better than K = 512 ones and rewrite
-            // their output tile less often; one macro panel at a time where the chain is (the bulk stream has slack and
-            // the tail after the last leaf stays short).
+        {   // the rest, ONE launch: A's trailing update beyond the columns already done; B: the NEXT macro's columns are brought up
+            // to date (they are consumed right after the next chain) and the columns beyond; and -- gradient only -- this macro
+            // panel's contribution to K^-1.  (Chunks of several macro panels -- longer K per task -- were measured in rounds 2-3:
+            // N = 8192, MB = 8: 14.1 / 14.6 ms at 1 / 2 panels per chunk; one panel at a time is what stayed.)
             const int a_lo = last ? nb : (shift ? std::min(M1 + MB, nb - 1) + 1 : M2);
-            const bool chunk_now = last || (M1 - far_done) >= bulk_every * MB;
-            const bool kinv_now = p.kinv_streamed && chunk_now && kinv_lo < M1;
+            const bool kinv_now = p.kinv_streamed && kinv_lo < M1;
             const int n_a = a_lo < nb ? ntiles_cols(a_lo, nb) : 0;
-            const int n_b = last ? 0 : M1 * ((chunk_now ? nb : M2) - M1);
+            const int n_b = last ? 0 : M1 * (nb - M1);
             const int n_k = kinv_now ? M1 * (M1 + 1) / 2 : 0;
-            int T = pick_tile(p, n_a + n_b + n_k);
+            const int T = pick_tile(p, n_a + n_b + n_k);
             auto by_length = [&](int first) {   // longest K first: the launch's tail is then made of its shortest tasks;
                 std::stable_sort(p.tasks.begin() + first, p.tasks.end(),     // super-blocks stay together within a K class
                                  [](const GemmTask& x, const GemmTask& y) { return x.klen > y.klen; });
-                if (bulk_xcd) xcd_interleave(p.tasks, first, bulk_bi * bulk_bj);
+                xcd_interleave(p.tasks, first, bulk_bi * bulk_bj);            // deal the super-blocks to the 8 XCDs (workgroup p runs on XCD p mod 8)
             };
-            auto common_b = [&]() {
-                if (!last) b_update(T, 0, M1, M1, M2, far_done, M1);                       // catch-up of the next macro's columns
-                if (!last && chunk_now && M2 < nb) b_update(T, 0, M1, M2, nb, far_done, M1);   // the columns beyond
-            };
-            auto common_a = [&]() {
+            auto common = [&]() {
+                if (!last) b_update(T, 0, M1, M1, M2, M0, M1);                 // catch-up of the next macro's columns
+                if (!last && M2 < nb) b_update(T, 0, M1, M2, nb, M0, M1);      // the columns beyond
                 if (a_lo < nb) a_update(T, a_lo, nb, M0, M1);
             };
-            auto push_bulk = [&](int first, int count, int gfirst, int gcount) {
-                if (count <= 0 && gcount <= 0) return;
+            const int first = (int)p.tasks.size();
+            common();
+            by_length(first);
+            const int count = (int)p.tasks.size() - first;
+            int gfirst = 0, gcount = 0;
+            if (kinv_now) {   // the gradient variant of this launch: the same tasks + the K^-1 chunk, ordered as a whole
+                gfirst = (int)p.tasks.size();
+                kinv_update(T, kinv_lo, M1);
+                common();
+                by_length(gfirst);
+                gcount = (int)p.tasks.size() - gfirst;
+                kinv_lo = M1;
+            }
+            if (count > 0 || gcount > 0) {
                 Step st{};
                 st.kind = 1; st.tile = T; st.first = first; st.count = count; st.gfirst = gfirst; st.gcount = gcount;
                 st.a = st.b = st.c = st.c2 = BUF_A;
                 st.strm = 1;
                 p.steps.push_back(st);
                 bulk_steps.push_back(p.steps.size() - 1);
-            };
-            if (cols_stream) {
-                // rest_a: A's trailing update -- needs only chain(M), starts beside the column launch
-                if (n_a > 0) {
-                    T = pick_tile(p, n_a);
-                    const int first = (int)p.tasks.size();
-                    common_a();
-                    by_length(first);
-                    push_bulk(first, (int)p.tasks.size() - first, 0, 0);
-                }
-                // rest_b: B and K^-1 -- they read the rows of X^T the column launch produces
-                T = pick_tile(p, n_b + n_k);
-                const int first = (int)p.tasks.size();
-                common_b();
-                by_length(first);
-                const int count = (int)p.tasks.size() - first;
-                int gfirst = 0, gcount = 0;
-                if (kinv_now) {
-                    gfirst = (int)p.tasks.size();
-                    kinv_update(T, kinv_lo, M1);
-                    common_b();
-                    by_length(gfirst);
-                    gcount = (int)p.tasks.size() - gfirst;
-                    kinv_lo = M1;
-                }
-                const size_t before = bulk_steps.size();
-                push_bulk(first, count, gfirst, gcount);
-                if (bulk_steps.size() > before && colsx_step >= 0) {
-                    // waits for the column launch (which waited for the chain): its event, or a fresh one if it has none
-                    Step& cx = p.steps[(size_t)colsx_step];
-                    if (cx.rec_ev == 0) cx.rec_ev = bulk_event();
-                    p.steps[bulk_steps.back()].wait_ev = cx.rec_ev;
-                    rest_b_waits_colsx = true;
-                }
-            } else {
-                const int first = (int)p.tasks.size();
-                common_b();
-                common_a();
-                by_length(first);
-                const int count = (int)p.tasks.size() - first;
-                int gfirst = 0, gcount = 0;
-                if (kinv_now) {   // the gradient variant of this launch: the same tasks + the K^-1 chunk, ordered as a whole
-                    gfirst = (int)p.tasks.size();
-                    kinv_update(T, kinv_lo, M1);
-                    common_b();
-                    common_a();
-                    by_length(gfirst);
-                    gcount = (int)p.tasks.size() - gfirst;
-                    kinv_lo = M1;
-                }
-                push_bulk(first, count, gfirst, gcount);
             }
-            if (chunk_now) far_done = M1;
         }
-        if (!bulk_steps.empty() || colsx_step >= 0) {
+        if (!bulk_steps.empty()) {
             bulk_used = true;
             const int ev_chain = new_event(p);
             bulk_order.resize(ev_chain + 1, 0);
             p.steps[chain_last].rec_ev = ev_chain;            // chain(M) complete: L[:, M], X_MM, B's in-macro part are final
-            if (colsx_step >= 0) { p.steps[(size_t)colsx_step].wait_ev = ev_chain; cols_used = true; }
-            // the bulk stream's first step of this macro waits for the chain unless it already waits for the column launch
-            // (which implies the chain)
-            if (!bulk_steps.empty() && p.steps[bulk_steps.front()].wait_ev == 0) p.steps[bulk_steps.front()].wait_ev = ev_chain;
-            if (!last && !bulk_steps.empty()) {
+            p.steps[bulk_steps.front()].wait_ev = ev_chain;   // the bulk stream's first step of this macro waits for the chain
+            if (!last) {
                 ev_rest_prev = bulk_event();
                 Step& lastb = p.steps[bulk_steps.back()];
                 if (lastb.rec_ev == 0) lastb.rec_ev = ev_rest_prev; else lastb.rec_ev_final = ev_rest_prev;
-            } else if (!last) {
-                ev_rest_prev = 0;
             }
         } else if (!last) {
             ev_rest_prev = 0;
         }
-        (void)rest_b_waits_colsx;
     }
     if (nb <= MB) {
         // a single macro panel: its bulk work depends on the whole chain and nothing runs beside it -- keep it on the main
@@ -911,24 +790,12 @@ static void plan_sweep(Plan& p) {
         j.kind = 2;
         j.wait_ev = ev;
         p.steps.push_back(j);
-        if (cols_used) {   // the third stream joins as well (its last launch is normally implied by the bulk stream's last wait)
-            for (size_t i = p.steps.size(); i-- > 0;)
-                if (p.steps[i].strm == 2) {
-                    const int ev2 = new_event(p);
-                    if (p.steps[i].rec_ev == 0) p.steps[i].rec_ev = ev2; else p.steps[i].rec_ev_final = ev2;
-                    Step j2{};
-                    j2.kind = 2;
-                    j2.wait_ev = ev2;
-                    p.steps.push_back(j2);
-                    break;
-                }
-        }
     }
 }
 
 void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride) {
     p = Plan{};
-    p.t128_min = getenv("MFGP_T128_MIN") ? atoi(getenv("MFGP_T128_MIN")) : (nblk >= 56 ? 600 : 300);
+    p.t128_min = env_int("MFGP_T128_MIN", nblk >= 56 ? 600 : 300);
     p.nblk = nblk;
     p.ld = ld;
     p.stride = stride;

@@ -369,8 +369,71 @@ def _capped(f_fp, cap, x0):
 
 
 class _OptRun:
-    def __init__(self, x_opt, f_opt, n_evals, status):
+    def __init__(self, x_opt, f_opt, n_evals, status, background=False):
         self.x_opt, self.f_opt, self.n_evals, self.status = x_opt, f_opt, n_evals, status
+        self.background = background     # a randomized restart that ran beside the model's own sequential runs
+
+
+class LockstepEvaluator:
+    """Independent L-BFGS-B runs on ONE engine handle, one evaluation per run and round: every run asks for its next objective
+    (+ gradient) through `evaluate` and blocks; when all runs still alive have asked, the round goes to the GPU as ONE batched
+    pass (`Engine.eval_batch`: the B matrix sets side by side in every launch of the factorisation sweep) and everybody gets
+    its own result back.  The restarts of the reference's recipe (optimize_restarts(6, ...), src/abstractMFGP.py:137) are such
+    runs: by paramz' semantics they start from fresh N(0,1) draws and never look at each other.  A batched evaluation is
+    bitwise the single one, so every run takes exactly the steps it takes alone -- only the wall clock changes: at N <= 4096 one
+    evaluation leaves most of the GPU idle (its serial Cholesky chain), B of them cost little more than one."""
+
+    def __init__(self, engine, n_slots):
+        import threading
+        self._eng = engine
+        self._cv = threading.Condition()
+        self._active = int(n_slots)
+        self._pending = {}
+        self._results = {}
+        self.rounds = 0
+        self.evals = 0
+        self.round_sizes = []
+
+    def evaluate(self, slot, theta, noise, jitter):
+        """-> (nlml, grad) of THIS slot's point; raises NotPositiveDefinite for it alone"""
+        with self._cv:
+            self._pending[slot] = (np.array(theta, dtype=np.float64), float(noise), float(jitter))
+            if len(self._pending) >= self._active:
+                self._run_round()
+            while slot not in self._results:
+                self._cv.wait()
+            res = self._results.pop(slot)
+        if isinstance(res, BaseException):
+            raise res
+        return res
+
+    def retire(self, slot):
+        """this slot's run is over (it asks for nothing more): the others no longer wait for it"""
+        with self._cv:
+            self._active -= 1
+            if self._pending and len(self._pending) >= self._active:
+                self._run_round()
+
+    def _run_round(self):
+        # called with the lock held; every live run is blocked in evaluate(), so nothing else touches the engine
+        slots = sorted(self._pending)
+        reqs = [self._pending.pop(k) for k in slots]
+        cap = getattr(self._eng, "MAX_BATCH", 16)
+        try:
+            for c0 in range(0, len(slots), cap):
+                part, sl = reqs[c0:c0 + cap], slots[c0:c0 + cap]
+                nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
+                                                           [r[2] for r in part], want_grad=True)
+                for j, k in enumerate(sl):
+                    self._results[k] = (NotPositiveDefinite(int(status[j])) if status[j] != 0
+                                        else (float(nlml[j]), np.array(grads[j])))
+        except BaseException as ex:  # noqa: BLE001 - an engine error ends every run of the round, not just the caller's
+            for k in slots:
+                self._results.setdefault(k, ex)
+        self.rounds += 1
+        self.evals += len(slots)
+        self.round_sizes.append(len(slots))
+        self._cv.notify_all()
 
 
 class GPRegression:
@@ -407,6 +470,7 @@ class GPRegression:
         self._jitter_used = CONST_JITTER
         self._fail_count = 0
         self.optimization_runs = []
+        self._eval_hook = None     # (theta, noise, jitter) -> (nlml, grad): evaluations routed through a LockstepEvaluator
         self.n_evals = 0           # objective(+gradient) evaluations issued to the GPU
         self._main_evals = 0       # ... of those, the ones issued through this object's own state (not by background restarts)
         self.update_model = True
@@ -491,7 +555,13 @@ class GPRegression:
         jitter_extra, tries = 0.0, 0
         while True:
             try:
-                res = self._engine.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=want_grad)
+                if self._eval_hook is not None:
+                    # (the engine's own factorisation is NOT at these parameters afterwards: whoever installs the hook marks the
+                    # model dirty when taking it out)
+                    res = self._eval_hook(theta, noise, CONST_JITTER + jitter_extra)
+                    res = res if want_grad else res[0]
+                else:
+                    res = self._engine.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=want_grad)
                 self.n_evals += 1
                 self._main_evals += 1
                 break
@@ -578,9 +648,10 @@ class GPRegression:
         return run
 
     # ---- stateless objective: lets independent L-BFGS-B runs proceed concurrently on separate engines --------
-    def _stateless_objective(self, eng, free):
+    def _stateless_objective(self, eng, free, evaluate=None):
         """-> f_fp(x) evaluating NLML and its optimizer-space gradient on `eng` WITHOUT touching the model's
-        Param objects (free = the parameters x stands for; every other parameter keeps its current value)."""
+        Param objects (free = the parameters x stands for; every other parameter keeps its current value).
+        `evaluate(theta, noise, jitter) -> (nlml, grad)` replaces eng.eval where given (a LockstepEvaluator slot)."""
         params = self.parameters()
         base = {id(p): p.value for p in params}
         free_ids = [id(p) for p in free]
@@ -601,7 +672,10 @@ class GPRegression:
                 _check_parameters(theta, noise)
                 while True:
                     try:
-                        nlml, g = eng.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=True)
+                        if evaluate is not None:
+                            nlml, g = evaluate(theta, noise, CONST_JITTER + jitter_extra)
+                        else:
+                            nlml, g = eng.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=True)
                         self.n_evals += 1
                         break
                     except NotPositiveDefinite:
@@ -672,7 +746,7 @@ class GPRegression:
                 except _BudgetExhausted:
                     x_opt, f_opt = budget["x"], budget["f"]
                 with lock:
-                    self.optimization_runs.append(_OptRun(np.array(x_opt), float(f_opt), -1, "background"))
+                    self.optimization_runs.append(_OptRun(np.array(x_opt), float(f_opt), -1, "background", background=True))
                 return float(f_opt), np.array(x_opt), i
             finally:
                 pool_q.put(eng)
@@ -696,6 +770,71 @@ class GPRegression:
                     return [f.result() for f in futs]
                 finally:
                     ex.shutdown(wait=True)
+        return _Handle()
+
+    def start_lockstep_restarts(self, indices, lockstep, slots, free=None, rand_gen=None, max_iters=1000):
+        """The randomized restarts `indices` as lock-stepped runs: one thread per SLOT, every evaluation through
+        `lockstep.evaluate(slot, ...)` (a LockstepEvaluator over this model's engine, shared with whatever else -- the
+        caller's own sequential runs -- holds a slot of it); a slot takes the next restart still waiting when its run ends
+        and retires when none is left.  Same draws, same L-BFGS-B controls, same `eval_cap` as start_background_restarts;
+        .result() -> [(f_opt, x_opt, index), ...] after every slot has retired."""
+        import queue
+        import threading
+        free = list(free) if free is not None else self.parameters()
+        indices = list(indices)
+        starts = {}
+        for i in indices:  # draw in index order (deterministic with a seeded rand_gen(i))
+            gen = rand_gen(i) if callable(rand_gen) else None
+            draw = gen(size=len(free)) if gen is not None else np.random.normal(size=len(free))
+            starts[i] = _logexp_finv(_logexp_f(draw))   # the round trip randomize() + optimize() makes: bit-identical start
+        lock = threading.Lock()
+        out, errors = {}, {}
+        todo = queue.Queue()
+        for i in indices:
+            todo.put(i)
+
+        def worker(slot):
+            try:
+                while True:
+                    try:
+                        i = todo.get_nowait()
+                    except queue.Empty:
+                        return
+                    try:
+                        one(i, slot)
+                    except BaseException as ex:  # noqa: BLE001 - reported by result(); the slot goes on to the next restart
+                        errors[i] = ex
+            finally:
+                lockstep.retire(slot)
+
+        def one(i, slot):
+            count = {"n": 0}
+
+            def evaluate(theta, noise, jitter):
+                count["n"] += 1
+                return lockstep.evaluate(slot, theta, noise, jitter)
+
+            f_fp, budget = _capped(self._stateless_objective(None, free, evaluate=evaluate), self.eval_cap, starts[i])
+            try:
+                x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(f_fp, starts[i], maxfun=int(max_iters), maxiter=int(max_iters))
+                task = d.get("task", d.get("warnflag"))
+            except _BudgetExhausted:
+                x_opt, f_opt, task = budget["x"], budget["f"], "STOP: evaluation cap reached"
+            with lock:
+                self.optimization_runs.append(_OptRun(np.array(x_opt), float(f_opt), count["n"], task, background=True))
+                out[i] = (float(f_opt), np.array(x_opt), i)
+
+        threads = [threading.Thread(target=worker, args=(slot,), daemon=True) for slot in slots]
+        for t in threads:
+            t.start()
+
+        class _Handle:
+            def result(self_inner):
+                for t in threads:
+                    t.join()
+                if errors:
+                    raise errors[min(errors)]
+                return [out[i] for i in indices]
         return _Handle()
 
     def lend_engine(self, handle):

@@ -103,9 +103,26 @@ def make_case(name):
         c = make_case("matern52_mixed_n48")
         c.update(parts=composite(4, 1, M52, RBF | ARD, M32 | ARD), theta=[1.1, 1.3, 0.7, 0.8, 0.6, 1.2, 0.9, 0.5, 0.9, 0.7, 1.4, 0.65])
         return c
+    # mid-size vectors (round 4): several 128-blocks, so that the golden fixtures also cover the blocked factorisation -- stored
+    # compactly (no K / L: alpha, diag(L), NLML, gradient, mean and BOTH variance forms)
+    if name == "nargp_4d_n512":
+        X = rng.uniform(size=(512, 4)); Y = hf_4d(X)
+        Xa = np.hstack([X, lf_4d(X)[:, None]])
+        Xs = rng.uniform(size=(32, 4)); Xsa = np.hstack([Xs, lf_4d(Xs)[:, None]])
+        return dict(parts=composite(4, 1), theta=[1.2, 1.1, 0.9, 0.6, 0.4, 0.8], noise=0.01 * Y.var(), X=Xa, Y=Y, Xs=Xsa)
+    if name == "rbf_3d_n1024":
+        X = rng.uniform(size=(1024, 3)); Y = hf_3d(X)
+        return dict(parts=single(RBF, 3), theta=[1.0, 0.3], noise=0.01 * Y.var(), X=X, Y=Y, Xs=rng.uniform(size=(32, 3)))
+    if name == "matern52_mixed_ard_n1000":
+        X = rng.uniform(size=(1000, 4)); Y = hf_4d(X)
+        Xa = np.hstack([X, lf_4d(X)[:, None]])
+        Xs = rng.uniform(size=(32, 4)); Xsa = np.hstack([Xs, lf_4d(Xs)[:, None]])
+        return dict(parts=composite(4, 1, M52, RBF | ARD, M32), theta=[1.1, 1.3, 0.7, 0.8, 0.6, 1.2, 0.9, 0.5, 0.9], noise=0.02,
+                    X=Xa, Y=Y, Xs=Xsa)
     raise KeyError(name)
 
 
+MID_GOLDEN_CASES = ["nargp_4d_n512", "rbf_3d_n1024", "matern52_mixed_ard_n1000"]
 GOLDEN_CASES = ["rbf_3d_n50", "rbf_1d_forrester_lf", "nargp_1d_forrester_hf", "nargp_4d_n64", "gpdfc_2d_n40",
                 "gpdf_2d_n40", "matern32_3d_n48", "matern52_mixed_n48", "rbf_addnoise_n60",
                 "rbf_ard_3d_n50", "nargp_ard_4d_n64", "matern_ard_mixed_n48"]

@@ -194,7 +194,7 @@ extern "C" {
 // [3] = max |K^-1 - X^T X| / max |X^T X| (want_grad only), [4] = number of races, [5] = steps, [6] = tasks, [7] = events
 // numeric = 0: race check only (any size); 1: also execute.  slack = extra rows of capacity (stride = (ld + slack)^2).
 // mutate (self-test of the checker): 1 = the first bulk launch forgets to wait for the chain; 2 = the main stream forgets
-// the final join; 3 = the second macro's first leaf forgets its event wait; 4 / 5 = three-stream plans (see below)
+// the final join; 3 = the second macro's first leaf forgets its event wait
 int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double* report, char* msg, int msglen) {
     Sim s;
     s.ld = (int64_t)nblk * NB;
@@ -210,19 +210,6 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
         int seen = 0;
         for (Step& st : s.p.steps)
             if (st.strm == 0 && st.wait_ev > 0 && st.kind != 2 && ++seen == 1) { st.wait_ev = 0; break; }
-    } else if (mutate == 4) {   // three-stream plans: the second column launch forgets the chain
-        int seen = 0;
-        for (Step& st : s.p.steps)
-            if (st.strm == 2 && st.wait_ev > 0 && ++seen == 2) { st.wait_ev = 0; break; }
-    } else if (mutate == 5) {   // three-stream plans: a B / K^-1 launch forgets the column launch it reads from
-        int seen = 0;
-        for (size_t i = 0; i < s.p.steps.size(); ++i) {
-            Step& st = s.p.steps[i];
-            if (st.strm != 1 || st.wait_ev <= 0) continue;
-            bool from_cols = false;
-            for (const Step& o : s.p.steps) if (o.strm == 2 && o.rec_ev == st.wait_ev) from_cols = true;
-            if (from_cols && ++seen == 2) { st.wait_ev = 0; break; }
-        }
     }
     const Plan& p = s.p;
     s.cpr = (int)(s.ld / CELL);

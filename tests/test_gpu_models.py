@@ -173,22 +173,82 @@ def test_adaptation_improves_mse():
     model.close()
 
 
-def test_concurrent_restarts_give_the_sequential_result():
-    """restart_concurrency > 1 runs the randomized restarts on auxiliary engines beside the first run:
-    same runs, same winner (seeded per-restart draws), so the fitted parameters agree."""
+@pytest.mark.parametrize("n_hf", [150, 700, 1500])
+def test_concurrent_and_lockstep_restarts_give_the_sequential_result(n_hf):
+    """The three ways of running the recipe's 1 + 6 L-BFGS-B runs: sequentially (the reference's order), with the randomized
+    restarts on auxiliary engine handles in background threads (restart_concurrency), and in LOCK STEP on one handle -- every
+    round one batched pass (mfgp_eval_batch) over the live runs (restart_lockstep, the default).  Same runs, same steps: the
+    fitted parameters, every run's optimum and every run's evaluation count are IDENTICAL (bitwise), for every lock-step
+    width.  Sizes: one leaf block, a single macro panel, several macro panels on two streams."""
     import multifidelity_datafusion_gps_amd as mf
     rng = np.random.default_rng(21)
-    X_hf = rng.uniform(size=(150, 2))
-    out = []
-    for conc in (1, 3):
+    X_hf = rng.uniform(size=(n_hf, 2))
+    out = {}
+    for mode in ("sequential", "concurrent", "lockstep", "lockstep_w7", "lockstep_w2"):
         model = mf.NARGP(2, hf2, lf2, seed=5)
-        model.first_run_max_iters, model.restart_max_iters, model.restart_concurrency = 40, 40, conc
+        model.first_run_max_iters = model.restart_max_iters = 40
+        model.eval_cap = 12 if n_hf > 200 else None
+        model.restart_lockstep = mode.startswith("lockstep")
+        model.restart_concurrency = 3 if mode == "concurrent" else 1
+        model.lockstep_width = {"lockstep_w7": 7, "lockstep_w2": 2}.get(mode)
         model.fit(X_hf)
-        out.append(np.array([p.value for p in model.hf_model.parameters()]))
-        if conc > 1:
+        runs = sorted((r.f_opt, tuple(r.x_opt)) for r in model.hf_model.optimization_runs)
+        out[mode] = (np.array([p.value for p in model.hf_model.parameters()]), runs, model.hf_model.n_evals)
+        if mode == "concurrent":
             assert any(k.startswith("hf#") for k in model._engines)
+        if mode.startswith("lockstep"):
+            assert not any(k.startswith("hf#") for k in model._engines)          # one handle: the batch sets live inside it
+            ls = model.last_lockstep
+            assert ls.evals == sum(r.n_evals for r in model.hf_model.optimization_runs)
+            assert max(ls.round_sizes) == {"lockstep": 4, "lockstep_w7": 6, "lockstep_w2": 2}[mode]
+        mean, var = model.predict(X_hf[:20])                                       # the winner is installed and factorised
+        out[mode] += (mean, var)
         model.close()
-    np.testing.assert_allclose(out[1], out[0], rtol=1e-6)
+    ref = out["sequential"]
+    for mode, got in out.items():
+        assert np.array_equal(got[0], ref[0]), mode
+        assert got[1] == ref[1], mode
+        assert got[2] == ref[2], mode
+        assert np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4]), mode
+
+
+def test_batched_evaluation_is_bitwise_the_single_evaluation(engine):
+    """mfgp_eval_batch (B matrix sets side by side in every launch of the sweep) against B mfgp_eval calls: bitwise, at sizes on
+    both sides of the planner's regimes (one leaf, single macro panel, two streams, slim chain); a set whose Ky is not positive
+    definite reports its own status and leaves the others alone; the handle's own factorisation survives the batch."""
+    rng = np.random.default_rng(77)
+    parts = cases.composite(4, 1)
+    for N in (100, 900, 2100, 3200):
+        X = rng.uniform(size=(N, 4))
+        Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+        Y = cases.hf_4d(X)
+        engine.set_data(Xa, Y)
+        engine.set_kernel(parts)
+        B = 5
+        thetas = np.exp(rng.uniform(np.log(0.5), np.log(2.0), size=(B, 6)))
+        noises = np.exp(rng.uniform(np.log(1e-3), np.log(1e-1), size=B)) * Y.var()
+        engine.factorize(thetas[0], noises[0])
+        m0, v0 = engine.predict(Xa[:7])
+        f, g, st = engine.eval_batch(thetas, noises, 1e-8)
+        assert not st.any()
+        m1, v1 = engine.predict(Xa[:7])                       # the handle's own factorisation is untouched
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+        for b in range(B):
+            fb, gb = engine.eval(thetas[b], noises[b], 1e-8)
+            assert f[b] == fb and np.array_equal(g[b], gb), (N, b)
+        f2, _, st2 = engine.eval_batch(thetas[:2], noises[:2], 1e-8, want_grad=False)     # fewer sets, no gradient
+        assert not st2.any() and np.array_equal(f2, f[:2])
+    # one set not positive definite (duplicate rows, no noise, no jitter): its status only
+    Xd = Xa.copy(); Xd[5] = Xd[3]
+    engine.set_data(Xd, Y)
+    f, g, st = engine.eval_batch(thetas[:3], [noises[0], 0.0, noises[2]], [1e-8, 0.0, 1e-8])
+    assert st[0] == 0 and st[2] == 0 and 1 <= st[1] <= len(Y)
+    fb, gb = engine.eval(thetas[2], noises[2], 1e-8)
+    assert f[2] == fb and np.array_equal(g[2], gb)
+    with pytest.raises((RuntimeError, ValueError)):
+        engine.eval_batch(np.ones((17, 6)), np.ones(17))      # more than 16 sets
+    with pytest.raises((RuntimeError, ValueError)):
+        engine.eval_batch(-np.ones((2, 6)), np.ones(2))       # non-positive parameters
 
 
 def test_adapt_without_reoptimisation_uses_rank1_append():

@@ -5,8 +5,9 @@ size-independent properties.
 Stated fp64 tolerances (the oracle is "parity unpinned" w.r.t. GPy itself):
   K entries      abs <= 2e-13 * sigma^2 * (1 + 1/l^2)  (GPy's |x|^2+|x'|^2-2x.x' form loses ~eps|x|^2/l^2; ours does not)
   logdet, NLML   rel <= 1e-10 (noise >= 1e-4 var), <= 1e-7 in the add_noise regime (noise = 1e-6)
-  gradient       rel <= 1e-8 of the gradient's max-norm (1e-5 in the add_noise regime)
-  mean / var     abs <= 1e-9 * max(1, |y|_inf) (1e-6 in the add_noise regime)
+  gradient       PER COMPONENT |dg_k| <= 1e-8 * max(|g_k|, 1e-3 |g|_2) (1e-5 in the add_noise regime) -- tests/tolerances.py
+  mean / var     abs <= 1e-9 * max(1, |y|_inf) (1e-6 in the add_noise regime); the variance against BOTH predictive forms of the
+                 oracle: GPy's explicit-inverse form (`predict`: what the reference returns) and the triangular one
   L, alpha only through residuals: |L L^T - Ky|_F / |Ky|_F <= 1e-14 N ; |Ky alpha - y| / |y| <= 1e-12 * cond-ish
 """
 import os
@@ -16,9 +17,23 @@ import pytest
 
 from oracle import gp_oracle as orc
 from tests import cases
+from tests import tolerances as tol
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _check_all(parts, theta, noise, X, Y, st, Xs, nlml, grad, mean, var, label):
+    """the stated tolerances (tests/tolerances.py) against the oracle state `st`; the variance against BOTH of the oracle's
+    predictive forms -- GPy's explicit-inverse one (what the reference returns, src/MFDataFusion.py:156) and the triangular one"""
+    tol.check_nlml(nlml, st["nlml"], label=label)
+    tol.check_grad(grad, st["grad"], label=label)
+    mu, var_inv = orc.predict(parts, theta, noise, X, st, Xs)
+    _, var_tri = orc.predict_stable(parts, theta, noise, X, st, Xs)
+    ys = np.abs(Y).max()
+    tol.check_pred(mean, mu, ys, label=label, what="mean")
+    tol.check_pred(var, var_inv, ys, label=label, what="var_explicit_inverse")
+    tol.check_pred(var, var_tri, ys, label=label, what="var_triangular")
 
 
 def _run(engine, parts, theta, noise, X, Y, Xs):
@@ -47,12 +62,33 @@ def test_golden_vectors(engine, name):
     assert np.linalg.norm(L @ L.T - Ky) / np.linalg.norm(Ky) <= 1e-14 * N
     alpha = engine.get_alpha()
     assert np.linalg.norm(Ky @ alpha - g["Y"]) / np.linalg.norm(g["Y"]) <= 1e-11 * (1 if tight else 1e3)
-    assert nlml == pytest.approx(float(g["nlml"]), rel=1e-10 if tight else 1e-7)
-    gtol = (1e-8 if tight else 1e-5) * np.abs(g["grad"]).max()
-    np.testing.assert_allclose(grad, g["grad"], rtol=0, atol=gtol)
-    ytol = (1e-9 if tight else 1e-6) * max(1.0, np.abs(g["Y"]).max())
-    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=ytol)
-    np.testing.assert_allclose(var, g["var"], rtol=0, atol=ytol)
+    tol.check_nlml(nlml, float(g["nlml"]), rel=tol.NLML_REL if tight else tol.NLML_REL_ADDNOISE, label="golden/" + name)
+    tol.check_grad(grad, g["grad"], rel=tol.GRAD_REL if tight else tol.GRAD_REL_ADDNOISE, label="golden/" + name)
+    ys = np.abs(g["Y"]).max()
+    tol.check_pred(mean, g["mean"], ys, tol.PRED_ABS if tight else 1e-6, label="golden/" + name, what="mean")
+    tol.check_pred(var, g["var"], ys, tol.PRED_ABS if tight else 1e-6, label="golden/" + name, what="var_explicit_inverse")
+
+
+@pytest.mark.parametrize("name", cases.MID_GOLDEN_CASES)
+def test_mid_size_golden_vectors(engine, name):
+    """committed vectors at N = 512 .. 1024 (4 .. 8 leaf blocks: the blocked factorisation, not one leaf): NLML, log-det,
+    gradient per component, alpha, diag(L), the mean and BOTH variance forms (GPy's explicit inverse and the triangular one)"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    parts = [tuple(int(v) for v in p) for p in g["parts"]]
+    theta, noise = g["theta"], float(g["noise"])
+    nlml, grad, mean, var = _run(engine, parts, theta, noise, g["X"], g["Y"], g["Xs"])
+    lab = "golden/" + name
+    tol.check_nlml(nlml, float(g["nlml"]), label=lab)
+    tol.check_grad(grad, g["grad"], label=lab)
+    L = engine.get_L()
+    assert 2.0 * np.log(np.diag(L)).sum() == pytest.approx(float(g["logdet"]), rel=1e-10)
+    np.testing.assert_allclose(np.diag(L), g["diagL"], rtol=1e-9)
+    alpha = engine.get_alpha()
+    np.testing.assert_allclose(alpha, g["alpha"], rtol=0, atol=1e-16 * float(g["cond"]) * 10 * np.abs(g["alpha"]).max() + 1e-12)
+    ys = np.abs(g["Y"]).max()
+    tol.check_pred(mean, g["mean"], ys, label=lab, what="mean")
+    tol.check_pred(var, g["var"], ys, label=lab, what="var_explicit_inverse")
+    tol.check_pred(var, g["var_stable"], ys, label=lab, what="var_triangular")
 
 
 def _extended_precision_variance(K, noise, Kx, kss):
@@ -111,7 +147,7 @@ def test_kinv_and_state_machine(engine):
     with pytest.raises(RuntimeError):
         engine.get_Kinv()  # not computed yet
     g = engine.nlml_grad()  # lazily runs K^-1 + reduction
-    np.testing.assert_allclose(g, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    tol.check_grad(g, st["grad"])
     Kinv = engine.get_Kinv()
     np.testing.assert_allclose(Kinv, st["Kinv"], rtol=0, atol=1e-9 * np.abs(st["Kinv"]).max())
     engine.predict(c["Xs"])
@@ -134,9 +170,9 @@ def test_ragged_sizes_against_oracle(engine, N):
         mu, var = orc.predict(parts, theta, noise, X, st, Xs)
         nlml, grad, mean, v = _run(engine, parts, theta, noise, X, Y, Xs)
         assert nlml == pytest.approx(st["nlml"], rel=1e-10, abs=1e-10)
-        np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * max(1.0, np.abs(st["grad"]).max()))
-        np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-9)
-        np.testing.assert_allclose(v, var, rtol=0, atol=1e-9)
+        tol.check_grad(grad, st["grad"], label="ragged")
+        tol.check_pred(mean, mu, np.abs(Y).max(), label="ragged", what="mean")
+        tol.check_pred(v, var, label="ragged", what="var_explicit_inverse")
 
 
 def test_predict_many_rows_chunks_and_noise_flag(engine):
@@ -199,8 +235,8 @@ def test_refit_with_new_sizes_reuses_handle(engine):
         engine.set_data(Xall[:n], Yall[:n])
         nlml, grad = engine.eval(theta, 0.01)
         st = orc.inference(parts, theta, 0.01, Xall[:n], Yall[:n])
-        assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-        np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+        tol.check_nlml(nlml, st["nlml"])
+        tol.check_grad(grad, st["grad"])
 
 
 @pytest.mark.parametrize("N", [1000, 1600, 1700, 2500, 3100, 4200, 5200])
@@ -216,13 +252,9 @@ def test_medium_size_all_tile_paths(engine, N):
     st = orc.inference(parts, theta, noise, Xa, Y)
     Xs = rng.uniform(size=(300, 4))
     Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
-    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
     nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
     print("N=%d timings:" % N, engine.timings())
-    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
-    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
-    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
+    _check_all(parts, theta, noise, Xa, Y, st, Xsa, nlml, grad, mean, v, "medium/N=%d" % N)
 
 
 def test_bench_size_properties(engine):
@@ -251,7 +283,7 @@ def test_bench_size_properties(engine):
     engine.set_data(Xa[perm], Y[perm])
     nlml_p, grad_p = engine.eval(theta, noise)
     assert nlml_p == pytest.approx(nlml, rel=1e-10)
-    np.testing.assert_allclose(grad_p, grad, rtol=0, atol=1e-7 * np.abs(grad).max())
+    tol.check_grad(grad_p, grad, label="north_star/permutation")
     # directional central difference of the HIP objective
     d = rng.standard_normal(7)
     d /= np.linalg.norm(d)
@@ -325,7 +357,7 @@ def test_rank1_append_equals_fresh_factorisation(engine, engine_cls):
         np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
     g1 = engine.nlml_grad()                # the appended state also feeds the gradient path
     g2 = fresh.nlml_grad()
-    np.testing.assert_allclose(g1, g2, rtol=0, atol=1e-8 * np.abs(g2).max())
+    tol.check_grad(g1, g2)
     fresh.close()
     # a duplicate of an existing row with zero noise is not positive definite -> status > 1, state unchanged
     engine.set_data(X[:50], Y[:50])
@@ -398,10 +430,10 @@ def test_wide_inputs_up_to_the_column_limit(engine):
     Xs = rng.uniform(size=(11, 32))
     mu, var = orc.predict(parts, theta, noise, X, st, Xs)
     nlml, grad, mean, v = _run(engine, parts, theta, noise, X, Y, Xs)
-    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
-    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-9)
-    np.testing.assert_allclose(v, var, rtol=0, atol=1e-9)
+    tol.check_nlml(nlml, st["nlml"], label="wide_d32")
+    tol.check_grad(grad, st["grad"], label="wide_d32")
+    tol.check_pred(mean, mu, label="wide_d32", what="mean")
+    tol.check_pred(v, var, label="wide_d32", what="var_explicit_inverse")
     with pytest.raises(RuntimeError):
         engine.set_data(np.zeros((4, 33)), np.zeros(4))
 
@@ -514,13 +546,13 @@ def test_skinny_variance_path_for_small_batches(engine, N):
         assert np.array_equal(v, v2)                          # deterministic
     # the gradient after a skinny predict is still right (V overwrote the K^-1 storage -> recomputed lazily)
     nlml, grad = engine.eval(theta, noise, 1e-8, want_grad=True)
-    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-    assert np.abs(grad - st["grad"]).max() <= 1e-8 * np.abs(st["grad"]).max()
+    tol.check_nlml(nlml, st["nlml"])
+    tol.check_grad(grad, st["grad"], label="skinny/N=%d" % N)
     # ... and without a refactorisation in between: a lazy gradient straight after a skinny predict
     engine.factorize(theta, noise)
     engine.predict(Xs_all[:3])
     lazy = engine.nlml_grad()
-    assert np.abs(lazy - st["grad"]).max() <= 1e-8 * np.abs(st["grad"]).max()
+    tol.check_grad(lazy, st["grad"])
 
 
 def test_cfg2_single_rbf_n4096_against_oracle(engine):
@@ -531,10 +563,9 @@ def test_cfg2_single_rbf_n4096_against_oracle(engine):
     X = rng.uniform(size=(N, 3)); Y = cases.hf_3d(X)
     parts, theta, noise = cases.single(cases.RBF, 3), np.array([1.0, 0.3]), 1e-2 * Y.var()
     st = orc.inference(parts, theta, noise, X, Y)
-    engine.set_data(X, Y); engine.set_kernel(parts)
-    nlml, grad = engine.eval(theta, noise)
-    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    Xs = rng.uniform(size=(200, 3))
+    nlml, grad, mean, v = _run(engine, parts, theta, noise, X, Y, Xs)
+    _check_all(parts, theta, noise, X, Y, st, Xs, nlml, grad, mean, v, "cfg2/N=4096")      # incl. GPy's explicit-inverse variance
     L = engine.get_L()
     Ky = orc.cov(parts, theta, X) + (noise + 1e-8) * np.eye(N)
     assert np.linalg.norm(L @ L.T - Ky) / np.linalg.norm(Ky) <= 1e-14 * N
@@ -552,12 +583,8 @@ def test_slim_chain_regime_n6200_against_oracle(engine):
     st = orc.inference(parts, theta, noise, Xa, Y)
     Xs = rng.uniform(size=(70, 4))
     Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
-    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
     nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
-    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
-    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
-    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
+    _check_all(parts, theta, noise, Xa, Y, st, Xsa, nlml, grad, mean, v, "slim_chain/N=6200")
 
 
 def test_north_star_size_n8192_against_oracle(engine):
@@ -571,25 +598,22 @@ def test_north_star_size_n8192_against_oracle(engine):
     st = orc.inference(parts, theta, noise, Xa, Y)
     Xs = rng.uniform(size=(65, 4))
     Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
-    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
     nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
-    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
-    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
-    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
+    _check_all(parts, theta, noise, Xa, Y, st, Xsa, nlml, grad, mean, v, "north_star/N=8192")   # incl. GPy's explicit-inverse variance
 
 
 def test_randomised_parity_soak_across_planner_boundaries():
     """60 seeded random cases of tools/fuzz_parity.py (sizes 1 .. 2000 with the block counts at which the planner's defaults
     change over-represented; single / composite kernels of RBF / Matern-3/2 / -5/2 factors, isotropic or ARD; random
     hyper-parameters, noise from 1e-4 to 0.3 of Var(y); every fourth case a rank-1 append against the fused evaluation):
-    NLML 1e-9, gradient / mean / variance 1e-7 against the oracle.  (A 402-case, 4-minute run of the same generator:
-    0 mismatches, worst NLML 1.0e-10, gradient 2.0e-10, mean 1.8e-9, variance 1.4e-13 -- profiles/r03_fuzz_parity.txt.)"""
+    the stated tolerances (tests/tolerances.py: NLML 1e-10, gradient 1e-8 per component, mean / variance 1e-9 max(1, |y|), the
+    variance against both predictive forms of the oracle) times the case's conditioning factor (1 up to cond(Ky) ~ 1e7)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                                            "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    n, bad, worst = fz.run(seconds=120.0, seed=7, nmax=2000, max_cases=60, verbose=False)
+    n, bad, worst = fz.run(seconds=3600.0, seed=7, nmax=2000, max_cases=60, verbose=False)   # the count bounds it, not the clock
+    print("soak: worst error / tolerance", worst)
     assert n == 60 and not bad, bad[:3]

@@ -8,18 +8,15 @@ import pytest
 
 from oracle import gp_oracle as orc
 from tests import cases
+from tests import tolerances as tol
 
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [{}, {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "recursive"}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"},
-            {"MFGP_KINV_STREAM": "0"}, {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2", "MFGP_XPANEL_MERGE": "1"},
-            {"MFGP_CHAIN_SLIM": "1", "MFGP_T128_MIN": "8"}, {"MFGP_BULK_XCD": "0", "MFGP_BULK_BI": "2", "MFGP_BULK_BJ": "3"},
-            # round 3: the column launch on a third stream beside a split bulk launch; the 4-wave chain kernel; CUs kept out
-            # of the bulk stream's mask
-            {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "2"},
-            {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "3", "MFGP_CHAIN_SLIM": "1", "MFGP_CHAIN_WAVES": "4",
-             "MFGP_CHAIN_TILE": "64", "MFGP_T128_MIN": "8"},
-            {"MFGP_U_RESERVE": "1", "MFGP_CHAIN_SLIM": "1", "MFGP_CHAIN_WAVES": "4", "MFGP_CHAIN_TILE": "64"}]
+            {"MFGP_KINV_STREAM": "0"}, {"MFGP_MACRO": "4", "MFGP_SHIFT": "1"},
+            {"MFGP_CHAIN_SLIM": "1", "MFGP_T128_MIN": "8"}, {"MFGP_CHAIN_SLIM": "0", "MFGP_MACRO": "1"}]
+# (every switch the planner still reads -- plan.cpp's header comment; the variants rounds 1-3 measured and retired are recorded
+# in tools/gemm_lab/RETIRED.md)
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
@@ -47,17 +44,23 @@ def test_planner_variant_matches_oracle(engine_cls, env):
                 os.environ[k] = v
     e.set_kernel(parts)
     nlml, grad = e.eval(theta, noise, 1e-8)
-    assert nlml == pytest.approx(st["nlml"], rel=1e-10)
-    np.testing.assert_allclose(grad, st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    tol.check_nlml(nlml, st["nlml"])
+    tol.check_grad(grad, st["grad"])
     Kinv = e.get_Kinv()
     assert np.abs(Kinv - st["Kinv"]).max() <= 1e-9 * np.abs(st["Kinv"]).max()
     mean, v = e.predict(Xsa)
-    np.testing.assert_allclose(mean, mu, rtol=0, atol=1e-8)
-    np.testing.assert_allclose(v, var, rtol=0, atol=1e-8)
+    tol.check_pred(mean, mu, np.abs(Y).max(), what="mean")
+    tol.check_pred(v, var, np.abs(Y).max(), what="var")
     # the gradient-free factorisation + the lazy gradient (stand-alone K^-1 launch) give the same numbers
     e.factorize(theta, noise, 1e-8)
-    assert e.nlml() == pytest.approx(st["nlml"], rel=1e-10)
-    np.testing.assert_allclose(e.nlml_grad(), st["grad"], rtol=0, atol=1e-8 * np.abs(st["grad"]).max())
+    tol.check_nlml(e.nlml(), st["nlml"])
+    tol.check_grad(e.nlml_grad(), st["grad"])
+    # ... and so does the batched evaluation under this variant's plan: bitwise, three points at once
+    thetas = np.vstack([theta, theta * 1.1, theta * 0.9])
+    fb, gb, sb = e.eval_batch(thetas, [noise, 1.5 * noise, noise], 1e-8)
+    assert not sb.any() and fb[0] == nlml and np.array_equal(gb[0], grad)
+    f1, g1 = e.eval(thetas[1], 1.5 * noise, 1e-8)
+    assert fb[1] == f1 and np.array_equal(gb[1], g1)
     nlml2, grad2 = e.eval(theta, noise, 1e-8)
     assert nlml2 == nlml and np.array_equal(grad2, grad)        # deterministic
     e.close()

@@ -26,6 +26,26 @@ def test_oracle_reproduces_golden(name):
     np.testing.assert_allclose(var, g["var"], rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("name", cases.MID_GOLDEN_CASES)
+def test_oracle_reproduces_mid_size_golden(name):
+    """N = 512 .. 1024 vectors (compact: no K / L), both variance forms"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    c = cases.make_case(name)
+    assert np.array_equal(c["X"], g["X"]) and np.array_equal(c["Y"], g["Y"]) and np.array_equal(c["Xs"], g["Xs"])
+    parts = [tuple(p) for p in g["parts"]]
+    st = orc.inference(parts, g["theta"], float(g["noise"]), g["X"], g["Y"])
+    mu, var = orc.predict(parts, g["theta"], float(g["noise"]), g["X"], st, g["Xs"])
+    _, var_s = orc.predict_stable(parts, g["theta"], float(g["noise"]), g["X"], st, g["Xs"])
+    np.testing.assert_allclose(st["nlml"], g["nlml"], rtol=1e-12)
+    np.testing.assert_allclose(st["grad"], g["grad"], rtol=1e-8, atol=1e-9 * np.abs(g["grad"]).max())
+    np.testing.assert_allclose(st["alpha"], g["alpha"], rtol=0, atol=1e-8 * np.abs(g["alpha"]).max())
+    np.testing.assert_allclose(np.diag(st["L"]), g["diagL"], rtol=1e-10)
+    np.testing.assert_allclose(mu, g["mean"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(var, g["var"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(var_s, g["var_stable"], rtol=0, atol=1e-11)
+    assert np.abs(g["var"] - g["var_stable"]).max() <= 1e-9          # the two forms agree within the stated tolerance here
+
+
 @pytest.mark.parametrize("name", cases.GOLDEN_CASES)
 def test_gradient_matches_central_differences(name):
     c = cases.make_case(name)

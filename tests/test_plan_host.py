@@ -53,12 +53,9 @@ def _run(lib, specs, env=None):
 
 
 ENVS = [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}, {"MFGP_SHIFT": "0"}, {"MFGP_KINV_STREAM": "0"},
-        {"MFGP_T128_MIN": "10"}, {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2"}, {"MFGP_MACRO": "1", "MFGP_BULK_EVERY": "3"},
-        {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2", "MFGP_XPANEL_MERGE": "1", "MFGP_SHIFT": "0"},
-        {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0"}, {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "2"},
-        {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2", "MFGP_XPANEL_MERGE": "0"},
-        {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "1", "MFGP_KINV_STREAM": "0"},
-        {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "recursive"}]
+        {"MFGP_T128_MIN": "10"}, {"MFGP_MACRO": "1"}, {"MFGP_MACRO": "4", "MFGP_SHIFT": "1", "MFGP_CHAIN_SLIM": "1"},
+        {"MFGP_MACRO": "2", "MFGP_KINV_STREAM": "0", "MFGP_SHIFT": "0"},
+        {"MFGP_PLAN": "levels"}, {"MFGP_PLAN": "levels", "MFGP_MACRO": "2", "MFGP_SHIFT": "0"}, {"MFGP_PLAN": "recursive"}]
 
 
 @pytest.mark.parametrize("env", ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
@@ -75,9 +72,8 @@ def test_plans_factorise_invert_and_accumulate_kinv_without_races(simlib, env):
         assert rep[4] == 0
 
 
-@pytest.mark.parametrize("env", [{}, {"MFGP_SHIFT": "1"}, {"MFGP_SHIFT": "0"}, {"MFGP_MACRO": "6"}, {"MFGP_PLAN": "levels"},
-                                 {"MFGP_COLS_STREAM": "1"}, {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0"},
-                                 {"MFGP_COLS_STREAM": "1", "MFGP_CHAIN_WAVES": "4", "MFGP_MACRO": "5"}],
+@pytest.mark.parametrize("env", [{}, {"MFGP_SHIFT": "1"}, {"MFGP_SHIFT": "0"}, {"MFGP_MACRO": "6"}, {"MFGP_MACRO": "8", "MFGP_SHIFT": "0"},
+                                 {"MFGP_PLAN": "levels"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_schedules_of_the_bench_sizes_are_race_free(simlib, env):
     """race check only (no arithmetic) at the block counts of the BASELINE configurations: 32 (N = 4096), 47 / 48 / 49
@@ -94,13 +90,6 @@ def test_the_checker_catches_a_dropped_dependency(simlib):
     assert no_chain_wait[0] == 1 and no_chain_wait[1][4] > 0 and "race" in no_chain_wait[2]
     assert no_join[0] == -3 and "not joined" in no_join[2]
     assert no_leaf_wait[0] == 1 and no_leaf_wait[1][4] > 0
-    # the three-stream schedule: 4 = the column launch (third stream) forgets to wait for the chain; 5 = the B / K^-1 launch
-    # forgets to wait for the column launch whose rows of X^T it reads
-    env = {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0"}
-    ok3, no_cols_wait, no_x_wait = _run(simlib, [(16, 0, 1, 0, m) for m in (0, 4, 5)], env)
-    assert ok3[0] == 0
-    assert no_cols_wait[0] == 1 and no_cols_wait[1][4] > 0 and "race" in no_cols_wait[2]
-    assert no_x_wait[0] == 1 and no_x_wait[1][4] > 0 and "race" in no_x_wait[2]
 
 
 # ---- the same planner + checker under AddressSanitizer / UndefinedBehaviorSanitizer (CPU build) -------------
@@ -117,8 +106,8 @@ def asan_bin():
     return ASAN_BIN
 
 
-@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2", "MFGP_BULK_EVERY": "2"}, {"MFGP_SHIFT": "0"}, {"MFGP_PLAN": "levels"},
-                                 {"MFGP_PLAN": "recursive"}, {"MFGP_COLS_STREAM": "1", "MFGP_SHIFT": "0", "MFGP_MACRO": "2"}],
+@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_SHIFT": "0"}, {"MFGP_PLAN": "levels"},
+                                 {"MFGP_PLAN": "recursive"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0", "MFGP_KINV_STREAM": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_planner_and_checker_are_clean_under_asan_and_ubsan(asan_bin, env):
     """heap / stack overflows, use after free, signed overflow, misaligned or out-of-range accesses in plan.cpp while it

@@ -1,0 +1,115 @@
+"""The stated fp64 tolerances of the parity tests (BASELINE.md "Parity gate"), in one place, and a recorder of
+the errors actually measured (written to gpurun_out/parity_errors.json at the end of a GPU session: DESIGN.md section 5 quotes it).
+
+Normal-noise regime (sigma_n^2 >= 1e-4 sigma^2):
+    NLML, log-det   rel <= 1e-10
+    gradient        PER COMPONENT  |dg_k| <= 1e-8 * max(|g_k|, GRAD_FLOOR * |g|_2)
+                    (a component that is itself tiny against the gradient's norm cannot carry 8 digits of ITS OWN magnitude:
+                     every component is a sum of N^2 terms of the size of the largest one)
+    mean, variance  abs <= 1e-9 * max(1, |y|_inf)
+add_noise regime (sigma_n^2 = 1e-6, src/MFDataFusion.py:154-155; cond(Ky) ~ 1e9 .. 1e10):
+    NLML rel <= 1e-7, mean / variance abs <= 1e-7 * max(1, |y|_inf)  [SURVEY 8(c)]; gradient 1e-5 per component
+"""
+import atexit
+import json
+import os
+
+import numpy as np
+
+NLML_REL = 1e-10
+GRAD_REL = 1e-8
+GRAD_FLOOR = 1e-3
+PRED_ABS = 1e-9
+
+NLML_REL_ADDNOISE = 1e-7
+PRED_ABS_ADDNOISE = 1e-7
+GRAD_REL_ADDNOISE = 1e-5
+
+COND_KNEE = 1e7      # the normal-noise figures hold up to cond(Ky) ~ 1e7 and grow linearly with it beyond -- reaching the
+COND_CAP = 1e3       # add_noise figures (x 1e2 .. 1e3) at cond ~ 1e9 .. 1e10: both ends are SURVEY 8(c)'s
+
+
+def cond_bound(Ky_or_K, noise=None, jitter=1e-8):
+    """cheap upper bound of cond_2(Ky): |Ky|_1 / (sigma_n^2 + jitter) (lambda_max <= |.|_1, lambda_min >= the diagonal shift)"""
+    K = np.asarray(Ky_or_K)
+    shift = 0.0 if noise is None else noise + jitter
+    top = np.abs(K).sum(axis=1).max() + shift
+    lo = shift if noise is not None else np.linalg.eigvalsh(K)[0]
+    return float(top / lo)
+
+
+def cond_factor(cond):
+    """factor on the normal-noise tolerances for a case whose cond(Ky) bound is `cond`: two backward-stable fp64 evaluations of
+    the same quantity differ by O(eps * cond); 1e-9 is that figure at cond ~ 1e7"""
+    return float(np.clip(cond / COND_KNEE, 1.0, COND_CAP))
+
+
+EXPLICIT_INVERSE_C = 16.0
+
+
+def explicit_inverse_bound(cond, kss, y_scale=1.0, base=PRED_ABS):
+    """tolerance for a comparison with GPy's EXPLICIT-INVERSE predictive variance k** - kx^T Ky^-1 kx (oracle `predict`, what the
+    reference returns, src/MFDataFusion.py:156) when Ky is ill-conditioned.  That form carries an error of its own: dpotri's
+    Ky^-1 is accurate to eps * cond(Ky) relative, and the subtraction cancels k** ~ kx^T Ky^-1 kx almost entirely, so its
+    result is off by up to ~ eps * cond * k** whatever it is compared with (at cond ~ 1e10 it returns 1e-5 .. 1e-15 (clipped)
+    for variances that are ~ 1e-9: GPU run of round 4, cfg3's fitted level) -- the triangular form the HIP path computes does
+    not.  The bound is the stated tolerance, widened to EXPLICIT_INVERSE_C * eps * cond * k** where that is larger (measured
+    worst over the round-4 soak and configuration runs: ~ 5 eps cond k**; asserted at ~ 3 x that)."""
+    return max(base * max(1.0, float(y_scale)), EXPLICIT_INVERSE_C * np.finfo(np.float64).eps * float(cond) * float(kss))
+
+
+_measured = {}
+
+
+def _record(label, kind, ratio):
+    """ratio = measured error / stated tolerance (<= 1 passes)"""
+    if label is None:
+        return
+    slot = _measured.setdefault(label, {})
+    slot[kind] = max(float(ratio), slot.get(kind, 0.0))
+
+
+def grad_scale(g_ref, floor=GRAD_FLOOR):
+    g_ref = np.asarray(g_ref, dtype=np.float64)
+    return np.maximum(np.abs(g_ref), floor * np.linalg.norm(g_ref))
+
+
+def check_nlml(value, ref, rel=NLML_REL, label=None):
+    err = abs(value - ref) / abs(ref)
+    _record(label, "nlml_rel", err / rel)
+    assert err <= rel, "NLML %.15g vs %.15g: rel %.2e > %.1e" % (value, ref, err, rel)
+
+
+def check_grad(g, g_ref, rel=GRAD_REL, floor=GRAD_FLOOR, label=None):
+    g, g_ref = np.asarray(g, dtype=np.float64), np.asarray(g_ref, dtype=np.float64)
+    ratio = np.abs(g - g_ref) / grad_scale(g_ref, floor)
+    _record(label, "grad_rel_per_component", ratio.max() / rel)
+    assert np.all(ratio <= rel), "gradient: per-component error / scale = %s > %.1e (g = %s)" % (ratio, rel, g_ref)
+
+
+def check_pred(v, v_ref, y_scale=1.0, tol=PRED_ABS, label=None, what="pred"):
+    v, v_ref = np.asarray(v, dtype=np.float64).reshape(-1), np.asarray(v_ref, dtype=np.float64).reshape(-1)
+    bound = tol * max(1.0, float(y_scale))
+    err = np.abs(v - v_ref).max()
+    _record(label, what + "_abs", err / bound)
+    assert err <= bound, "%s: max abs error %.2e > %.1e" % (what, err, bound)
+
+
+def measured():
+    return _measured
+
+
+def _dump():
+    if not _measured:
+        return
+    out = os.environ.get("MFGP_PARITY_ERRORS", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                             "gpurun_out", "parity_errors.json"))
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        with open(out, "w") as f:
+            json.dump({"unit": "measured error / stated tolerance (<= 1 passes)", "cases": _measured}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+atexit.register(_dump)

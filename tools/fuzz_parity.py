@@ -1,7 +1,9 @@
 """Randomised parity soak on the GPU box: random sizes (block-count boundaries of the planner included), random kernel
 structures (single / composite, RBF / Matern-3/2 / -5/2, isotropic / ARD), random hyper-parameters and noise levels; the HIP
-engine against the numpy/LAPACK oracle on NLML, gradient, alpha (through K^-1 y), predictive mean and variance -- and, every few
-cases, a rank-1 append against a fresh factorisation.  usage: fuzz_parity.py [seconds=120] [seed=0] [nmax=3000]"""
+engine against the numpy/LAPACK oracle on NLML, gradient (per component), predictive mean and variance (against BOTH of the
+oracle's predictive forms: GPy's explicit inverse and the triangular one) -- and, every few cases, a rank-1 append against a
+fresh factorisation.  Errors are reported in units of the stated tolerances (tests/tolerances.py) times the case's conditioning
+factor: <= 1 passes.  usage: fuzz_parity.py [seconds=120] [seed=0] [nmax=3000]"""
 import os
 import sys
 import time
@@ -11,6 +13,7 @@ import numpy as np  # noqa: E402
 from multifidelity_datafusion_gps_amd._lib import Engine  # noqa: E402
 from oracle import gp_oracle as orc  # noqa: E402
 from tests import cases  # noqa: E402
+from tests import tolerances as tol  # noqa: E402
 
 BOUNDARY_NB = [1, 2, 3, 4, 5, 8, 12, 13, 14, 15, 23, 24, 25, 26, 47, 48, 49, 55, 56, 57]   # planner defaults change around these block counts
 
@@ -46,7 +49,7 @@ def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
     """-> (number of cases, list of mismatches, worst relative errors)"""
     rng = np.random.default_rng(seed)
     e, fresh = Engine(0), Engine(0)
-    t0, n, worst = time.time(), 0, dict(nlml=0.0, grad=0.0, mean=0.0, var=0.0, append=0.0)
+    t0, n, worst = time.time(), 0, dict(nlml=0.0, grad=0.0, mean=0.0, var=0.0, var_inv=0.0, inv_c=0.0, append=0.0)
     bad = []
     while time.time() - t0 < seconds and (max_cases is None or n < max_cases):
         c = random_case(rng, nmax)
@@ -55,20 +58,30 @@ def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
         e.set_data(c["X"], c["Y"]); e.set_kernel(c["parts"])
         nlml, grad = e.eval(c["theta"], c["noise"], 1e-8)
         m, v = e.predict(c["Xs"])
-        gs = max(1.0, np.abs(st["grad"]).max())
-        err = dict(nlml=abs(nlml - st["nlml"]) / max(1.0, abs(st["nlml"])), grad=np.abs(grad - st["grad"]).max() / gs,
-                   mean=np.abs(m - mu).max() / max(1.0, np.abs(c["Y"]).max()), var=np.abs(v - var).max(), append=0.0)
+        _, var_inv = orc.predict(c["parts"], c["theta"], c["noise"], c["X"], st, c["Xs"])      # GPy's explicit-inverse form
+        ys = max(1.0, np.abs(c["Y"]).max())
+        # errors in units of the stated tolerances (tests/tolerances.py): NLML rel 1e-10, gradient per component 1e-8, mean /
+        # variance 1e-9 max(1, |y|) -- each times the case's conditioning factor (1 up to cond(Ky) ~ 1e7)
+        cond = tol.cond_bound(st["K"], c["noise"])
+        cf = tol.cond_factor(cond)
+        kss = orc.cov_diag(c["parts"], c["theta"], 1)[0]
+        err = dict(nlml=abs(nlml - st["nlml"]) / max(1.0, abs(st["nlml"])) / (tol.NLML_REL * cf),
+                   grad=(np.abs(grad - st["grad"]) / tol.grad_scale(st["grad"])).max() / (tol.GRAD_REL * cf),
+                   mean=np.abs(m - mu).max() / (tol.PRED_ABS * ys * cf),
+                   var=np.abs(v - var).max() / (tol.PRED_ABS * ys * cf),
+                   # GPy's explicit-inverse form: the stated tolerance, widened by that form's own eps * cond * k** error
+                   var_inv=np.abs(v - var_inv).max() / tol.explicit_inverse_bound(cond, kss, ys, tol.PRED_ABS * cf),
+                   inv_c=np.abs(v - var_inv).max() / (np.finfo(float).eps * cond * kss), append=0.0)
         if n % 4 == 0 and c["N"] >= 2:          # rank-1 append of the last row against the fused evaluation of all rows
             fresh.set_data(c["X"][:-1], c["Y"][:-1]); fresh.set_kernel(c["parts"])
             fresh.eval(c["theta"], c["noise"], 1e-8, want_grad=False)
             if fresh.append_row(c["X"][-1], float(c["Y"][-1])):
                 m2, v2 = fresh.predict(c["Xs"])
-                err["append"] = max(np.abs(m2 - m).max() / max(1.0, np.abs(c["Y"]).max()), np.abs(v2 - v).max())
+                err["append"] = max(np.abs(m2 - m).max(), np.abs(v2 - v).max()) / (tol.PRED_ABS * ys * cf)
         scale = float(os.environ.get("FUZZ_TOL_SCALE", "1"))
-        tol = {k: v * scale for k, v in dict(nlml=1e-9, grad=1e-7, mean=1e-7, var=1e-7, append=1e-7).items()}
         for k in worst:
             worst[k] = max(worst[k], float(err[k]))
-        if any(not (err[k] <= tol[k]) for k in tol):
+        if any(not (err[k] <= scale) for k in err if k != "inv_c"):     # (inv_c: |var - explicit inverse| in units of eps cond k**, reported only)
             bad.append((n, c["N"], c["D"], c["parts"], [float(x) for x in c["theta"]], c["noise"], {k: float(x) for k, x in err.items()}))
             if verbose:
                 print("MISMATCH", bad[-1], flush=True)
@@ -77,7 +90,7 @@ def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
             print("%d cases, %.0f s, worst so far %s" % (n, time.time() - t0, {k: "%.1e" % x for k, x in worst.items()}), flush=True)
     e.close(); fresh.close()
     if verbose:
-        print("fuzz_parity: %d cases in %.0f s (seed %d, N <= %d), %d mismatches; worst relative errors %s"
+        print("fuzz_parity: %d cases in %.0f s (seed %d, N <= %d), %d mismatches; worst error / tolerance %s"
               % (n, time.time() - t0, seed, nmax, len(bad), {k: "%.2e" % x for k, x in worst.items()}))
     return n, bad, worst
 

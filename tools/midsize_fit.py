@@ -1,5 +1,7 @@
-"""A mid-size fit as a user of the reference would run it (the ARD recipe: 1 + 6 L-BFGS-B runs, here with a budget of 50
-evaluations per run), sequential restarts against concurrent ones.  usage: midsize_fit.py N_hf [N_hf ...]"""
+"""A mid-size fit as a user of the reference would run it (the ARD recipe: 1 + 6 L-BFGS-B runs, here with a budget of --evals
+evaluations per run): sequential restarts (the reference's order), concurrent ones on auxiliary handles (round 3) and the
+LOCK-STEPPED runs over one batched evaluation per round (round 4, the default).
+usage: midsize_fit.py [--evals E] N_hf [N_hf ...]"""
 import os
 import sys
 import time
@@ -14,14 +16,19 @@ def col(f):
     return lambda x: f(x)[:, None]
 
 
-for n_hf in [int(a) for a in sys.argv[1:]] or [1024]:
+argv = sys.argv[1:]
+evals = 50
+if argv and argv[0] == "--evals":
+    evals = int(argv[1]); argv = argv[2:]
+MODES = [("sequential", dict(restart_lockstep=False, restart_concurrency=1)),
+         ("concurrent 2", dict(restart_lockstep=False, restart_concurrency=2)),
+         ("lockstep w4", dict(restart_lockstep=True)), ("lockstep w7", dict(restart_lockstep=True, lockstep_width=7))]
+print("# python3 tools/midsize_fit.py --evals %d ...: one fit of the reference's ARD recipe (1 + 6 L-BFGS-B runs, %d evaluations each), HF level only timed" % (evals, evals))
+for n_hf in [int(a) for a in argv] or [1024]:
     line = "N_hf=%d (N_lf=%d):" % (n_hf, 2 * n_hf)
     ref = None
-    for conc in (1, 2, 3):
-        class M(mf.NARGP):
-            lf_max_iters = first_run_max_iters = restart_max_iters = 50
-            eval_cap = 50
-            restart_concurrency = conc
+    for name, kw in MODES:
+        M = type("M", (mf.NARGP,), dict(lf_max_iters=evals, first_run_max_iters=evals, restart_max_iters=evals, eval_cap=evals, **kw))
         rng = np.random.default_rng(1)
         X_lf = rng.uniform(size=(2 * n_hf, 4))
         m = M(4, col(cases.hf_4d), None, lf_X=X_lf, lf_Y=col(cases.lf_4d)(X_lf), seed=3)
@@ -33,6 +40,7 @@ for n_hf in [int(a) for a in sys.argv[1:]] or [1024]:
         th = np.array([p.value for p in m.hf_model.parameters()])
         if ref is None:
             ref = th
-        line += "  conc %d: %.0f ms (%d evals)%s" % (conc, dt * 1e3, m.hf_model.n_evals, "" if np.array_equal(th, ref) else " DIFFERENT theta")
+        line += "  %s: %.0f ms (%d evals)%s" % (name, dt * 1e3, m.hf_model.n_evals, "" if np.array_equal(th, ref) else " DIFFERENT theta")
         m.close()
     print(line, flush=True)
+print("# identical fitted hyper-parameters in every column (bit for bit) unless a column says otherwise")
