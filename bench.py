@@ -74,6 +74,9 @@ def one_step(args, comm, engines, data):
         restart_max_iters = args.evals
         num_restarts = args.restarts
         restart_concurrency = args.concurrency
+        restart_lockstep = bool(args.lockstep)
+        lockstep_lanes = args.lanes if args.lanes > 0 else None
+        lockstep_width = args.width if args.width > 0 else None
         restart_aux = args.aux if args.aux > 0 else None
         restart_lend_main = bool(args.lend_main)
         eval_cap = args.evals          # exact: scipy's maxfun alone lets a run overshoot by a line search
@@ -87,8 +90,12 @@ def one_step(args, comm, engines, data):
     mean, var = model.predict(X_st)
     t3 = time.perf_counter()
     # the sequential pieces of the job: the LF run, rank 0's first HF run -> restart 0, the predict
-    chain_evals = sum(r.n_evals for r in model.hf_model.optimization_runs if r.n_evals >= 0)
+    chain_evals = sum(r.n_evals for r in model.hf_model.optimization_runs if not r.background)
     model.phase = {"lf_ms": (t1 - t0) * 1e3, "fit_ms": (t2 - t1) * 1e3, "predict_ms": (t3 - t2) * 1e3, "chain_evals": chain_evals}
+    lanes = getattr(model, "last_lockstep_lanes", None)
+    if lanes:
+        model.phase["lockstep"] = [{"rounds": ls.rounds, "evaluations": ls.evals, "engine_ms": round(ls.engine_s * 1e3, 1),
+                                    "largest_round": max(ls.round_sizes) if ls.round_sizes else 0} for ls in lanes]
     return mean, var, model
 
 
@@ -370,8 +377,13 @@ def main():
     ap.add_argument("--evals", type=int, default=20, help="objective evaluations per L-BFGS-B run")
     ap.add_argument("--restarts", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--lockstep", type=int, default=1,
+                    help="1 (default): the HF level's 1 + 6 runs as lock-stepped runs over batched evaluations (mfgp_eval_batch); "
+                         "0: round 3's concurrent restarts on auxiliary handles (--concurrency)")
+    ap.add_argument("--lanes", type=int, default=0, help="engine handles the lock-stepped runs are dealt to (0: the model's default: 1 at N >= 6144, else 2)")
+    ap.add_argument("--width", type=int, default=0, help="live lock-step slots per rank (0: half the rank's runs, rounded up)")
     ap.add_argument("--concurrency", type=int, default=2,
-                    help="randomized restarts in flight beside the main run (auxiliary engine handles per rank)")
+                    help="--lockstep 0 only: randomized restarts in flight beside the main run (auxiliary engine handles per rank)")
     ap.add_argument("--aux", type=int, default=0, help="auxiliary engine handles of the concurrent restarts (0: --concurrency of them)")
     ap.add_argument("--aux-order", default="natural", choices=["natural", "reversed"])
     ap.add_argument("--lend-main", type=int, default=0, help="1: the main engine joins the restarts' pool after restart 0")
@@ -415,7 +427,9 @@ def main():
     # creation ORDER matters: HIP maps the handles' streams onto its hardware queues by creation, and handles that share a queue
     # serialise (tools/queue_pairs.py: of four handles created back to back, 0 + 3 and 1 + 2 share).  --aux-order reversed creates
     # hf#2 before hf#1, so that the first auxiliary handle lands on the lane the main handle (hf) is NOT on.
-    js = list(range(1, args.concurrency + 1 if args.concurrency > 1 else 1))
+    lanes = args.lanes if args.lanes > 0 else (2 if args.n < 6144 else 1)
+    n_aux = (lanes - 1) if args.lockstep else (args.concurrency if args.concurrency > 1 else 0)
+    js = list(range(1, n_aux + 1))
     for j in (reversed(js) if args.aux_order == "reversed" else js):
         engines["hf#%d" % j] = Engine(local_rank)
     collectives = "none (1 rank)"
@@ -511,9 +525,13 @@ def main():
                        "evals_issued_rank0_per_step": evals / args.steps,
                        "gpu_ms_per_evaluation": (round(tot["total_ms"] / tot["timed_evals"], 3) if tot["timed_evals"] else None),
                        "wall_ms_per_evaluation": round(ms_per_step * args.steps / max(evals, 1), 3),
-                       "restart_concurrency": args.concurrency, "collectives": collectives,
+                       "restarts_run_as": ("lock-stepped runs over batched evaluations (mfgp_eval_batch): %d lanes, %s live slots"
+                                           % (lanes, args.width or "auto")) if args.lockstep
+                                          else "concurrent restarts on %d auxiliary handles" % args.concurrency,
+                       "restart_concurrency": None if args.lockstep else args.concurrency, "collectives": collectives,
                        "ranks": world, "rccl_ranks": int(engines["hf"].comm_size),
-                       "sharding": "randomized restarts + predictive rows over ranks; LF run replicated; first HF run -> restart 0 on rank 0 only"},
+                       "sharding": "randomized restarts + predictive rows over ranks; LF run on rank 0 (the others adopt its optimum); "
+                                   "first HF run -> restart 0 on rank 0 only"},
             # the dominant work: ONE sweep per evaluation = Cholesky + triangular inverse%s, timed with HIP events on the
             # engine's main stream around the sweep (the bulk stream joins before the closing event)
             "roofline": {"kernel": "factorisation sweep per evaluation: mfgp_leaf_cholinv_f64 + mfgp_gemm_nt_f64_{t128,t64,chain} on v_mfma_f64_4x4x4_4b "
@@ -526,8 +544,8 @@ def main():
                          "traffic": pmc_traffic("sweep", args.n), "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes over "
                          "tools/time_eval.py, committed; not measured by this run)",
                          "launches": int(evals), "flops_per_launch": tot["cholinv_flops"] / max(evals, 1),
-                         "achieved_is": "all sweep flops of the timed region / its wall time (%d evaluations in flight at once: "
-                                        "their launch intervals overlap)" % (1 + max(args.concurrency, 0) if args.concurrency > 1 else 1),
+                         "achieved_is": "all sweep flops of the timed region / its wall time (several evaluations are in flight at once -- "
+                                        "batched passes on %d lanes -- so per-launch intervals overlap)" % (lanes if args.lockstep else 1 + args.concurrency),
                          "per_launch_overlapped": {"avg_launch_ms": round(tot["cholinv_ms"] / max(evals, 1), 4),
                                                    "achieved": round(sweep_tf_launch, 2),
                                                    "note": "HIP events around each sweep on its engine's stream; the interval "
@@ -535,7 +553,7 @@ def main():
                          "uncontended": {"achieved": round(sweep_tf_alone, 2), "frac": round(sweep_tf_alone / FP64_PEAK_TFLOPS, 4),
                                          "launches": int(clf["evals"]), "avg_launch_ms": round(clf["cholinv_ms"] / max(clf["evals"], 1), 4),
                                          "note": "the LF level's evaluations only: they run alone on the GPU; the HF level's "
-                                                 "overlap with %d concurrent restarts" % max(args.concurrency, 0)}},
+                                                 "run batched / beside other lanes"}},
             "roofline_predvar": {"kernel": "mfgp_predvar_f64 (V = K(X*,X) L^-T, one launch per predict)", "bound": "mfma",
                                  "achieved": round(pv_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(pv_tf / FP64_PEAK_TFLOPS, 4), "traffic": pmc_traffic("mfgp_predvar_f64", args.n),
@@ -556,13 +574,14 @@ def main():
         # Amdahl floor of the strong-scaling curve, from THIS run's measurements on rank 0: the LF run and the first HF run ->
         # restart 0 are sequential chains of evaluations no rank count shortens (priced at the uncontended time per evaluation:
         # on N > 1 GPUs rank 0's chain runs alone), the predict is what this run measured for its row share
-        alone_ms = clf["total_ms"] / max(clf["evals"], 1)
+        alone_ms = (clf["total_ms"] / clf["timed_evals"]) if clf["timed_evals"] else None     # (below N = 4096 nothing is timed)
         lf_ms = float(np.mean([p["lf_ms"] for p in phases]))
         chain_evals = float(np.mean([p["chain_evals"] for p in phases]))
         predict_ms = float(np.mean([p["predict_ms"] for p in phases]))
-        out["serial_floor_ms"] = round(lf_ms + chain_evals * alone_ms + predict_ms, 1)
+        out["serial_floor_ms"] = round(lf_ms + chain_evals * alone_ms + predict_ms, 1) if alone_ms is not None else None
         out["serial_floor"] = {"lf_run_ms": round(lf_ms, 1), "hf_chain_evaluations": chain_evals,
-                               "ms_per_evaluation_alone": round(alone_ms, 3), "hf_chain_ms": round(chain_evals * alone_ms, 1),
+                               "ms_per_evaluation_alone": round(alone_ms, 3) if alone_ms is not None else None,
+                               "hf_chain_ms": round(chain_evals * alone_ms, 1) if alone_ms is not None else None,
                                "predict_ms_this_run": round(predict_ms, 1), "fit_ms_this_run": round(float(np.mean([p["fit_ms"] for p in phases])), 1),
                                "note": "value cannot fall below serial_floor_ms however many GPUs share the restarts and the "
                                        "predictive rows (the first HF run and restart 0 are one chain of %d + %d evaluations)"
@@ -571,6 +590,8 @@ def main():
             out["roofline_kinv"] = {"kernel": "mfgp_kinv_syrk_f64 (stand-alone K^-1 launch)", "bound": "mfma",
                                     "achieved": round(kinv_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(kinv_tf / FP64_PEAK_TFLOPS, 4)}
+        if phases and "lockstep" in phases[-1]:
+            out["lockstep_last_step"] = phases[-1]["lockstep"]
         if power is not None:
             out["power"] = power
         if rowblock is not None:

@@ -43,6 +43,11 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     lockstep_width = None       # live slots per round (None: half this rank's runs, rounded up -- 4 for the recipe's 1 + 6 runs: the
                                 # sequential pair first run -> restart 0 in one slot, the five randomized restarts 2 + 2 + 1 in three
                                 # more, so every round carries 3-4 evaluations instead of 6 for one half of the fit and 1 for the other)
+    lockstep_lanes = None       # engine handles the live slots are dealt to (each lane batches ITS slots' evaluations: a lane's serial
+                                # chain then overlaps another lane's bulk work, and the hosts' L-BFGS-B steps of one lane the GPU pass
+                                # of another).  None: 2 below N = 6144 (fits 8-15 % faster than on one lane at N = 1024 .. 4096,
+                                # profiles/r04_midsize_fit.txt), 1 from there (N = 8192: the job sits at the socket's power cap
+                                # either way; one lane of 4 evaluations measured 1 % ahead of 2 x 2)
     restart_lend_main = False   # the main engine joins the restarts' pool once its sequential runs are through
     restart_aux = None          # auxiliary engine handles of the concurrent restarts (None: restart_concurrency of them)
     diagonal_points = 1000      # resolution of the box diagonal the adaptation loop predicts on every step (:318)
@@ -226,11 +231,21 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         width = int(self.lockstep_width) if self.lockstep_width else (n_runs + 1) // 2
         n_bg_slots = min(len(mine_bg), max(width - own, 1 if mine_bg else 0))
         n_slots = n_bg_slots + own
-        lockstep = gp.LockstepEvaluator(model._engine, n_slots) if n_slots else None
+        # deal the slots to the lanes: lane 0 = the model's own handle (slot 0, the sequential pair, lives there)
+        want_lanes = int(self.lockstep_lanes) if self.lockstep_lanes else (2 if len(model.X) < 6144 else 1)
+        n_lanes = max(1, min(want_lanes, n_slots))
+        per_lane = [[k for k in range(n_slots) if k % n_lanes == j] for j in range(n_lanes)]
+        tag = self._level_of(model)
+        engines = [model._engine] + [self._engine("%s#%d" % (tag, j)) for j in range(1, n_lanes)]
+        for e in engines[1:]:
+            e.set_data(model.X, model.Y[:, 0])
+            e.set_kernel(model._parts)
+        lanes = [gp.LockstepEvaluator(e, len(sl)) for e, sl in zip(engines, per_lane)]
+        lockstep = lanes[0] if lanes else None
         handle = None
         if mine_bg:
-            handle = model.start_lockstep_restarts(mine_bg, lockstep, slots=list(range(1, n_bg_slots + 1)),
-                                                   free=list(model.parameters()),      # all free during the restarts
+            bg = [(ls, [k for k in sl if not (own and k == 0)]) for ls, sl in zip(lanes, per_lane)]
+            handle = model.start_lockstep_restarts(mine_bg, bg, free=list(model.parameters()),      # all free during the restarts
                                                    rand_gen=self._restart_rng(), max_iters=self.restart_max_iters)
         runs = []
         try:
@@ -251,6 +266,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         if handle is not None:
             runs += handle.result()
         self.last_lockstep = lockstep
+        self.last_lockstep_lanes = lanes
         if size > 1:
             runs = [r for part in self.comm.allgather_object(runs) for r in part]
         if runs:

@@ -284,10 +284,12 @@ struct Rbf2Spec {
     int32_t a0, a1, b0, b1, has2, D;
 };
 
+struct Rbf2Batch { Rbf2Spec s[MFGP_BATCH_MAX]; };   // the parameter sets of a batched evaluation, by value (1.1 KB of kernel arguments)
+
 template <int MODE>
-__global__ __launch_bounds__(256) void mfgp_kbuild_rbf2_f64(Rbf2Spec sp, const double* __restrict__ Xr,
-                                                            const double* __restrict__ Xc, int N, int Np,
-                                                            double* __restrict__ out, int ld, int row_tile0) {
+__device__ __forceinline__ void kbuild_rbf2_body(const Rbf2Spec& sp, const double* __restrict__ Xr,
+                                                 const double* __restrict__ Xc, int N, int Np,
+                                                 double* __restrict__ out, int ld, int row_tile0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sxi = smem;
     double* sxj = smem + sp.D * XP;
@@ -354,6 +356,19 @@ __global__ __launch_bounds__(256) void mfgp_kbuild_rbf2_f64(Rbf2Spec sp, const d
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void mfgp_kbuild_rbf2_f64(Rbf2Spec sp, const double* __restrict__ Xr,
+                                                            const double* __restrict__ Xc, int N, int Np,
+                                                            double* __restrict__ out, int ld, int row_tile0) {
+    kbuild_rbf2_body<MODE>(sp, Xr, Xc, N, Np, out, ld, row_tile0);
+}
+// the lower-triangle build for the B parameter sets of a batched evaluation: blockIdx.y = set, its matrix bstride elements on
+__global__ __launch_bounds__(256) void mfgp_kbuild_rbf2_batch_f64(Rbf2Batch specs, const double* __restrict__ X, int N, int Np,
+                                                                  double* __restrict__ out, int ld, long long bstride) {
+    const Rbf2Spec sp = specs.s[blockIdx.y];
+    kbuild_rbf2_body<MODE_TRI>(sp, X, X, N, Np, out + blockIdx.y * bstride, ld, 0);
+}
+
 // does the description match the fast path?  (host side; the generic kernel remains for everything else: Matern factors,
 // other products / sums)
 static bool rbf2_match(const KernSpecDev& s, Rbf2Spec& o) {
@@ -393,6 +408,19 @@ void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X,
     }
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_TRI>), dim3(nt * (nt + 1) / 2), dim3(256), kb_lds(spec.D), s,
                        spec, X, X, N, Np, A, ld, 0);
+}
+void launch_kbuild_tri_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, int N, int Np, double* A,
+                             int ld, long long bstride) {
+    const int nt = Np / KT;
+    Rbf2Batch fb;
+    bool fast = nbatch <= MFGP_BATCH_MAX;
+    for (int b = 0; fast && b < nbatch; ++b) fast = rbf2_match(specs[b], fb.s[b]);
+    if (fast) {
+        hipLaunchKernelGGL(mfgp_kbuild_rbf2_batch_f64, dim3(nt * (nt + 1) / 2, nbatch), dim3(256), kb_lds(specs[0].D), s, fb, X, N,
+                           Np, A, ld, bstride);
+        return;
+    }
+    for (int b = 0; b < nbatch; ++b) launch_kbuild_tri(s, specs[b], X, N, Np, A + b * bstride, ld);
 }
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
                          const double* X, int N, int Np, double* Kx, int ld) {
@@ -587,10 +615,10 @@ __global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp,
 //     s1 = sum G K1,  s1a = sum G K1 r2_A,  s1b = sum G K1 r2_B,  s2 = sum G K2,  s2b = sum G K2 r2_B,  sn = sum_i G_ii
 // (dk/dl l/k = r^2/l^2 for an RBF factor; both factors of the product term share s1) -- ONE pass over the pairs instead of
 // the generic kernel's two passes per term with r^2 re-accumulated per factor.  Same partials layout as the generic kernel.
-__global__ __launch_bounds__(256) void mfgp_grad_rbf2_f64(Rbf2Spec sp, const double* __restrict__ X,
-                                                          const double* __restrict__ Kinv, int ld,
-                                                          const double* __restrict__ alpha, int N,
-                                                          double* __restrict__ partials) {
+__device__ __forceinline__ void grad_rbf2_body(const Rbf2Spec& sp, const double* __restrict__ X,
+                                               const double* __restrict__ Kinv, int ld,
+                                               const double* __restrict__ alpha, int N,
+                                               double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sxi = smem;
     double* sxj = smem + sp.D * XP;
@@ -679,6 +707,44 @@ __global__ __launch_bounds__(256) void mfgp_grad_rbf2_f64(Rbf2Spec sp, const dou
     }
 }
 
+__global__ __launch_bounds__(256) void mfgp_grad_rbf2_f64(Rbf2Spec sp, const double* __restrict__ X,
+                                                          const double* __restrict__ Kinv, int ld,
+                                                          const double* __restrict__ alpha, int N,
+                                                          double* __restrict__ partials) {
+    grad_rbf2_body(sp, X, Kinv, ld, alpha, N, partials);
+}
+// the B sets of a batched evaluation: blockIdx.y = set
+__global__ __launch_bounds__(256) void mfgp_grad_rbf2_batch_f64(Rbf2Batch specs, const double* __restrict__ X,
+                                                                const double* __restrict__ Kinv, long long kstride, int ld,
+                                                                const double* __restrict__ alpha, long long astride, int N,
+                                                                double* __restrict__ partials, long long pstride) {
+    const Rbf2Spec sp = specs.s[blockIdx.y];
+    grad_rbf2_body(sp, X, Kinv + blockIdx.y * kstride, ld, alpha + blockIdx.y * astride, N, partials + blockIdx.y * pstride);
+}
+// mfgp_grad_finish_f64 for the B sets: blockIdx.y = set; the parameters it divides by come from device-readable memory
+__global__ __launch_bounds__(256) void mfgp_grad_finish_batch_f64(int np, const double* __restrict__ thetas, int tstride,
+                                                                  const double* __restrict__ partials, long long pstride,
+                                                                  int nblocks, double* __restrict__ out, int ostride) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x;
+    partials += blockIdx.y * pstride;
+    double s = 0.0;
+    for (int b = tid; b < nblocks; b += 256) s += partials[(int64_t)b * NSUM + i];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double S = red[0];
+        double* o = out + (int64_t)blockIdx.y * ostride;
+        if (i == np) o[np] = -0.5 * S;
+        else if (i < np) o[i] = -0.5 * S / thetas[(int64_t)blockIdx.y * tstride + i];
+    }
+}
+
 int grad_num_partials(int Np) {
     const int nt = Np / KT;
     return nt * (nt + 1) / 2;
@@ -698,6 +764,25 @@ void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
                            partials);
     }
     hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(spec.np + 1), dim3(256), 0, s, spec, partials, nb, out);
+}
+
+void launch_grad_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, const double* Kinv, long long kstride,
+                       int ld, const double* alpha, long long astride, int N, int Np, double* partials, long long pstride,
+                       double* out, int ostride, const double* thetas, int tstride) {
+    const int nb = grad_num_partials(Np);
+    Rbf2Batch fb;
+    bool fast = nbatch <= MFGP_BATCH_MAX;
+    for (int b = 0; fast && b < nbatch; ++b) fast = rbf2_match(specs[b], fb.s[b]);
+    if (!fast) {
+        for (int b = 0; b < nbatch; ++b)
+            launch_grad(s, specs[b], X, Kinv + b * kstride, ld, alpha + b * astride, N, Np, partials + b * pstride,
+                        out + (int64_t)b * ostride);
+        return;
+    }
+    hipLaunchKernelGGL(mfgp_grad_rbf2_batch_f64, dim3(nb, nbatch), dim3(256), kb_lds(specs[0].D) + (size_t)256 * 6 * sizeof(double),
+                       s, fb, X, Kinv, kstride, ld, alpha, astride, N, partials, pstride);
+    hipLaunchKernelGGL(mfgp_grad_finish_batch_f64, dim3(specs[0].np + 1, nbatch), dim3(256), 0, s, specs[0].np, thetas, tstride,
+                       partials, pstride, nb, out, ostride);
 }
 
 // var[i] = max(kss - ss[i], 1e-15) + add,  kss = sum_terms prod var_f  (GPy Kdiag of a stationary kernel)

@@ -38,15 +38,16 @@ static int upload_tasks(mfgp_handle* h) {
 // One step of a plan.  nbatch > 0: over the handle's batch sets (mfgp_eval_batch) instead of its own slab -- the same launch
 // with one more grid dimension.  -> 0, or -1 when the planner asked for a kernel that does not exist (h->err says which).
 static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nbatch = 0) {
-    hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
+    const GemmTask* const dtasks = nbatch > 0 ? h->dtasks_b : h->dtasks;
     const bool batched = nbatch > 0;
+    hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
     const long long bstride = batched ? 4LL * h->cap * h->cap : 0;
     auto base = [&](int k) { return batched ? h->bslab + (size_t)k * h->cap * h->cap : h->buf[k]; };
     if (s.wait_ev > 0) (void)hipStreamWaitEvent(st, h->evpool[s.wait_ev - 1], 0);
     if (s.kind == 0) {
         if (batched)
             launch_leaf(st, base(BUF_A), base(BUF_L), base(BUF_S), (int)h->Np, s.blk, h->blogdet,
-                        reinterpret_cast<int*>(h->bdres + 30), nbatch, bstride, (int)(h->cap / NB), 256);
+                        reinterpret_cast<int*>(h->bdres + 30), nbatch, bstride, (int)(h->cap / NB), 2 * mfgp_handle::BRES);
         else
             launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
         h->launches++;
@@ -55,7 +56,7 @@ static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nb
         const bool g = want_grad && s.gcount > 0;
         const int n = g ? s.gcount : s.count;
         if (n > 0) {
-            if (launch_gemm(st, s.tile, h->dtasks + (g ? s.gfirst : s.first), n, base(s.a), base(s.b), base(s.c),
+            if (launch_gemm(st, s.tile, dtasks + (g ? s.gfirst : s.first), n, base(s.a), base(s.b), base(s.c),
                             s.c2 >= 0 ? base(s.c2) : nullptr, (int)h->Np, s.role, batched ? nbatch : 1, bstride) != 0)
                 return fail(h, -1, "planner bug: no tile-GEMM kernel for tile " + std::to_string(s.tile) + ", role " +
                                        std::to_string(s.role));
@@ -143,6 +144,7 @@ static void free_batch(mfgp_handle* h) {
     h->bhres = h->bdres = nullptr;
     h->bsets = 0;
     h->bsets_cap = 0;
+    h->plb_div = 0;      // (the batch plan's offsets follow the slab's capacity too)
 }
 
 static void free_mats(mfgp_handle* h) {
@@ -168,6 +170,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->doffs) hipFree(h->doffs);
     if (h->dAug) hipFree(h->dAug);
     if (h->dtasks) hipFree(h->dtasks);
+    if (h->dtasks_b) hipFree(h->dtasks_b);
     comm_release(h);
     if (h->dstage) hipFree(h->dstage);
     if (h->hres) hipHostFree(h->hres);
@@ -181,7 +184,8 @@ int32_t mfgp_destroy(mfgp_handle* h) {
 }
 
 static int build_plans(mfgp_handle* h) {
-    build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap);
+    build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap, plan_opts_from_env());
+    h->plb_div = 0;      // the batch plan follows: rebuilt, under the same switches, when the next batch arrives
     while ((int)h->evpool.size() < h->pl.n_events) {
         hipEvent_t e;
         // the plan's events order kernels of ONE device across the handle's two streams: no system-scope fence (cache
@@ -431,11 +435,34 @@ static int ensure_batch(mfgp_handle* h, int B) {
     HIPCHK(h, hipMalloc(&h->balpha, (size_t)want * cap * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->blogdet, (size_t)want * (cap / NB) * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->bpart, (size_t)want * grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1) * sizeof(double)));
-    HIPCHK(h, hipHostMalloc(&h->bhres, (size_t)want * 128 * sizeof(double), hipHostMallocMapped));
+    HIPCHK(h, hipHostMalloc(&h->bhres, (size_t)want * mfgp_handle::BRES * sizeof(double), hipHostMallocMapped));
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->bdres), h->bhres, 0));
-    memset(h->bhres, 0, (size_t)want * 128 * sizeof(double));
+    memset(h->bhres, 0, (size_t)want * mfgp_handle::BRES * sizeof(double));
     h->bsets = want;
     h->bsets_cap = h->cap;
+    return 0;
+}
+
+// the batch's plan: the handle's plan with the 128-tile threshold divided by the number of sets a launch carries (classes
+// 1 / 2 / 3-4 / 5-8 / 9-16, so that a fit's rounds of 4 and then 3 evaluations share one plan)
+static int ensure_batch_plan(mfgp_handle* h, int B) {
+    const int div = B >= 9 ? 9 : (B >= 5 ? 5 : (B >= 3 ? 3 : B));
+    if (h->plb_div == div && h->plb.nblk == h->nblk && h->plb.ld == h->Np) return 0;
+    build_plan(h->plb, h->nblk, h->Np, (int64_t)h->cap * h->cap, h->pl.opts, div);
+    while ((int)h->evpool.size() < h->plb.n_events) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+        h->evpool.push_back(e);
+    }
+    const size_t need = h->plb.tasks.size();
+    if (need > h->tasks_b_cap) {
+        if (h->dtasks_b) HIPCHK(h, hipFree(h->dtasks_b));
+        h->tasks_b_cap = need + need / 2 + 1024;
+        HIPCHK(h, hipMalloc(&h->dtasks_b, h->tasks_b_cap * sizeof(GemmTask)));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->dtasks_b, h->plb.tasks.data(), need * sizeof(GemmTask), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->plb_div = div;
     return 0;
 }
 
@@ -467,35 +494,38 @@ int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const d
     }
     rc = ensure_batch(h, B);
     if (rc) return rc;
+    rc = ensure_batch_plan(h, B);
+    if (rc) return rc;
     hipStream_t s = h->stream;
     const size_t cap = (size_t)h->cap, set = 4 * cap * cap;
     const int Np = (int)h->Np;
     const bool grad = want_grad != 0;
+    constexpr int BRES = mfgp_handle::BRES;
     h->launches = 0;
-    for (int b = 0; b < B; ++b) *reinterpret_cast<int*>(h->bhres + (size_t)b * 128 + 30) = 0;   // (the previous call synchronised)
+    for (int b = 0; b < B; ++b) {   // (the previous call synchronised: the pinned blocks are the host's to write)
+        double* r = h->bhres + (size_t)b * BRES;
+        *reinterpret_cast<int*>(r + 30) = 0;
+        for (int i = 0; i < np; ++i) r[128 + i] = specs[b].theta[i];        // the gradient's finishing kernel divides by them
+    }
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], s));
-    for (int b = 0; b < B; ++b)
-        launch_kbuild_tri(s, specs[b], h->dX, (int)h->N, Np, h->bslab + b * set, Np);
-    h->launches += B;
+    launch_kbuild_tri_batch(s, specs.data(), B, h->dX, (int)h->N, Np, h->bslab, Np, (long long)set);
+    h->launches += 1;
     if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[1], s));
-    const bool stream_kinv = grad && h->pl.kinv_streamed;
-    for (const Step& st : h->pl.steps)
+    const bool stream_kinv = grad && h->plb.kinv_streamed;
+    for (const Step& st : h->plb.steps)
         if (run_step(h, st, stream_kinv, B) != 0) return -1;
     if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[2], s));
-    for (int b = 0; b < B; ++b) {
-        double* S_b = h->bslab + b * set + (size_t)BUF_S * cap * cap;
-        launch_rowdot(s, S_b, Np, h->dY, h->bz + b * cap, Np, Np, 0);                       // z = X y
-        launch_alpha_finish(s, S_b, Np, h->bz + b * cap, h->balpha + b * cap, Np, h->blogdet + b * (cap / NB), h->nblk,
-                            h->bdres + (size_t)b * 128);
-    }
-    h->launches += 2 * B;
+    double* const S0 = h->bslab + (size_t)BUF_S * cap * cap;
+    launch_rowdot(s, S0, Np, h->dY, h->bz, Np, Np, 0, B, (long long)set, 0, (long long)cap);                   // z = X y
+    launch_alpha_finish(s, S0, Np, h->bz, h->balpha, Np, h->blogdet, h->nblk, h->bdres, B, (long long)set, (long long)cap,
+                        (int)(cap / NB), BRES);
+    h->launches += 2;
     if (grad) {
-        if (!stream_kinv && run_step(h, h->pl.kinv_step, true, B) != 0) return -1;
+        if (!stream_kinv && run_step(h, h->plb.kinv_step, true, B) != 0) return -1;
         const size_t npart = (size_t)grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1);
-        for (int b = 0; b < B; ++b)
-            launch_grad(s, specs[b], h->dX, h->bslab + b * set, Np, h->balpha + b * cap, (int)h->N, Np, h->bpart + b * npart,
-                        h->bdres + (size_t)b * 128 + 64);
-        h->launches += 2 * B;
+        launch_grad_batch(s, specs.data(), B, h->dX, h->bslab, (long long)set, Np, h->balpha, (long long)cap, (int)h->N, Np,
+                          h->bpart, (long long)npart, h->bdres + 64, BRES, h->bdres + 128, BRES);
+        h->launches += 2;
     }
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
     HIPCHK(h, hipGetLastError());
@@ -512,7 +542,7 @@ int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const d
     if (h->timing) t.total_ms = ev_ms(h->ev[0], h->ev[5]);
     t.timed = h->stage_timing ? 3 : (h->timing ? 1 : 0);
     t.kbuild_bytes = B * 4.0 * npd * (npd + 64.0);
-    t.kinv_flops = (grad && !stream_kinv) ? B * npd * npd * npd / 3.0 : 0.0;
+    t.kinv_flops = (grad && !stream_kinv) ? B * npd * npd * npd / 3.0 : 0.0;   // (a streamed plan counts K^-1 inside the sweep)
     t.cholinv_flops = B * (stream_kinv ? 3.0 : 2.0) * npd * npd * npd / 3.0;
     t.n_launches = h->launches;
     if (h->timing) h->cum.timed_evals += B;
@@ -525,7 +555,7 @@ int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const d
     h->cum.kinv_flops += t.kinv_flops;
     h->cum.cholinv_flops += t.cholinv_flops;
     for (int b = 0; b < B; ++b) {
-        const double* r = h->bhres + (size_t)b * 128;
+        const double* r = h->bhres + (size_t)b * BRES;
         const int info = *reinterpret_cast<const int*>(r + 30);
         status[b] = info;
         nlml[b] = 0.5 * ((double)h->N * 1.8378770664093453 + r[1] + r[0]);

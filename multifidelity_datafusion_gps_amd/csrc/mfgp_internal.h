@@ -57,6 +57,11 @@ void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld
 //   tri: lower-triangle 64x64 tiles of Ky = K + (noise+jitter) I over padded Np (identity padding)
 void launch_kbuild_tri(hipStream_t s, const KernSpecDev& spec, const double* X,
                        int N, int Np, double* A, int ld);
+//   the same for nbatch parameter sets (specs[b] -> A + b * bstride): ONE launch where every set takes the RBF fast path
+//   (mfgp_kbuild_rbf2_batch_f64), one launch per set otherwise
+constexpr int MFGP_BATCH_MAX = 16;
+void launch_kbuild_tri_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, int N, int Np, double* A,
+                             int ld, long long bstride);
 //   panel: Kx[r][c] = k(Xs[r], X[c]) for r < Nsp, c < Np (0 for padded columns c >= N)
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
                          const double* X, int N, int Np, double* Kx, int ld);
@@ -69,15 +74,17 @@ void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
 
 // vector ops
 //   y[i] = sum_{k in range(i)} M[i][k] x[k];  mode 0: k <= i (lower), 1: k >= i (upper), 2: all k < ncols
+//   nbatch sets: M, x, y of set b lie b * (mstride, xstride, ystride) elements further on (blockIdx.y = b)
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
-                   int ncols, int mode);
+                   int ncols, int mode, int nbatch = 1, long long mstride = 0, long long xstride = 0, long long ystride = 0);
 void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
                           double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y);
 //   rowsumsq[i] = sum_{k < ncols} M[i][k]^2
 void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols);
 //   scalars[0] = sum z^2 ; scalars[1] = 2*sum logdet_part ; (single small block)
 void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z, double* alpha, int Np,
-                         const double* logdet_part, int nblk, double* scalars);   // alpha = X^T z + the scalars, one launch
+                         const double* logdet_part, int nblk, double* scalars,   // alpha = X^T z + the scalars, one launch
+                         int nbatch = 1, long long sstride = 0, long long vstride = 0, int ldstride = 0, int scstride = 0);
 void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* logdet_part, int nblk,
                          double* scalars);
 //   gradient: partial sums over lower-triangle 64x64 tiles; out[2*nf+1] (natural-parameter gradient of NLML)
@@ -85,6 +92,11 @@ void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
                  const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
                  double* out);
 int grad_num_partials(int Np);
+//   nbatch sets: K^-1 of set b at Kinv + b * kstride, alpha + b * astride, partials + b * pstride, out + b * ostride; thetas =
+//   device-readable copy of the sets' parameter vectors, tstride apart (the finishing kernel divides by them)
+void launch_grad_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, const double* Kinv, long long kstride,
+                       int ld, const double* alpha, long long astride, int N, int Np, double* partials, long long pstride,
+                       double* out, int ostride, const double* thetas, int tstride);
 //   var[i] = max(kss - ss[i], 1e-15) + add ; kss from spec.theta
 void launch_finish_var(hipStream_t s, const KernSpecDev& spec, const double* ss,
                        double* var, int n, double add);
@@ -155,7 +167,12 @@ struct mfgp_handle {
     int64_t bsets_cap = 0;               // the padded capacity (h->cap) the sets were allocated for
     double* bslab = nullptr;
     double *bz = nullptr, *balpha = nullptr, *blogdet = nullptr, *bpart = nullptr;
-    double *bhres = nullptr, *bdres = nullptr;
+    double *bhres = nullptr, *bdres = nullptr;   // BRES doubles per set: [0,1] scalars, [30] pivot status, [64..] gradient, [128..] theta
+    static constexpr int BRES = 256;
+    mfgp::Plan plb;                      // the batch's own plan: same macro panels (same arithmetic), 128-tiles from fewer tiles per set
+    int plb_div = 0;                     // the t128 divisor plb was built for (0: none yet)
+    mfgp::GemmTask* dtasks_b = nullptr;
+    size_t tasks_b_cap = 0;
 };
 
 #define HIPCHK(h, call)                                                                         \

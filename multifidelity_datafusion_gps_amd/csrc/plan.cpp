@@ -17,6 +17,18 @@ static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+PlanOpts plan_opts_from_env() {
+    PlanOpts o;
+    const char* pm = getenv("MFGP_PLAN");
+    o.kind = (pm && strcmp(pm, "levels") == 0) ? 1 : ((pm && strcmp(pm, "recursive") == 0) ? 2 : 0);
+    o.macro = std::max(0, env_int("MFGP_MACRO", 0));
+    o.shift = env_int("MFGP_SHIFT", -1);
+    o.kinv_stream = env_int("MFGP_KINV_STREAM", -1);
+    o.chain_slim = env_int("MFGP_CHAIN_SLIM", -1);
+    o.t128_min = std::max(0, env_int("MFGP_T128_MIN", 0));
+    return o;
+}
+static int opt(int v, int dflt) { return v >= 0 ? v : dflt; }
 
 // ------------------------------------------------------------------------------------------------
 // planner
@@ -154,15 +166,15 @@ static void plan_potrf_rl(Plan& p) {
     //       which overlaps the next macro's chain.
     const int64_t ld = p.ld;
     const int nb = p.nblk;
-    const int MB = std::max(1, env_int("MFGP_MACRO", 4));   // 2 is ~1.5 % faster for one evaluation alone, 4 is ~5 % faster with evaluations in flight
+    const int MB = p.opts.macro > 0 ? p.opts.macro : 4;   // 2 is ~1.5 % faster for one evaluation alone, 4 is ~5 % faster with evaluations in flight
     // `shift`: the chain's K = 128 inner updates also cover the NEXT macro panel's first column, so that no K = MB*128
     // step (and no wait for the previous macro's bulk update) gates its first leaf.  Pays where the factorisation is
     // chain-bound throughout (N = 4096: 3.42 -> 3.28 ms, 2048: 1.37 -> 1.28); neutral at N = 8192, where the first half
     // is bound by the bulk updates and the gating step's slack is worth as much as its latency.
-    const bool shift = env_int("MFGP_SHIFT", nb < 48) != 0;
+    const bool shift = opt(p.opts.shift, nb < 48) != 0;
     // slim chain workgroups (role 3) co-reside with the bulk update's workgroups; alone they are ~30 % slower than the
     // double-buffered 64-tile kernel, so they only pay where bulk updates are long enough to overlap the chain
-    const int chain_role = env_int("MFGP_CHAIN_SLIM", nb >= 48) ? 3 : 0;
+    const int chain_role = opt(p.opts.chain_slim, nb >= 48) ? 3 : 0;
     auto syrk_tasks = [&](int T, int jlo, int jhi, int klo, int khi) {
         // A[i,j] -= sum_{k in [klo,khi) blocks} L[i,k] L[j,k]^T for block columns j in [jlo,jhi), rows i >= j
         const int sc = NB / T;
@@ -498,18 +510,18 @@ static void plan_sweep(Plan& p) {
     //   6144 6.02 / 6.21 / 6.22 / 6.24 / 6.29;  8192 12.27 / 12.05 / 11.80 / 11.92 / 12.00 / 12.35 / 13.5;
     //   12288 - / - / 34.50 / 34.48 / 34.66 / 36.0 / 37.2;  16384 - / - / 75.9 / 75.7 / 77.6 / 77.9 / 81.7
     // (rounds 1-2 had 2 / 3 / 4 / 6 / 8 / 16 from 14 / 33 / 41 / 52 / 64 / 96 block columns up).
-    const int MB = std::max(1, env_int("MFGP_MACRO", nb >= 80 ? 5 : (nb >= 56 ? 4 : (nb >= 25 ? 2 : (nb > 13 ? 3 : nb)))));
-    const bool shift = env_int("MFGP_SHIFT", nb < 48) != 0;   // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
+    const int MB = p.opts.macro > 0 ? p.opts.macro : (nb >= 80 ? 5 : (nb >= 56 ? 4 : (nb >= 25 ? 2 : (nb > 13 ? 3 : nb))));
+    const bool shift = opt(p.opts.shift, nb < 48) != 0;   // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     // slim (16 KB LDS) chain workgroups fit on a CU beside a 128 KB bulk workgroup; the 64 KB kernel would wait for one to
     // retire (N = 4096: 3.27 -> 3.03 ms).  Below ~24 blocks the bulk launches are 64-tiles themselves: no difference.
-    const int chain_role = env_int("MFGP_CHAIN_SLIM", nb >= 24) ? 3 : 0;
+    const int chain_role = opt(p.opts.chain_slim, nb >= 24) ? 3 : 0;
     // tile edge of the chain's own launches (panel, inner).  They are latency-bound: a 64x64x128 tile is 128 dependent-ish
     // MFMAs per SIMD (5.3 us) behind 8 serial K-steps; as 32x32 tiles (4 waves, 16 KB of LDS, four times the workgroups, four
     // K-steps) the same work spreads over four times as many SIMDs (N = 1024 0.60 -> 0.53 ms, 2048 1.20 -> 1.03, 4096 2.93 -> 2.80).  Chain-bound sizes only: at N >= 6144 the chain hides behind the
     // bulk stream and fewer, larger workgroups disturb it less.
     const int CT = nb < 48 ? 32 : 64;
     const int chain_role_ct = CT == 32 ? 5 : chain_role;
-    p.kinv_streamed = env_int("MFGP_KINV_STREAM", 1) != 0;
+    p.kinv_streamed = opt(p.opts.kinv_stream, 1) != 0;
     int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
     const bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
     // One macro panel (nothing runs beside the chain): K^-1 is accumulated column by column in the chain's own K = 128 launches
@@ -793,16 +805,16 @@ static void plan_sweep(Plan& p) {
     }
 }
 
-void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride) {
+void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& opts, int t128_div) {
     p = Plan{};
-    p.t128_min = env_int("MFGP_T128_MIN", nblk >= 56 ? 600 : 300);
+    p.opts = opts;
+    p.t128_min = std::max(1, (opts.t128_min > 0 ? opts.t128_min : (nblk >= 56 ? 600 : 300)) / std::max(1, t128_div));
     p.nblk = nblk;
     p.ld = ld;
     p.stride = stride;
-    const char* pm = getenv("MFGP_PLAN");
-    if (pm && strcmp(pm, "recursive") == 0) {
+    if (opts.kind == 2) {
         plan_cholinv(p, 0, nblk);
-    } else if (pm && strcmp(pm, "levels") == 0) {
+    } else if (opts.kind == 1) {
         plan_potrf_rl(p);
         plan_trtri_levels(p);
     } else {

@@ -53,6 +53,17 @@ struct Step {
     int rec_ev_final;   // a second event recorded after the launch (the plan's final join), 0 = none
 };
 
+// The planner's switches (DESIGN.md "Planner switches"): read from the environment ONCE when a handle plans for a size
+// (plan_opts_from_env) and kept with the handle, so that the plan of its batched evaluations -- built later, when the first batch
+// arrives -- is the same plan.  -1 / 0 = the size-dependent default (the measured best).
+struct PlanOpts {
+    int kind = 0;          // MFGP_PLAN: 0 sweep (default), 1 levels, 2 recursive
+    int macro = 0;         // MFGP_MACRO: block columns per macro panel
+    int shift = -1;        // MFGP_SHIFT
+    int kinv_stream = -1;  // MFGP_KINV_STREAM
+    int chain_slim = -1;   // MFGP_CHAIN_SLIM
+    int t128_min = 0;      // MFGP_T128_MIN: tiles per launch from which 128-tiles are used
+};
 struct Plan {
     int nblk = 0;
     int64_t ld = 0;                 // = padded size Np
@@ -66,10 +77,14 @@ struct Plan {
     int n_events = 0;               // events the steps refer to (1-based ids 1..n_events)
     int t128_min = 300;             // tiles per launch from which 128-tiles are used (64-tiles below)
     bool kinv_streamed = false;     // the steps accumulate K^-1 behind the chain
+    PlanOpts opts;                  // the switches it was planned under
 };
 
-// environment-selected planner variants (read once per plan; defaults = the measured best, DESIGN.md "Planner switches")
-void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride);
+PlanOpts plan_opts_from_env();
+// t128_div > 1: the plan of a BATCHED evaluation of about that many matrix sets per launch -- a launch carries t128_div times
+// the tiles, so the 128-tile threshold is reached that much earlier (tile sizes do not change any result bit: a tile's
+// elements accumulate over k in the same order in both kernels)
+void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& opts = PlanOpts(), int t128_div = 1);
 // (re)plan the predictive-variance product for a panel of rows_p rows; keeps everything planned before it
 void plan_predv(Plan& p, int rows_p);
 

@@ -9,9 +9,12 @@
 namespace mfgp {
 
 // one wave per row, 16 B per lane, rows fully coalesced; mode 0: k<=i, 1: k>=i, 2: all
+// blockIdx.y = set b of a batched evaluation: M, x, y move by b * (mstride, xstride, ystride) elements (0 for a single one)
 __global__ __launch_bounds__(256) void mfgp_rowdot_f64(const double* __restrict__ M, int ld,
                                                        const double* __restrict__ x, double* __restrict__ y,
-                                                       int nrows, int ncols, int mode) {
+                                                       int nrows, int ncols, int mode, long long mstride, long long xstride,
+                                                       long long ystride) {
+    M += blockIdx.y * mstride; x += blockIdx.y * xstride; y += blockIdx.y * ystride;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -74,7 +77,12 @@ __global__ __launch_bounds__(256) void mfgp_finish_solve_f64(const double* __res
 __global__ __launch_bounds__(256) void mfgp_alpha_finish_f64(const double* __restrict__ S, int ld,
                                                              const double* __restrict__ z, double* __restrict__ alpha,
                                                              int Np, const double* __restrict__ logdet_part, int nblk,
-                                                             double* __restrict__ scalars) {
+                                                             double* __restrict__ scalars, long long sstride, long long vstride,
+                                                             int ldstride, int scstride) {
+    // blockIdx.y = set b of a batched evaluation: S moves by b * sstride, z and alpha by b * vstride, the log-det partials by
+    // b * ldstride, the scalars by b * scstride elements (all 0 for a single one)
+    S += blockIdx.y * sstride; z += blockIdx.y * vstride; alpha += blockIdx.y * vstride;
+    logdet_part += blockIdx.y * ldstride; scalars += blockIdx.y * scstride;
     if (blockIdx.x == gridDim.x - 1) {   // the extra workgroup: scalars
         __shared__ double red[256];
         const int tid = threadIdx.x;
@@ -170,16 +178,18 @@ void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, co
 }
 
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
-                   int ncols, int mode) {
-    hipLaunchKernelGGL(mfgp_rowdot_f64, dim3((nrows + 3) / 4), dim3(256), 0, s, M, ld, x, y, nrows, ncols, mode);
+                   int ncols, int mode, int nbatch, long long mstride, long long xstride, long long ystride) {
+    hipLaunchKernelGGL(mfgp_rowdot_f64, dim3((nrows + 3) / 4, nbatch > 0 ? nbatch : 1), dim3(256), 0, s, M, ld, x, y, nrows, ncols,
+                       mode, mstride, xstride, ystride);
 }
 void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols) {
     hipLaunchKernelGGL(mfgp_rowsumsq_f64, dim3((nrows + 3) / 4), dim3(256), 0, s, M, ld, out, nrows, ncols);
 }
 void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z, double* alpha, int Np,
-                         const double* logdet_part, int nblk, double* scalars) {
-    hipLaunchKernelGGL(mfgp_alpha_finish_f64, dim3((Np + 3) / 4 + 1), dim3(256), 0, s, S, ld, z, alpha, Np, logdet_part, nblk,
-                       scalars);
+                         const double* logdet_part, int nblk, double* scalars, int nbatch, long long sstride, long long vstride,
+                         int ldstride, int scstride) {
+    hipLaunchKernelGGL(mfgp_alpha_finish_f64, dim3((Np + 3) / 4 + 1, nbatch > 0 ? nbatch : 1), dim3(256), 0, s, S, ld, z, alpha, Np,
+                       logdet_part, nblk, scalars, sstride, vstride, ldstride, scstride);
 }
 void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* logdet_part, int nblk,
                          double* scalars) {

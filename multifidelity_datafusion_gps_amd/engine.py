@@ -24,6 +24,7 @@ only marks the model dirty; the factorisation happens at the next query (GPy re-
 on every assignment -- same results, fewer O(N^3) passes).
 """
 import re
+import time
 
 import numpy as np
 from scipy import optimize as _sciopt
@@ -393,6 +394,7 @@ class LockstepEvaluator:
         self.rounds = 0
         self.evals = 0
         self.round_sizes = []
+        self.engine_s = 0.0       # wall seconds inside eval_batch (the rest of a fit's time is the hosts' L-BFGS-B steps and hand-offs)
 
     def evaluate(self, slot, theta, noise, jitter):
         """-> (nlml, grad) of THIS slot's point; raises NotPositiveDefinite for it alone"""
@@ -419,6 +421,7 @@ class LockstepEvaluator:
         slots = sorted(self._pending)
         reqs = [self._pending.pop(k) for k in slots]
         cap = getattr(self._eng, "MAX_BATCH", 16)
+        t0 = time.perf_counter()
         try:
             for c0 in range(0, len(slots), cap):
                 part, sl = reqs[c0:c0 + cap], slots[c0:c0 + cap]
@@ -430,6 +433,7 @@ class LockstepEvaluator:
         except BaseException as ex:  # noqa: BLE001 - an engine error ends every run of the round, not just the caller's
             for k in slots:
                 self._results.setdefault(k, ex)
+        self.engine_s += time.perf_counter() - t0
         self.rounds += 1
         self.evals += len(slots)
         self.round_sizes.append(len(slots))
@@ -652,21 +656,24 @@ class GPRegression:
         """-> f_fp(x) evaluating NLML and its optimizer-space gradient on `eng` WITHOUT touching the model's
         Param objects (free = the parameters x stands for; every other parameter keeps its current value).
         `evaluate(theta, noise, jitter) -> (nlml, grad)` replaces eng.eval where given (a LockstepEvaluator slot)."""
+        # index tables built once: the per-evaluation work is a handful of small-array operations (it runs under the GIL, beside
+        # the other runs of a lock-stepped fit: every microsecond here is GPU idle time times the number of runs)
         params = self.parameters()
-        base = {id(p): p.value for p in params}
-        free_ids = [id(p) for p in free]
-        part_ids = [[id(v)] + [id(l) for l in ls] for v, ls in self._part_params]
-        term_ids = [[id(f.variance) for f in term] for term in self.kern._terms()]
-        noise_id = id(self.likelihood.variance)
+        pos = {id(p): k for k, p in enumerate(params)}
+        base = np.array([p.value for p in params], dtype=np.float64)
+        free_idx = np.array([pos[id(p)] for p in free], dtype=np.intp)
+        theta_idx = np.array([pos[id(q)] for v, ls in self._part_params for q in [v] + ls], dtype=np.intp)
+        term_idx = [np.array([pos[id(f.variance)] for f in term], dtype=np.intp) for term in self.kern._terms()]
+        noise_idx = pos[id(self.likelihood.variance)]
+        shared = len(set(theta_idx.tolist())) != len(theta_idx)      # a Param object used by several factors: gradients add up
         state = {"fails": 0, "g": None}
 
         def f_fp(x):
-            vals = dict(base)
+            vals = base.copy()
             pv = _logexp_f(np.asarray(x, dtype=np.float64))
-            for k, v in zip(free_ids, pv):
-                vals[k] = float(v)
-            theta = np.array([vals[k] for ids in part_ids for k in ids])
-            noise = vals[noise_id]
+            vals[free_idx] = pv
+            theta = vals[theta_idx]
+            noise = float(vals[noise_idx])
             jitter_extra, tries = 0.0, 0
             try:
                 _check_parameters(theta, noise)
@@ -681,7 +688,7 @@ class GPRegression:
                     except NotPositiveDefinite:
                         self.n_evals += 1
                         tries += 1
-                        diag_mean = sum(np.prod([vals[k] for k in t]) for t in term_ids) + noise + CONST_JITTER
+                        diag_mean = sum(float(np.prod(vals[t])) for t in term_idx) + noise + CONST_JITTER
                         if tries > 5 or not np.isfinite(diag_mean):
                             raise np.linalg.LinAlgError("not positive definite, even with jitter.")
                         jitter_extra = diag_mean * 1e-6 * 10 ** (tries - 1)
@@ -692,13 +699,13 @@ class GPRegression:
                 state["fails"] += 1
                 stale = state["g"] if state["g"] is not None else np.zeros_like(pv)
                 return _F_FAILED, np.clip(stale, -_G_CLIP_FAILED, _G_CLIP_FAILED)
-            acc, pos = {}, 0
-            for ids in part_ids:
-                for k in ids:
-                    acc[k] = acc.get(k, 0.0) + g[pos]
-                    pos += 1
-            acc[noise_id] = g[-1]
-            gf = _logexp_gradfactor(pv, np.array([acc[k] for k in free_ids]))
+            acc = np.zeros(len(params))
+            if shared:
+                np.add.at(acc, theta_idx, g[:-1])
+            else:
+                acc[theta_idx] = g[:-1]
+            acc[noise_idx] = g[-1]
+            gf = _logexp_gradfactor(pv, acc[free_idx])
             state["g"] = gf
             return nlml, np.clip(gf, -1e100, 1e100)
 
@@ -772,12 +779,12 @@ class GPRegression:
                     ex.shutdown(wait=True)
         return _Handle()
 
-    def start_lockstep_restarts(self, indices, lockstep, slots, free=None, rand_gen=None, max_iters=1000):
-        """The randomized restarts `indices` as lock-stepped runs: one thread per SLOT, every evaluation through
-        `lockstep.evaluate(slot, ...)` (a LockstepEvaluator over this model's engine, shared with whatever else -- the
-        caller's own sequential runs -- holds a slot of it); a slot takes the next restart still waiting when its run ends
-        and retires when none is left.  Same draws, same L-BFGS-B controls, same `eval_cap` as start_background_restarts;
-        .result() -> [(f_opt, x_opt, index), ...] after every slot has retired."""
+    def start_lockstep_restarts(self, indices, lanes, free=None, rand_gen=None, max_iters=1000):
+        """The randomized restarts `indices` as lock-stepped runs.  `lanes` = [(LockstepEvaluator, [slot, ...]), ...]: one thread
+        per slot, every evaluation through its lane's `evaluate(slot, ...)` (a lane = one engine handle with this model's data
+        and its own rounds; the caller's own sequential runs may hold a slot of a lane too); a slot takes the next restart
+        still waiting when its run ends and retires when none is left.  Same draws, same L-BFGS-B controls, same `eval_cap`
+        as start_background_restarts; .result() -> [(f_opt, x_opt, index), ...] after every slot has retired."""
         import queue
         import threading
         free = list(free) if free is not None else self.parameters()
@@ -793,7 +800,7 @@ class GPRegression:
         for i in indices:
             todo.put(i)
 
-        def worker(slot):
+        def worker(lockstep, slot):
             try:
                 while True:
                     try:
@@ -801,13 +808,13 @@ class GPRegression:
                     except queue.Empty:
                         return
                     try:
-                        one(i, slot)
+                        one(i, lockstep, slot)
                     except BaseException as ex:  # noqa: BLE001 - reported by result(); the slot goes on to the next restart
                         errors[i] = ex
             finally:
                 lockstep.retire(slot)
 
-        def one(i, slot):
+        def one(i, lockstep, slot):
             count = {"n": 0}
 
             def evaluate(theta, noise, jitter):
@@ -824,7 +831,7 @@ class GPRegression:
                 self.optimization_runs.append(_OptRun(np.array(x_opt), float(f_opt), count["n"], task, background=True))
                 out[i] = (float(f_opt), np.array(x_opt), i)
 
-        threads = [threading.Thread(target=worker, args=(slot,), daemon=True) for slot in slots]
+        threads = [threading.Thread(target=worker, args=(ls, slot), daemon=True) for ls, slots in lanes for slot in slots]
         for t in threads:
             t.start()
 

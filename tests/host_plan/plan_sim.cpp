@@ -199,7 +199,7 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
     Sim s;
     s.ld = (int64_t)nblk * NB;
     s.stride = (s.ld + slack) * (s.ld + slack);
-    build_plan(s.p, nblk, s.ld, s.stride);
+    build_plan(s.p, nblk, s.ld, s.stride, plan_opts_from_env());
     if (mutate == 1) {
         for (Step& st : s.p.steps)
             if (st.strm == 1 && st.wait_ev > 0) { st.wait_ev = 0; break; }

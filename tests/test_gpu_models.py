@@ -176,31 +176,32 @@ def test_adaptation_improves_mse():
 @pytest.mark.parametrize("n_hf", [150, 700, 1500])
 def test_concurrent_and_lockstep_restarts_give_the_sequential_result(n_hf):
     """The three ways of running the recipe's 1 + 6 L-BFGS-B runs: sequentially (the reference's order), with the randomized
-    restarts on auxiliary engine handles in background threads (restart_concurrency), and in LOCK STEP on one handle -- every
-    round one batched pass (mfgp_eval_batch) over the live runs (restart_lockstep, the default).  Same runs, same steps: the
+    restarts on auxiliary engine handles in background threads (restart_concurrency), and in LOCK STEP -- the live runs dealt to one, two or three engine
+    handles ("lanes"), every round of a lane one batched pass (mfgp_eval_batch) over its runs (restart_lockstep, the default).  Same runs, same steps: the
     fitted parameters, every run's optimum and every run's evaluation count are IDENTICAL (bitwise), for every lock-step
     width.  Sizes: one leaf block, a single macro panel, several macro panels on two streams."""
     import multifidelity_datafusion_gps_amd as mf
     rng = np.random.default_rng(21)
     X_hf = rng.uniform(size=(n_hf, 2))
     out = {}
-    for mode in ("sequential", "concurrent", "lockstep", "lockstep_w7", "lockstep_w2"):
+    for mode in ("sequential", "concurrent", "lockstep", "lockstep_1lane", "lockstep_w7", "lockstep_w2"):
         model = mf.NARGP(2, hf2, lf2, seed=5)
         model.first_run_max_iters = model.restart_max_iters = 40
         model.eval_cap = 12 if n_hf > 200 else None
         model.restart_lockstep = mode.startswith("lockstep")
         model.restart_concurrency = 3 if mode == "concurrent" else 1
         model.lockstep_width = {"lockstep_w7": 7, "lockstep_w2": 2}.get(mode)
+        model.lockstep_lanes = {"lockstep_1lane": 1, "lockstep_w7": 3}.get(mode, 2)
         model.fit(X_hf)
         runs = sorted((r.f_opt, tuple(r.x_opt)) for r in model.hf_model.optimization_runs)
         out[mode] = (np.array([p.value for p in model.hf_model.parameters()]), runs, model.hf_model.n_evals)
         if mode == "concurrent":
             assert any(k.startswith("hf#") for k in model._engines)
         if mode.startswith("lockstep"):
-            assert not any(k.startswith("hf#") for k in model._engines)          # one handle: the batch sets live inside it
-            ls = model.last_lockstep
-            assert ls.evals == sum(r.n_evals for r in model.hf_model.optimization_runs)
-            assert max(ls.round_sizes) == {"lockstep": 4, "lockstep_w7": 6, "lockstep_w2": 2}[mode]
+            lanes = model.last_lockstep_lanes
+            assert len(lanes) == {"lockstep": 2, "lockstep_1lane": 1, "lockstep_w7": 3, "lockstep_w2": 2}[mode]
+            assert sum(ls.evals for ls in lanes) == sum(r.n_evals for r in model.hf_model.optimization_runs)
+            assert max(max(ls.round_sizes) for ls in lanes) == {"lockstep": 2, "lockstep_1lane": 4, "lockstep_w7": 2, "lockstep_w2": 1}[mode]
         mean, var = model.predict(X_hf[:20])                                       # the winner is installed and factorised
         out[mode] += (mean, var)
         model.close()

@@ -22,7 +22,9 @@ if argv and argv[0] == "--evals":
     evals = int(argv[1]); argv = argv[2:]
 MODES = [("sequential", dict(restart_lockstep=False, restart_concurrency=1)),
          ("concurrent 2", dict(restart_lockstep=False, restart_concurrency=2)),
-         ("lockstep w4", dict(restart_lockstep=True)), ("lockstep w7", dict(restart_lockstep=True, lockstep_width=7))]
+         ("lockstep 1 lane", dict(restart_lockstep=True, lockstep_lanes=1)), ("lockstep 2 lanes", dict(restart_lockstep=True, lockstep_lanes=2)),
+         ("2 lanes w6", dict(restart_lockstep=True, lockstep_lanes=2, lockstep_width=6)),
+         ("3 lanes w6", dict(restart_lockstep=True, lockstep_lanes=3, lockstep_width=6))]
 print("# python3 tools/midsize_fit.py --evals %d ...: one fit of the reference's ARD recipe (1 + 6 L-BFGS-B runs, %d evaluations each), HF level only timed" % (evals, evals))
 for n_hf in [int(a) for a in argv] or [1024]:
     line = "N_hf=%d (N_lf=%d):" % (n_hf, 2 * n_hf)
