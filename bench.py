@@ -243,44 +243,79 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=170.0):
                          measured, n_lf_evals, n_hf_evals)}
 
 
-PMC_FILE = os.path.join("profiles", "r03_pmc.json")
-MFMA_FILE = os.path.join("profiles", "r03_mfma_counters.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc.json")
+MFMA_FILE = os.path.join("profiles", "r04_mfma_counters.json")
 BARE_MFMA_TFLOPS = 71.0   # bare v_mfma_f64_4x4x4_4b loop on this part (profiles/r03_probes.txt): what the instruction itself can issue
 
 
-def pmc_traffic(kernel, n):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes, or None (not measured by THIS run)"""
+def committed_counters(path, build_id):
+    """-> (dict, None) for a committed counter summary taken with THIS library (its `csrc_hash` equals the id embedded in the
+    loaded libmfgp_hip.so), else (None, reason): counters of another build are not reported as this run's (VERDICT r3 #8)"""
     try:
-        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
-        return int(d[kernel]["traffic_bytes"]) if int(d.get("n", -1)) == int(n) else None
-    except Exception:  # noqa: BLE001
-        return None
+        d = json.load(open(os.path.join(ROOT, path)))
+    except Exception as ex:  # noqa: BLE001
+        return None, "%s: %s" % (path, ex.__class__.__name__)
+    have = d.get("csrc_hash")
+    if not have:
+        return None, "%s carries no csrc_hash (taken before the sources were stamped)" % path
+    if have != build_id:
+        return None, "%s was taken with library build %s, this run loaded %s" % (path, have, build_id)
+    return d, None
 
 
-def mfma_busy():
-    """matrix-pipe busy fraction per kernel from the committed SQ counter pass over one evaluation at N = 8192
-    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); profiles/README.md has the calibration on the bare probes)"""
+def pmc_traffic(kernel, n, build_id):
+    """-> (HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes, or None; the reason when None)"""
+    d, why = committed_counters(PMC_FILE, build_id)
+    if d is None:
+        return None, why
+    if int(d.get("n", -1)) != int(n):
+        return None, "%s was taken at N = %s" % (PMC_FILE, d.get("n"))
     try:
-        d = json.load(open(os.path.join(ROOT, MFMA_FILE)))["pmcA_eval"]
-        return {k: v["mfma_busy"] for k, v in d.items() if v.get("mfma_busy", 0) > 0}
+        return int(d[kernel]["traffic_bytes"]), None
     except Exception:  # noqa: BLE001
-        return None
+        return None, "%s has no entry for %s" % (PMC_FILE, kernel)
+
+
+def mfma_busy(build_id):
+    """-> (matrix-pipe busy fraction per kernel from the committed SQ counter pass over one evaluation at N = 8192
+    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); profiles/README.md has the calibration), or None; the reason)"""
+    d, why = committed_counters(MFMA_FILE, build_id)
+    if d is None:
+        return None, why
+    try:
+        return {k: v["mfma_busy"] for k, v in d["pmcA_eval"].items() if v.get("mfma_busy", 0) > 0}, None
+    except Exception:  # noqa: BLE001
+        return None, "%s has no pmcA_eval block" % MFMA_FILE
 
 
 def _rate(num, ms):
     return num / (ms * 1e-3) if ms > 0 else 0.0
 
 
+_PROFILER_ENV = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")
+
+
+def under_profiler(env=None):
+    """is this process running under rocprofv3 (or anything else that preloads a tool library)?"""
+    env = os.environ if env is None else env
+    return any(env.get(k) for k in _PROFILER_ENV) or any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in env)
+
+
 def start_power_watch():
-    """rocm-smi sampled by a CHILD process (tools/power_watch.py --until-eof) beside the run: socket power against its cap and
-    the shader clock the power management holds.  Best effort: None where the tool is missing."""
+    """--power: socket power / shader clock sampled by a CHILD process (tools/power_watch.py --until-eof) beside the run.
+    OPT-IN (ADVICE r3): the sampler costs host CPU beside the L-BFGS-B driver threads, so the default bench line is taken without
+    it.  Never under a profiler: the child tree would inherit the profiler's preloaded library, and every exec in it is the
+    exec-after-GPU-init this pool forbids -- returns None there; the child's environment is stripped of the preload variables
+    in any case, and the sampler reads sysfs (no process per sample) where the driver exposes the sensors."""
     import subprocess
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "power_watch.py")
-    if not os.path.exists(tool):
+    if not os.path.exists(tool) or under_profiler():
         return None
+    env = {k: v for k, v in os.environ.items()
+           if k not in _PROFILER_ENV and not k.startswith("ROCPROFILER_") and not k.startswith("ROCPROF_")}
     try:
         return subprocess.Popen([sys.executable, tool, "--period", "0.1", "--until-eof"], stdin=subprocess.PIPE,
-                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
     except OSError:
         return None
 
@@ -302,7 +337,7 @@ def stop_power_watch(proc, wall0, wall1):
     med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
     pw, ck = [r[1] for r in rows], [r[2] for r in rows]
     hot = [r for r in rows if d.get("cap_w") and r[1] >= 0.93 * d["cap_w"]]
-    return {"source": "rocm-smi sampled every ~0.1 s by a child process over the timed region (tools/power_watch.py)",
+    return {"source": d.get("source", "rocm-smi") + " sampled every ~0.1 s by a child process over the timed region (tools/power_watch.py)",
             "cap_w": d.get("cap_w"), "samples": len(rows), "socket_w_median": med(pw), "socket_w_max": max(pw),
             "sclk_mhz_median": med(ck), "sclk_mhz_min": min(ck), "junction_c_max": max(r[3] for r in rows),
             "fraction_of_samples_within_7pct_of_cap": round(len(hot) / len(rows), 3),
@@ -320,14 +355,15 @@ def launch_ranks(n_ranks, argv, script=None):
     import secrets
     import socket
     import subprocess
-    with socket.socket() as sk:
+    # two ports probed free: MASTER_PORT for whatever store a rank's own launcher-side code may open, MFGP_COMM_PORT for the
+    # rendezvous hub of sharding.comm_from_env (which would otherwise derive MASTER_PORT +- 1000 -- a port nobody checked)
+    with socket.socket() as sk, socket.socket() as sk2:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    if port + 1000 >= 65536:
-        port -= 2000
+        sk2.bind(("127.0.0.1", 0))
+        port, comm_port = sk.getsockname()[1], sk2.getsockname()[1]
     base = dict(os.environ)
     base.update({"WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
-                 "MFGP_COMM_TOKEN": secrets.token_hex(16)})
+                 "MFGP_COMM_PORT": str(comm_port), "MFGP_COMM_TOKEN": secrets.token_hex(16)})
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
     procs = []
     for r in range(n_ranks):
@@ -388,7 +424,9 @@ def main():
     ap.add_argument("--aux-order", default="natural", choices=["natural", "reversed"])
     ap.add_argument("--lend-main", type=int, default=0, help="1: the main engine joins the restarts' pool after restart 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (socket power, sclk) beside the timed region")
+    ap.add_argument("--power", action="store_true", help="sample socket power / sclk beside the timed region (a child process; "
+                                                         "off by default: it costs host CPU beside the optimiser threads; never under a profiler)")
+    ap.add_argument("--no-power", action="store_true", help="(accepted for old command lines; power sampling is off unless --power)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0; RCCL is made to accept that by giving every rank its own "
                          "NCCL_HOSTID (a real N-rank communicator over RCCL's socket transport on loopback)")
@@ -408,8 +446,12 @@ def main():
     # the caller's environment: make sure of it before the HIP runtime initialises
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     power_proc = None
-    if rank == 0 and not args.no_power:
-        power_proc = start_power_watch()       # a child that samples rocm-smi; started BEFORE this process touches HIP
+    if rank == 0 and args.power and not args.no_power:
+        power_proc = start_power_watch()       # a child that samples the sensors; started BEFORE this process touches HIP
+    # HIP's stream -> hardware-queue mapping: 2 queues per priority measured best for this job (profiles/r03_hw_queues.txt).  The
+    # package no longer changes it behind the host application's back: the bench asks for it explicitly, before the
+    # HIP runtime initialises, and reports what was in effect.
+    os.environ.setdefault("MFGP_HW_QUEUES", "2")
     from multifidelity_datafusion_gps_amd import sharding
     if world > 1 and args.single_device:
         os.environ.update(sharding.rehearsal_env(rank))      # before librccl is loaded (lazily, by attach_engine)
@@ -512,6 +554,10 @@ def main():
         pv_tf = _rate(tot["timed_predict_var_flops"], tot["predict_var_ms"]) / 1e12
         kinv_tf = _rate(tot["kinv_flops"], tot["kinv_ms"]) / 1e12
         streamed = tot["kinv_flops"] == 0
+        from multifidelity_datafusion_gps_amd._lib import build_id as _build_id
+        build_id = _build_id()
+        busy, busy_why = mfma_busy(build_id)
+        traffic_sweep, traffic_why = pmc_traffic("sweep", args.n, build_id)
         out = {
             "metric": "gp_fit_predict_wall_ms", "value": round(ms_per_step, 2), "unit": "ms",
             "n_gpus": 1 if args.single_device else world,
@@ -529,7 +575,8 @@ def main():
                                            % (lanes, args.width or "auto")) if args.lockstep
                                           else "concurrent restarts on %d auxiliary handles" % args.concurrency,
                        "restart_concurrency": None if args.lockstep else args.concurrency, "collectives": collectives,
-                       "ranks": world, "rccl_ranks": int(engines["hf"].comm_size),
+                       "ranks": world, "rccl_ranks": int(engines["hf"].comm_size), "library_build_id": build_id,
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
                        "sharding": "randomized restarts + predictive rows over ranks; LF run on rank 0 (the others adopt its optimum); "
                                    "first HF run -> restart 0 on rank 0 only"},
             # the dominant work: ONE sweep per evaluation = Cholesky + triangular inverse%s, timed with HIP events on the
@@ -539,10 +586,12 @@ def main():
                          "bound": "mfma", "achieved": round(sweep_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(sweep_tf / FP64_PEAK_TFLOPS, 4),
                          "frac_of_bare_mfma_loop": round(sweep_tf / BARE_MFMA_TFLOPS, 4), "bare_mfma_loop": BARE_MFMA_TFLOPS,
-                         "mfma_busy": mfma_busy(), "mfma_busy_source": MFMA_FILE + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
-                         "SQ_BUSY_CU_CYCLES ... over tools/time_eval.py 8192, committed; not measured by this run)",
-                         "traffic": pmc_traffic("sweep", args.n), "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes over "
-                         "tools/time_eval.py, committed; not measured by this run)",
+                         "mfma_busy": busy, "mfma_busy_source": (MFMA_FILE + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                         "SQ_BUSY_CU_CYCLES ... over tools/time_eval.py 8192, committed, taken with this library build %s; not "
+                         "measured by this run)" % build_id) if busy is not None else "null: " + busy_why,
+                         "traffic": traffic_sweep, "traffic_source": (PMC_FILE + " (rocprofv3 --pmc passes over "
+                         "tools/time_eval.py, committed, taken with this library build %s; not measured by this run)" % build_id)
+                         if traffic_sweep is not None else "null: " + traffic_why,
                          "launches": int(evals), "flops_per_launch": tot["cholinv_flops"] / max(evals, 1),
                          "achieved_is": "all sweep flops of the timed region / its wall time (several evaluations are in flight at once -- "
                                         "batched passes on %d lanes -- so per-launch intervals overlap)" % (lanes if args.lockstep else 1 + args.concurrency),
@@ -556,12 +605,12 @@ def main():
                                                  "run batched / beside other lanes"}},
             "roofline_predvar": {"kernel": "mfgp_predvar_f64 (V = K(X*,X) L^-T, one launch per predict)", "bound": "mfma",
                                  "achieved": round(pv_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": round(pv_tf / FP64_PEAK_TFLOPS, 4), "traffic": pmc_traffic("mfgp_predvar_f64", args.n),
+                                 "frac": round(pv_tf / FP64_PEAK_TFLOPS, 4), "traffic": pmc_traffic("mfgp_predvar_f64", args.n, build_id)[0],
                                  "launches": int(tot["predicts"]), "avg_launch_ms": round(tot["predict_var_ms"] / max(tot["predicts"], 1), 4)},
             "roofline_kbuild": {"kernel": "mfgp_kbuild_rbf2_f64<MODE_TRI> (K(X,X)+noise lower triangle, one launch per evaluation)",
                                 "bound": "hbm", "achieved": round(kb_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(kb_gbs / HBM_PEAK_GBS, 4),
-                                "traffic": pmc_traffic("mfgp_kbuild_rbf2_f64<0>", args.n),
+                                "traffic": pmc_traffic("mfgp_kbuild_rbf2_f64<0>", args.n, build_id)[0],
                                 "launches": int(evals), "avg_launch_ms": round(tot["kbuild_ms"] / max(evals, 1), 4),
                                 "uncontended": {"achieved": round(kb_gbs_alone, 1), "frac": round(kb_gbs_alone / HBM_PEAK_GBS, 4),
                                                 "avg_launch_ms": round(clf["kbuild_ms"] / max(clf["evals"], 1), 4)}},

@@ -103,6 +103,9 @@ int32_t mfgp_destroy(mfgp_handle* h);
 const char* mfgp_last_error(mfgp_handle* h);
 /* library / device identification string ("mfgp_hip gfx950 <device name> CUs=..") */
 const char* mfgp_device_info(mfgp_handle* h);
+/* hash of the sources this library was built from (build.py: sha256 over csrc/ + this header, 16 hex digits; "unknown" for a
+ * build that did not pass it): measurement files under profiles/ carry the id of the library they were taken with */
+const char* mfgp_build_id(void);
 
 /* replaces GPy.models.GPRegression(X=, Y=, kernel=) data capture
  * (src/MFDataFusion.py:93-98, src/abstractMFGP.py:100-102): one upload per fit.

@@ -24,7 +24,7 @@ def num_params(parts):
 
 # every symbol include/mfgp.h declares (tests check the .so exports each of them)
 EXPORTED_SYMBOLS = [
-    "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_set_data",
+    "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_build_id", "mfgp_set_data",
     "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_eval_batch", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
@@ -84,16 +84,14 @@ def load_library(path=None):
         raise EngineUnavailable(
             "%s not found: build it with `python -m multifidelity_datafusion_gps_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
-    # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues per priority (ROCm's default: 4).  A fit keeps up to
-    # four engine handles busy (low-fidelity level, high-fidelity level, two concurrent restarts), each with a high-priority
-    # chain stream and a low-priority bulk stream; measured with those eight streams (tools/gpu_r03_queues.sh,
-    # profiles/r03_hw_queues.txt): 2 queues per priority beat the default 4 -- cfg3's chain-bound HF level (N = 4096) 404 -> 345 ms
-    # per fit, the N = 8192 bench 1777 -> 1765 ms -- 3 are worse (500 / 1820), 1 serialises the evaluations (bench 1962),
-    # 8 and 12 equal 4; one evaluation alone does not care.  Only a default: the caller's own setting wins, and it must be in the
-    # environment before the HIP runtime initialises (the first library call), hence here.
-    # MFGP_HW_QUEUES=0 leaves the runtime's own default alone (a host application with its own stream-heavy HIP work).
-    if os.environ.get("MFGP_HW_QUEUES", "2") != "0":
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MFGP_HW_QUEUES", "2"))
+    # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues per priority (ROCm's default: 4).  For a fit that keeps
+    # several engine handles busy, 2 per priority measured best (profiles/r03_hw_queues.txt: cfg3's HF level 404 -> 345 ms, the
+    # N = 8192 bench 1777 -> 1765 ms).  OPT-IN: the setting is process-wide, changes the queue mapping of every other
+    # HIP user in the host application, and only takes effect if it is in the environment before the HIP runtime initialises --
+    # so it is applied only where the caller asks for it with MFGP_HW_QUEUES=<n> (bench.py and the tools do); a
+    # GPU_MAX_HW_QUEUES already in the environment wins.  `hw_queues_setting()` reports what is in effect.
+    if os.environ.get("MFGP_HW_QUEUES", "0") not in ("", "0"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ["MFGP_HW_QUEUES"])
     try:
         lib = ctypes.CDLL(p)
     except OSError as e:  # missing ROCm runtime etc.
@@ -106,6 +104,7 @@ def load_library(path=None):
         "mfgp_destroy": (i32, [H]),
         "mfgp_last_error": (ctypes.c_char_p, [H]),
         "mfgp_device_info": (ctypes.c_char_p, [H]),
+        "mfgp_build_id": (ctypes.c_char_p, []),
         "mfgp_set_data": (i32, [H, dp, i64, i32, dp]),
         "mfgp_set_kernel": (i32, [H, ctypes.POINTER(KernPart), i32]),
         "mfgp_num_params": (i32, [ctypes.POINTER(KernPart), i32]),
@@ -146,6 +145,16 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def hw_queues_setting():
+    """GPU_MAX_HW_QUEUES as this process will hand it to the HIP runtime ("runtime default" when unset)"""
+    return os.environ.get("GPU_MAX_HW_QUEUES", "runtime default")
+
+
+def build_id():
+    """the source hash the loaded library was built from (mfgp_build_id)"""
+    return load_library().mfgp_build_id().decode()
 
 
 def _dptr(a):

@@ -355,6 +355,17 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
                       % (step, planned, abs(reported), self.eps))
                 break
 
+    # ---- plotting: out of scope -------------------------------------------------------------------
+    def _no_plot(self, *args, **kwargs):
+        """the reference draws with matplotlib (src/abstractMFGP.py:139-273, called from src/MethodAssessment.py:51-56); this
+        package records what would have been drawn instead (`mse_history`, `acquired_points`, `acquisition_values`,
+        `last_diagonal_prediction`) -- callers that ask for a figure are told so, not handed an AttributeError"""
+        raise NotImplementedError("plotting is not part of this package (the reference's matplotlib code is out of scope): read "
+                                  "model.mse_history / acquired_points / acquisition_values / last_diagonal_prediction and plot them "
+                                  "with matplotlib in the calling code")
+
+    plot = plot_forecast = plot_uncertainties_2D = plot_compare_with_exact = _no_plot      # the reference's public plot methods
+
     def close(self):
         for e in self._engines.values():
             e.close()

@@ -15,6 +15,18 @@ SOURCES = ["gemm_f64.hip", "leaf_f64.hip", "covariance.hip", "vecops.hip", "comm
 HEADERS = ["mfgp_internal.h", "plan.h", os.path.join("..", "..", "include", "mfgp.h")]
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the library's sources -- csrc/*.hip, *.cpp, *.h and include/mfgp.h, in a fixed order:
+    embedded into libmfgp_hip.so when it is built (mfgp_build_id) and written into every counter summary under profiles/ when
+    it is produced, so that bench.py can tell whether committed counters still describe the library it loaded"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -53,11 +65,11 @@ def build_probes(force=False, verbose=False):
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    # MFGP_BUILD_DEFINES: extra -D switches of LAB builds on the GPU box (e.g. "-DMFGP_LAB_PLACEBO=1", tools/gpu_r03_placebo.sh);
-    # the library the repository ships is built without any
+    # MFGP_BUILD_DEFINES: extra -D switches of lab builds on the GPU box; the library the repository ships is built without any
     extra = os.environ.get("MFGP_BUILD_DEFINES", "").split()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-Wno-unused-value"] + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-result", "-Wno-unused-value", '-DMFGP_SRC_HASH="%s"' % source_hash()] + extra + ["-o", LIB] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

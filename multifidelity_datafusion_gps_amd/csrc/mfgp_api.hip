@@ -135,6 +135,11 @@ static int create_body(mfgp_handle* h, int device_id) {
 
 const char* mfgp_device_info(mfgp_handle* h) { return h ? h->info_str.c_str() : ""; }
 
+#ifndef MFGP_SRC_HASH
+#define MFGP_SRC_HASH "unknown"
+#endif
+const char* mfgp_build_id(void) { return MFGP_SRC_HASH; }
+
 static void free_batch(mfgp_handle* h) {
     for (double** p : {&h->bslab, &h->bz, &h->balpha, &h->blogdet, &h->bpart}) {
         if (*p) hipFree(*p);

@@ -42,6 +42,8 @@ def _enc(obj, out):
     elif isinstance(obj, (bool, np.bool_)):
         out.append(b"T" if obj else b"F")
     elif isinstance(obj, (int, np.integer)):
+        if not -(1 << 63) <= int(obj) < (1 << 63):
+            raise TypeError("integer %d does not fit the wire format's int64" % int(obj))
         out.append(b"i" + struct.pack("<q", int(obj)))
     elif isinstance(obj, (float, np.floating)):
         out.append(b"d" + struct.pack("<d", float(obj)))
@@ -51,10 +53,12 @@ def _enc(obj, out):
     elif isinstance(obj, (bytes, bytearray)):
         out.append(b"b" + struct.pack("<Q", len(obj)) + bytes(obj))
     elif isinstance(obj, np.ndarray):
-        a = np.ascontiguousarray(obj)
+        a = np.require(obj, requirements="C")        # (ascontiguousarray would turn a 0-d array into shape (1,))
         dt = a.dtype.newbyteorder("<").str if a.dtype.byteorder == ">" else a.dtype.str
         if dt not in _WIRE_DTYPES:
             raise TypeError("array dtype %s is not part of the wire format" % a.dtype)
+        if a.ndim > 8:
+            raise TypeError("arrays of more than 8 dimensions are not part of the wire format")
         a = a.astype(np.dtype(dt), copy=False)
         out.append(b"a" + struct.pack("<BB", _WIRE_DTYPES.index(dt), a.ndim) + struct.pack("<%dQ" % a.ndim, *a.shape))
         out.append(a.tobytes())
@@ -79,7 +83,12 @@ def wire_encode(obj):
     return b"".join(out)
 
 
-def _dec(buf, pos):
+_WIRE_MAX_DEPTH = 64      # nesting of lists / tuples / dicts a frame may carry (the payloads here nest three deep)
+
+
+def _dec(buf, pos, depth=0):
+    if depth > _WIRE_MAX_DEPTH:
+        raise ValueError("frame nests deeper than %d levels" % _WIRE_MAX_DEPTH)
     tag = buf[pos:pos + 1]
     pos += 1
     if tag == b"N":
@@ -109,9 +118,9 @@ def _dec(buf, pos):
         dt = np.dtype(_WIRE_DTYPES[di])
         count = 1
         for v in shape:
-            count *= v
+            count *= v                         # (python ints: no overflow; a header that claims more than the frame holds is refused)
         nbytes = count * dt.itemsize
-        if nbytes > len(buf) - pos:
+        if nbytes > len(buf) - pos or any(v > len(buf) for v in shape if count == 0):
             raise ValueError("truncated frame")
         a = np.frombuffer(buf, dtype=dt, count=count, offset=pos).reshape(shape).copy()
         return a, pos + nbytes
@@ -122,7 +131,7 @@ def _dec(buf, pos):
             raise ValueError("truncated frame")
         items = []
         for _ in range(n):
-            v, pos = _dec(buf, pos)
+            v, pos = _dec(buf, pos, depth + 1)
             items.append(v)
         return (items if tag == b"l" else tuple(items)), pos
     if tag == b"m":
@@ -132,16 +141,21 @@ def _dec(buf, pos):
             raise ValueError("truncated frame")
         d = {}
         for _ in range(n):
-            k, pos = _dec(buf, pos)
+            k, pos = _dec(buf, pos, depth + 1)
             if not isinstance(k, str):
                 raise ValueError("bad map key")
-            d[k], pos = _dec(buf, pos)
+            d[k], pos = _dec(buf, pos, depth + 1)
         return d, pos
     raise ValueError("unknown wire tag %r" % tag)
 
 
 def wire_decode(blob):
-    obj, pos = _dec(memoryview(blob), 0)
+    """-> the object; ValueError for ANY malformed frame (truncated, unknown tag, bad header, too deep): a collective that
+    receives one fails with that, not with whatever the parser happened to trip over"""
+    try:
+        obj, pos = _dec(memoryview(blob), 0)
+    except (struct.error, RecursionError, OverflowError, UnicodeDecodeError, MemoryError) as ex:
+        raise ValueError("malformed frame: %s" % ex.__class__.__name__) from ex
     if pos != len(blob):
         raise ValueError("trailing bytes in frame")
     return obj
@@ -204,8 +218,11 @@ class SocketComm:
         if self.size == 1:
             return
         loopback = addr in ("127.0.0.1", "localhost", "::1")
+        self._token_file = None
         if self.rank == 0:
+            _job_token.last_file = None
             key = _job_token(token, port, create=True, loopback=loopback)
+            self._token_file = _job_token.last_file      # (None when the launcher provided the token)
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             # loopback unless a multi-node address was asked for explicitly (then that interface, never 0.0.0.0)
@@ -397,6 +414,12 @@ class SocketComm:
             except OSError:
                 pass
         self._peers, self._hub = [], None
+        if getattr(self, "_token_file", None):        # rank 0 of a token-file rendezvous: the file has served its job
+            try:
+                os.unlink(self._token_file)
+            except OSError:
+                pass
+            self._token_file = None
 
 
 def rehearsal_env(rank):
@@ -446,6 +469,7 @@ def _job_token(token, port, create, loopback):
         with os.fdopen(fd, "wb") as f:
             f.write(key)
         os.replace(tmp, path)
+        _job_token.last_file = path
         return key
     st = os.stat(d)                          # FileNotFoundError (an OSError): rank 0 is not there yet -> the caller retries
     if st.st_uid != os.getuid() or (st.st_mode & 0o077):

@@ -58,3 +58,38 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", txt, flags=re.M), \
                     "%s imports test infrastructure" % os.path.join(dirpath, f)
                 assert "gp_oracle" not in txt, "%s references the oracle" % os.path.join(dirpath, f)
+
+
+def test_committed_counters_are_only_reported_for_the_library_build_they_were_taken_with(tmp_path, monkeypatch):
+    """profiles/r0N_pmc.json / r0N_mfma_counters.json carry the hash of the sources they were taken with;
+    bench.py reports their numbers only when that hash is the one embedded in the library it loaded (mfgp_build_id), and
+    null + the reason otherwise -- a kernel change can no longer keep stale counters in the bench line."""
+    import json
+    import bench
+    from multifidelity_datafusion_gps_amd import _lib, build
+    lib_id = _lib.build_id()
+    assert lib_id == build.source_hash() and len(lib_id) == 16          # the in-tree library was built from the in-tree sources
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    pmc = {"n": 8192, "csrc_hash": lib_id, "sweep": {"traffic_bytes": 123}}
+    mf = {"csrc_hash": lib_id, "pmcA_eval": {"mfgp_gemm_nt_f64_t128": {"mfma_busy": 0.8}}}
+    (prof / "pmc.json").write_text(json.dumps(pmc))
+    (prof / "mfma.json").write_text(json.dumps(mf))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "PMC_FILE", "profiles/pmc.json")
+    monkeypatch.setattr(bench, "MFMA_FILE", "profiles/mfma.json")
+    assert bench.pmc_traffic("sweep", 8192, lib_id) == (123, None)
+    assert bench.mfma_busy(lib_id)[0] == {"mfgp_gemm_nt_f64_t128": 0.8}
+    assert bench.pmc_traffic("sweep", 4096, lib_id)[0] is None           # another size
+    # edit the hash: nulls, with the reason
+    pmc["csrc_hash"] = mf["csrc_hash"] = "0123456789abcdef"
+    (prof / "pmc.json").write_text(json.dumps(pmc))
+    (prof / "mfma.json").write_text(json.dumps(mf))
+    t, why = bench.pmc_traffic("sweep", 8192, lib_id)
+    assert t is None and "0123456789abcdef" in why and lib_id in why
+    b, why = bench.mfma_busy(lib_id)
+    assert b is None and "0123456789abcdef" in why
+    # no stamp at all (the round-3 files): nulls as well
+    del pmc["csrc_hash"]
+    (prof / "pmc.json").write_text(json.dumps(pmc))
+    assert bench.pmc_traffic("sweep", 8192, lib_id) == (None, "profiles/pmc.json carries no csrc_hash (taken before the sources were stamped)")

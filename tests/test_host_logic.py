@@ -313,3 +313,20 @@ def test_ard_kernel_through_the_host_layer_with_the_oracle_double():
     assert len(model.hf_model.optimizer_array) == 2 + 3 + 3 + 1
     Xt = rng.uniform(size=(50, 2))
     assert model.get_mse(Xt, hf(Xt)) < 1e-2
+
+
+def test_plot_methods_say_what_to_do_instead():
+    """the reference's public plot methods (src/abstractMFGP.py:139-169,380: matplotlib, out of scope) exist and fail with a
+    message, not with AttributeError (INTEGRATION.md option A: src/MethodAssessment.py:51-56 calls model.plot())"""
+    from multifidelity_datafusion_gps_amd.abstractMFGP import AbstractMFGP
+    for name in ("plot", "plot_forecast", "plot_uncertainties_2D", "plot_compare_with_exact"):
+        with pytest.raises(NotImplementedError, match="matplotlib"):
+            getattr(AbstractMFGP, name)(None)
+
+
+def test_bench_never_starts_the_power_sampler_under_a_profiler():
+    """under rocprofv3 the sampler's child tree would inherit the preloaded tool library"""
+    import bench
+    assert not bench.under_profiler({"PATH": "/usr/bin"})
+    for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB"):
+        assert bench.under_profiler({k: "librocprofiler-sdk-tool.so"})

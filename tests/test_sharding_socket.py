@@ -148,7 +148,14 @@ def _token_worker(rank, world, port, q, token):
     from multifidelity_datafusion_gps_amd.sharding import SocketComm
     comm = SocketComm(rank, world, "127.0.0.1", port, timeout=30, token=token)
     try:
-        q.put((rank, comm.allgather_object(rank)))
+        res = comm.allgather_object(rank)
+        mode = None
+        if rank == 0 and getattr(comm, "_token_file", None):
+            import os
+            import stat
+            mode = stat.S_IMODE(os.stat(comm._token_file).st_mode)      # the token file while the job is alive
+        modes = comm.allgather_object(mode)
+        q.put((rank, res if token is not None else res + [modes[0]]))
     finally:
         comm.close()
 
@@ -222,10 +229,10 @@ def test_token_file_rendezvous_without_an_explicit_token(tmp_path, monkeypatch):
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    assert out == {0: [0, 1], 1: [0, 1]}
+    assert out == {0: [0, 1, 0o600], 1: [0, 1, 0o600]}                  # (third entry: the token file's mode while the job ran)
     d = tmp_path / "mfgp-comm"
     assert stat.S_IMODE(d.stat().st_mode) == 0o700
-    assert stat.S_IMODE((d / ("token-%d" % port)).stat().st_mode) == 0o600
+    assert not (d / ("token-%d" % port)).exists()                       # rank 0 removed it when it closed
 
 
 class _HangingEngine(_FakeEngine):
@@ -354,3 +361,29 @@ def test_restart_assignment_on_eight_ranks():
     assert a == [[], [], [], [5], [4], [3], [2], [1]]
     assert AbstractMFGP.assign_restarts(6, 2) == [[4], [1, 2, 3, 5]] and AbstractMFGP.assign_restarts(6, 1) == [[1, 2, 3, 4, 5]]
     assert AbstractMFGP.assign_restarts(6, 4) == [[], [3], [2, 5], [1, 4]]
+
+
+def test_wire_format_edge_cases():
+    """0-d arrays keep their shape, out-of-range ints are refused on the sending side, every malformed frame is a
+    ValueError on the receiving side (truncation, absurd nesting, absurd array headers)"""
+    import struct
+    from multifidelity_datafusion_gps_amd.sharding import wire_decode, wire_encode
+    a0 = np.array(3.5)
+    back = wire_decode(wire_encode(a0))
+    assert back.shape == () and back == 3.5
+    e = np.zeros((0, 4))
+    assert wire_decode(wire_encode(e)).shape == (0, 4)
+    with pytest.raises(TypeError):
+        wire_encode(2 ** 63)
+    with pytest.raises(TypeError):
+        wire_encode(-2 ** 63 - 1)
+    assert wire_decode(wire_encode(2 ** 63 - 1)) == 2 ** 63 - 1
+    deep = b"l" + struct.pack("<Q", 1)
+    with pytest.raises(ValueError):
+        wire_decode(deep * 2000 + b"N")
+    with pytest.raises(ValueError):
+        wire_decode(b"a" + struct.pack("<BB", 0, 2) + struct.pack("<2Q", 0, 2 ** 63))      # (0, 2^63) array header
+    with pytest.raises(ValueError):
+        wire_decode(b"i" + b"\x00" * 3)                                                     # truncated int
+    with pytest.raises(ValueError):
+        wire_decode(b"s" + struct.pack("<Q", 2) + b"\xff\xfe")                             # not UTF-8

@@ -1,6 +1,7 @@
 """One batched objective+gradient pass (mfgp_eval_batch) against B single evaluations: ms per pass and per evaluation, executed
 TFLOP/s (Np^3 flops per evaluation).  usage: batch_eval.py [N ...]   (env BATCHES="1 2 3 4 6 8")"""
 import os
+os.environ.setdefault("MFGP_HW_QUEUES", "2")   # opt-in since round 4 (2 hardware queues per priority: profiles/r03_hw_queues.txt)
 import sys
 import time
 

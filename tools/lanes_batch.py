@@ -1,6 +1,7 @@
 """lanes x batch: L engine handles driven by L host threads, each running batched passes of B evaluations back to back --
 aggregate ms per evaluation.  usage: lanes_batch.py N "L:B L:B ..." """
 import os
+os.environ.setdefault("MFGP_HW_QUEUES", "2")   # opt-in since round 4 (2 hardware queues per priority: profiles/r03_hw_queues.txt)
 import sys
 import threading
 import time

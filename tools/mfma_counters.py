@@ -86,6 +86,9 @@ for tag in ("pmcA_probes", "pmcA_eval", "pmcB_eval", "pmcC_eval"):
         res[tag] = table(disp, sorted(disp), per_dispatch=True)
     else:
         res[tag] = table(disp, last_eval(disp))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multifidelity_datafusion_gps_amd.build import source_hash  # noqa: E402
+res["csrc_hash"] = source_hash()      # the sources the profiled library was built from (bench.py checks it against mfgp_build_id)
 print(json.dumps(res, indent=1))
 if len(sys.argv) > 2:
     json.dump(res, open(sys.argv[2], "w"), indent=1)

@@ -3,6 +3,7 @@ evaluations per run): sequential restarts (the reference's order), concurrent on
 LOCK-STEPPED runs over one batched evaluation per round (round 4, the default).
 usage: midsize_fit.py [--evals E] N_hf [N_hf ...]"""
 import os
+os.environ.setdefault("MFGP_HW_QUEUES", "2")   # opt-in since round 4 (2 hardware queues per priority: profiles/r03_hw_queues.txt)
 import sys
 import time
 

@@ -6,9 +6,12 @@ for wide coalesced reads on gfx950; WRITE_SIZE is taken as is.  Per kernel: the 
 over every leaf / tile-GEMM dispatch of ONE evaluation (the dispatches between the last two K-build launches of the trace:
 tools/time_eval.py runs the same evaluation several times), i.e. the traffic of the Cholesky + inverse + K^-1 stage whose
 flops bench.py's `roofline` reports."""
-import csv, json, sys, statistics
+import csv, json, os, sys, statistics
 
-KERNELS = ["mfgp_kbuild_rbf2_f64<0>", "mfgp_kbuild_f64<0>", "mfgp_predvar_f64", "mfgp_grad_rbf2_f64", "mfgp_grad_tiles_f64",
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multifidelity_datafusion_gps_amd.build import source_hash  # noqa: E402  (the sources the profiled library was built from)
+
+KERNELS = ["mfgp_kbuild_rbf2_batch_f64", "mfgp_kbuild_rbf2_f64<0>", "mfgp_kbuild_f64<0>", "mfgp_predvar_f64", "mfgp_grad_rbf2_f64", "mfgp_grad_tiles_f64",
            "mfgp_predv_skinny_f64", "mfgp_kinv_syrk_f64", "mfgp_gemm_nt_f64_t128", "mfgp_gemm_nt_f64_t64",
            "mfgp_gemm_nt_f64_chain", "mfgp_leaf_cholinv_f64", "mfgp_rowdot_f64"]
 SWEEP = ("mfgp_gemm_nt_f64_t128", "mfgp_gemm_nt_f64_t64", "mfgp_gemm_nt_f64_chain", "mfgp_leaf_cholinv_f64")
@@ -66,7 +69,8 @@ def main():
     res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (with --kernel-trace only) over "
                    "`python3 tools/time_eval.py %d`; per kernel: per launch, median over the launches in the trace; 'sweep': sum over "
                    "the leaf + tile-GEMM dispatches of one evaluation. FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) "
-                   "prescribes for wide coalesced reads on gfx950; WRITE_SIZE is taken as is." % n, "n": n}
+                   "prescribes for wide coalesced reads on gfx950; WRITE_SIZE is taken as is." % n, "n": n,
+           "csrc_hash": source_hash()}
     for k in KERNELS:
         if k in fetch or k in write:
             fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
