@@ -476,14 +476,24 @@ def main():
         engines["hf#%d" % j] = Engine(local_rank)
     collectives = "none (1 rank)"
     if world > 1:
+        # librccl prints a version banner on the C-level stdout when its first communicator comes up: this job's stdout carries
+        # ONE JSON line, so the banner goes to stderr
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         try:
-            comm.attach_engine(engines["hf"], required=True)
+            # the world communicator lives in the LOW-fidelity level's handle: its run is then shared by all ranks
+            # (mfgp_eval_sharded) and the high-fidelity handle stays free for the group that shares first run -> restart 0
+            comm.attach_engine(engines["lf"], required=True)
         except sharding.RcclInitError as ex:
             # agreed by every rank over TCP: all of them end here.  No fall-back to TCP: a line that says n_gpus = N
             # must come from N ranks on RCCL.  os._exit: where the initialisation hangs, its thread never returns.
             sys.stderr.write("bench.py: rank %d: the RCCL communicator of %d ranks was not created: %s\n" % (rank, world, ex))
             sys.stderr.flush()
             os._exit(3)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         collectives = "rccl (ncclAllGather on the engine stream; rendezvous + object gathers over tcp)"
         if args.single_device:
             collectives += "; single-device rehearsal: %d ranks on GPU 0 posing as %d hosts (NCCL_HOSTID), RCCL socket transport" % (world, world)
@@ -516,8 +526,8 @@ def main():
     rowblock = None
     if world > 1:
         try:
-            th, nz = np.ones(6), 0.05
-            e = engines["hf"]
+            th, nz = np.ones(2), 0.05
+            e = engines["lf"]                 # (the handle that carries the world communicator)
             e.eval(th, nz)
             barrier()
             t1 = time.perf_counter()
@@ -575,7 +585,7 @@ def main():
                                            % (lanes, args.width or "auto")) if args.lockstep
                                           else "concurrent restarts on %d auxiliary handles" % args.concurrency,
                        "restart_concurrency": None if args.lockstep else args.concurrency, "collectives": collectives,
-                       "ranks": world, "rccl_ranks": int(engines["hf"].comm_size), "library_build_id": build_id,
+                       "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
                        "sharding": "randomized restarts + predictive rows over ranks; LF run on rank 0 (the others adopt its optimum); "
                                    "first HF run -> restart 0 on rank 0 only"},
@@ -635,6 +645,33 @@ def main():
                                "note": "value cannot fall below serial_floor_ms however many GPUs share the restarts and the "
                                        "predictive rows (the first HF run and restart 0 are one chain of %d + %d evaluations)"
                                        % (args.evals, args.evals)}
+        # ... and what the floor becomes where the sequential evaluations are SHARED by a group of GPUs (mfgp_eval_sharded: the
+        # LF run by all G ranks, first run -> restart 0 by rank 0 and the ranks that were dealt no restart): one rank's device work
+        # of such an evaluation measured HERE (mfgp_dbg_eval_as_rank: rank 0 of G, no exchange), the exchange priced at one xGMI
+        # link (153 GB/s) per owner -- a PROJECTION from one GPU, never run over xGMI
+        if world == 1 and args.n >= 2048:
+            try:
+                proj = {}
+                e_hf, e_lf = engines["hf"], engines["lf"]
+                npad = (args.n + 127) // 128 * 128
+                for G in (2, 3, 4, 8):
+                    t_hf = sorted(e_hf.dbg_eval_as_rank(np.ones(6), 0.05, 0, G) for _ in range(3))[1]
+                    t_lf = sorted(e_lf.dbg_eval_as_rank(np.ones(2), 0.05, 0, G) for _ in range(3))[1]
+                    xch = (4.0 * npad * npad / G) / 153e9 * 1e3        # every peer's chunk of the packed rows over its own link (ideal)
+                    proj[str(G)] = {"hf_rank_ms": round(t_hf, 3), "lf_rank_ms": round(t_lf, 3), "exchange_ms_model": round(xch, 3)}
+                groups = {"2": (2, 1), "4": (4, 1), "8": (8, 3)}       # ranks: (LF group, chain group = rank 0 + ranks without a restart)
+                floors = {}
+                n_lf = clf["evals"] / args.steps
+                for n_gpu, (g_lf, g_ch) in groups.items():
+                    lf_eval = proj[str(g_lf)]["lf_rank_ms"] + proj[str(g_lf)]["exchange_ms_model"]
+                    ch_eval = alone_ms if g_ch == 1 else proj[str(g_ch)]["hf_rank_ms"] + proj[str(g_ch)]["exchange_ms_model"]
+                    floors[n_gpu] = round(n_lf * lf_eval + chain_evals * ch_eval + predict_ms / int(n_gpu), 1)
+                out["serial_floor_sharded_projection"] = {
+                    "per_rank": proj, "floor_ms_by_gpus": floors,
+                    "note": "one GPU's measured share of a sharded evaluation + a bandwidth model of the exchange; the 1 -> 8 GPU "
+                            "curve itself has not been measured on hardware"}
+            except Exception as ex:  # noqa: BLE001 - diagnostic only
+                out["serial_floor_sharded_projection"] = {"error": repr(ex)[:200]}
         if not streamed:
             out["roofline_kinv"] = {"kernel": "mfgp_kinv_syrk_f64 (stand-alone K^-1 launch)", "bound": "mfma",
                                     "achieved": round(kinv_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -652,7 +689,9 @@ def main():
         print(json.dumps(out), flush=True)
     comm.barrier()
     if world > 1 and comm.transport == "rccl":
-        engines["hf"].comm_destroy()      # every rank still alive: destroy the communicator before anyone exits
+        for e_ in engines.values():       # every rank still alive: destroy the communicators (world, chain group) before anyone exits
+            if e_.comm_size > 1:
+                e_.comm_destroy()
         comm.barrier()
     comm.close()
 

@@ -165,6 +165,25 @@ int32_t mfgp_comm_init(mfgp_handle* h, const uint8_t* id128, int32_t rank, int32
 int32_t mfgp_comm_destroy(mfgp_handle* h);
 int32_t mfgp_allgather_rows(mfgp_handle* h);
 int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, double* recv);
+/* mfgp_eval_sharded: mfgp_eval as ONE evaluation across the ranks of the handle's communicator (collective: every rank calls it
+ *   with the same arguments on the same data; a handle without a communicator is the group of one).  The Cholesky's serial chain
+ *   does not shard and runs on every rank; the other two thirds of the evaluation's N^3 flops -- the rows of L^-T and, after one
+ *   exchange of those rows (their upper-triangular part packed by owner, ONE in-place ncclAllGather of 4 Np^2 bytes in all), the
+ *   rows of K^-1 and the gradient's tile
+ *   sums (one ncclAllReduce of P + 1 sums per tile) -- are split by 128-row block.  Every rank returns the same nlml / grad,
+ *   BITWISE those of mfgp_eval, and is left with the complete factorisation (mfgp_predict works; mfgp_get_Kinv does not: a rank
+ *   holds only its own rows).  What a fit's SEQUENTIAL evaluations -- the low-fidelity run, first run -> restart 0 of
+ *   src/abstractMFGP.py:131-137 -- gain from more GPUs. */
+int32_t mfgp_eval_sharded(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, double* nlml,
+                          double* grad);
+/* The same with ONE optimiser: rank 0 of the communicator LEADS (mfgp_sharded_lead = mfgp_eval_sharded whose arguments reach the
+ *   other ranks in a 64-double control block, one ncclBroadcast per evaluation), the others SERVE (mfgp_sharded_serve blocks,
+ *   runs its share of every evaluation the leader asks for, returns -- with their number -- when the leader calls
+ *   mfgp_sharded_release).  This is how the host layer runs an L-BFGS-B run's evaluations on a group: the optimiser exists once. */
+int32_t mfgp_sharded_lead(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, double* nlml,
+                          double* grad);
+int32_t mfgp_sharded_serve(mfgp_handle* h, int64_t* served);
+int32_t mfgp_sharded_release(mfgp_handle* h);
 int32_t mfgp_rows_download(mfgp_handle* h, int64_t row_begin, int64_t row_end, double* out);
 int32_t mfgp_rows_upload(mfgp_handle* h, int64_t row_begin, int64_t row_end, const double* in);
 
@@ -224,6 +243,10 @@ int32_t mfgp_device_synchronize(mfgp_handle* h);
  * Any other tile is reported as an error (status < 0): the library never terminates the host process. */
 int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, double* C, int32_t M,
                          int32_t N, int32_t K, double alpha, double beta, int32_t tile);
+/* the device work of rank `rank` of `size` of one mfgp_eval_sharded WITHOUT its exchange steps; *ms = its duration (what one GPU
+ * of a `size`-GPU group would spend; the results are not an evaluation's and the handle is left without a factorisation) */
+int32_t mfgp_dbg_eval_as_rank(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, int32_t rank,
+                              int32_t size, double* ms);
 /* Cholesky + inverse of one SPD 128x128 block through the leaf kernel: Lout, Xout are 128x128. */
 int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xout, double* logdet_half);
 #ifdef __cplusplus

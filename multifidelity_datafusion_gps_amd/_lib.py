@@ -25,13 +25,13 @@ def num_params(parts):
 # every symbol include/mfgp.h declares (tests check the .so exports each of them)
 EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_build_id", "mfgp_set_data",
-    "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_eval_batch", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
+    "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_eval_batch", "mfgp_eval_sharded", "mfgp_sharded_lead", "mfgp_sharded_serve", "mfgp_sharded_release", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters", "mfgp_device_synchronize",
     "mfgp_comm_unique_id", "mfgp_comm_init", "mfgp_comm_destroy", "mfgp_allgather_rows", "mfgp_allgather_host",
     "mfgp_rows_download", "mfgp_rows_upload",
-    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf",
+    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_eval_as_rank",
 ]
 
 
@@ -110,6 +110,11 @@ def load_library(path=None):
         "mfgp_num_params": (i32, [ctypes.POINTER(KernPart), i32]),
         "mfgp_eval": (i32, [H, dp, f64, f64, i32, dp, dp]),
         "mfgp_eval_batch": (i32, [H, i32, dp, dp, dp, i32, dp, dp, ctypes.POINTER(i32)]),
+        "mfgp_eval_sharded": (i32, [H, dp, f64, f64, i32, dp, dp]),
+        "mfgp_dbg_eval_as_rank": (i32, [H, dp, f64, f64, i32, i32, i32, dp]),
+        "mfgp_sharded_lead": (i32, [H, dp, f64, f64, i32, dp, dp]),
+        "mfgp_sharded_serve": (i32, [H, ctypes.POINTER(i64)]),
+        "mfgp_sharded_release": (i32, [H]),
         "mfgp_kbuild_rows": (i32, [H, dp, f64, f64, i64, i64]),
         "mfgp_dev_matrix": (i32, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(i64)]),
         "mfgp_eval_prebuilt": (i32, [H, i32, dp, dp]),
@@ -256,6 +261,44 @@ class Engine:
                                  ctypes.byref(nlml), _dptr(grad))
         self._check(rc, "mfgp_eval")
         return (nlml.value, grad) if want_grad else nlml.value
+
+    def eval_sharded(self, theta, noise, jitter=1e-8, want_grad=True):
+        """eval() as ONE evaluation across the ranks of this handle's communicator (collective; comm_init first; without a
+        communicator: the group of one).  Same results as eval(), bit for bit, on every rank."""
+        theta = self._theta(theta)
+        nlml = ctypes.c_double()
+        grad = np.zeros(self.n_params + 1)
+        rc = self._lib.mfgp_eval_sharded(self._h, _dptr(theta), float(noise), float(jitter), int(bool(want_grad)),
+                                         ctypes.byref(nlml), _dptr(grad))
+        self._check(rc, "mfgp_eval_sharded")
+        return (nlml.value, grad) if want_grad else nlml.value
+
+    def sharded_lead(self, theta, noise, jitter=1e-8, want_grad=True):
+        """rank 0 of the communicator: eval_sharded whose arguments travel to the serving ranks (sharded_serve) with the call"""
+        theta = self._theta(theta)
+        nlml = ctypes.c_double()
+        grad = np.zeros(self.n_params + 1)
+        rc = self._lib.mfgp_sharded_lead(self._h, _dptr(theta), float(noise), float(jitter), int(bool(want_grad)),
+                                         ctypes.byref(nlml), _dptr(grad))
+        self._check(rc, "mfgp_sharded_lead")
+        return (nlml.value, grad) if want_grad else nlml.value
+
+    def sharded_serve(self):
+        """ranks > 0: run this rank's share of every evaluation the leader asks for; returns their number at the leader's release"""
+        n = ctypes.c_int64()
+        self._check(self._lib.mfgp_sharded_serve(self._h, ctypes.byref(n)), "mfgp_sharded_serve")
+        return n.value
+
+    def sharded_release(self):
+        self._check(self._lib.mfgp_sharded_release(self._h), "mfgp_sharded_release")
+
+    def dbg_eval_as_rank(self, theta, noise, rank, size, jitter=1e-8, want_grad=True):
+        """-> milliseconds of the device work of rank `rank` of `size` of a sharded evaluation, without its exchange steps"""
+        theta = self._theta(theta)
+        ms = ctypes.c_double()
+        self._check(self._lib.mfgp_dbg_eval_as_rank(self._h, _dptr(theta), float(noise), float(jitter), int(bool(want_grad)),
+                                                    int(rank), int(size), ctypes.byref(ms)), "mfgp_dbg_eval_as_rank")
+        return ms.value
 
     MAX_BATCH = 16
 

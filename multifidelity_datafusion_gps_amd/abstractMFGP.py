@@ -48,6 +48,9 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
                                 # of another).  None: 2 below N = 6144 (fits 8-15 % faster than on one lane at N = 1024 .. 4096,
                                 # profiles/r04_midsize_fit.txt), 1 from there (N = 8192: the job sits at the socket's power cap
                                 # either way; one lane of 4 evaluations measured 1 % ahead of 2 x 2)
+    shard_sequential = True     # multi-GPU: the fit's SEQUENTIAL evaluations -- the low-fidelity run (all ranks would idle through it)
+                                # and first run -> restart 0 (beside the ranks that were dealt no restart) -- are shared by a group
+                                # of ranks (mfgp_eval_sharded: same numbers bit for bit, the rows of L^-T / K^-1 split); needs RCCL
     restart_lend_main = False   # the main engine joins the restarts' pool once its sequential runs are through
     restart_aux = None          # auxiliary engine handles of the concurrent restarts (None: restart_concurrency of them)
     diagonal_points = 1000      # resolution of the box diagonal the adaptation loop predicts on every step (:318)
@@ -149,9 +152,25 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         if self.comm.size == 1:
             run()
             return
-        if self.comm.rank == 0:
+        group = self._group(model, list(range(self.comm.size)))
+        if group is not None:
+            group.run(model, run)          # ONE optimiser (rank 0), every evaluation shared by all ranks
+        elif self.comm.rank == 0:
             run()
         model.optimizer_array = self.comm.bcast_object(model.optimizer_array if self.comm.rank == 0 else None, src=0)
+
+    def _group(self, model, members):
+        """the ShardGroup of `members` on `model`'s engine, or None (no RCCL, a test double, shard_sequential off, a group of
+        one); formed once per (engine, members) and kept -- the call is collective over all ranks"""
+        if not self.shard_sequential or len(members) < 2 or not hasattr(self.comm, "shard_group"):
+            return None
+        if getattr(self.comm, "transport", None) != "rccl":
+            return None                    # (the collectives of a shared evaluation are RCCL's; a TCP-only job keeps rank 0's own runs)
+        key = (id(model._engine), tuple(members))
+        cache = self.__dict__.setdefault("_shard_groups", {})
+        if key not in cache:
+            cache[key] = self.comm.shard_group(model._engine, members)
+        return cache[key]
 
     def _lf_posterior_mean(self, t):
         """f_low of a data-driven level: the CURRENT low-fidelity GP's posterior mean (mean only: the O(N^2 N*) variance
@@ -225,7 +244,27 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         first run (noise pinned), then restart 0, which continues from it -- the other slots are this rank's randomized
         restarts (as in _ard_concurrent: `assign_restarts`); every round is one batched pass over the live slots."""
         rank, size = self.comm.rank, self.comm.size
-        mine_bg = self.assign_restarts(num_restarts, size)[rank]
+        assign = self.assign_restarts(num_restarts, size)
+        mine_bg = assign[rank]
+        # the ranks that were dealt no restart share the sequential pair's evaluations with rank 0 (8 GPUs, 6 restarts: ranks 1-2)
+        chain_members = [0] + [r for r in range(1, size) if not assign[r]]
+        chain = self._group(model, chain_members) if (size > 1 and not assign[0]) else None
+        if chain is not None:
+            runs = []
+            if chain.leads:
+                chain.run(model, lambda: model.optimize(max_iters=self.first_run_max_iters))
+                self._free_noise(model)
+                r0 = chain.run(model, lambda: model.optimize(max_iters=self.restart_max_iters))
+                if r0 is not None:
+                    runs.append((r0.f_opt, r0.x_opt, 0))
+            else:
+                chain.run(model, None)
+                self._free_noise(model)
+                chain.run(model, None)
+            runs = [r for part in self.comm.allgather_object(runs) for r in part]
+            # (the ranks outside the group ran their restarts through the code below: every rank reaches the same two gathers)
+            self._install_winner(model, runs, rank, size)
+            return
         own = 1 if rank == 0 else 0
         n_runs = len(mine_bg) + 2 * own
         width = int(self.lockstep_width) if self.lockstep_width else (n_runs + 1) // 2
@@ -269,6 +308,9 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         self.last_lockstep_lanes = lanes
         if size > 1:
             runs = [r for part in self.comm.allgather_object(runs) for r in part]
+        self._install_winner(model, runs, rank, size)
+
+    def _install_winner(self, model, runs, rank, size):
         if runs:
             best = min(runs, key=lambda r: (r[0], r[2]))
             model.optimizer_array = best[1]

@@ -27,6 +27,9 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    // (optional: only mfgp_eval_sharded needs them)
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string load_error;
 };
@@ -55,6 +58,10 @@ RcclApi& rccl() {
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        if (ok) {
+            api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(api.lib, "ncclBroadcast"));
+            api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+        }
         if (!ok) { dlclose(api.lib); api.lib = nullptr; }
     });
     return api;
@@ -73,6 +80,32 @@ void comm_release(mfgp_handle* h) {
         h->comm_rank = 0;
         h->comm_size = 1;
     }
+}
+
+int comm_allgather_chunks(mfgp_handle* h, double* base, size_t chunk, hipStream_t s) {
+    if (!h->comm || h->comm_size <= 1) return 0;
+    ncclResult_t r = rccl().AllGather(base + (size_t)h->comm_rank * chunk, base, chunk, ncclDouble,
+                                      static_cast<ncclComm_t>(h->comm), s);
+    if (r != ncclSuccess) return rccl_fail(h, "ncclAllGather (rows of X^T)", r);
+    return 0;
+}
+
+int comm_bcast_words(mfgp_handle* h, double* dev, size_t count, int root, hipStream_t s) {
+    if (!h->comm || h->comm_size <= 1) return 0;
+    RcclApi& api = rccl();
+    if (!api.Broadcast) return fail(h, -4, "librccl lacks ncclBroadcast");
+    ncclResult_t r = api.Broadcast(dev, dev, count, ncclDouble, root, static_cast<ncclComm_t>(h->comm), s);
+    if (r != ncclSuccess) return rccl_fail(h, "ncclBroadcast (control block)", r);
+    return 0;
+}
+
+int comm_allreduce_sum(mfgp_handle* h, double* buf, size_t count, hipStream_t s) {
+    if (!h->comm || h->comm_size <= 1) return 0;
+    RcclApi& api = rccl();
+    if (!api.AllReduce) return fail(h, -4, "librccl lacks ncclAllReduce");
+    ncclResult_t r = api.AllReduce(buf, buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(h->comm), s);
+    if (r != ncclSuccess) return rccl_fail(h, "ncclAllReduce (gradient tile partials)", r);
+    return 0;
 }
 }  // namespace mfgp
 

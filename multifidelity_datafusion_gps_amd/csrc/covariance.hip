@@ -489,10 +489,20 @@ __device__ __forceinline__ void block_sum_to(double v, double* sred, double* dst
     __syncthreads();
 }
 
+// A SHARDED evaluation (mfgp_eval_sharded) reduces only the tiles whose rows of K^-1 this rank holds: `shard` = rank | size << 16
+// (0: every tile); the other tiles' slots of `partials` stay as the caller zeroed them, the ranks' arrays are then summed
+// (x + 0 = x: the sum is bitwise the single rank's array) and finished as usual.  Same ownership rule as plan.h shard_owner.
+__device__ __forceinline__ bool tile_row_is_mine(int bi, int shard) {
+    const int size = shard >> 16, rank = shard & 0xffff;
+    if (size <= 1) return true;
+    const int x = ((bi * KT) / 128) % (2 * size);
+    return (x < size ? x : 2 * size - 1 - x) == rank;
+}
+
 __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const double* __restrict__ X,
                                                            const double* __restrict__ Kinv, int ld,
                                                            const double* __restrict__ alpha, int N,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, int shard) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sxi = smem;
     double* sxj = smem + sp.D * XP;
@@ -501,6 +511,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
     int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
     while (bi * (bi + 1) / 2 > b) --bi;
+    if (!tile_row_is_mine(bi, shard)) return;
     const int bj = b - bi * (bi + 1) / 2;
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_finish_f64(KernSpecDev sp,
 __device__ __forceinline__ void grad_rbf2_body(const Rbf2Spec& sp, const double* __restrict__ X,
                                                const double* __restrict__ Kinv, int ld,
                                                const double* __restrict__ alpha, int N,
-                                               double* __restrict__ partials) {
+                                               double* __restrict__ partials, int shard = 0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sxi = smem;
     double* sxj = smem + sp.D * XP;
@@ -627,6 +638,7 @@ __device__ __forceinline__ void grad_rbf2_body(const Rbf2Spec& sp, const double*
     int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
     while (bi * (bi + 1) / 2 > b) --bi;
+    if (!tile_row_is_mine(bi, shard)) return;
     const int bj = b - bi * (bi + 1) / 2;
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
@@ -710,8 +722,8 @@ __device__ __forceinline__ void grad_rbf2_body(const Rbf2Spec& sp, const double*
 __global__ __launch_bounds__(256) void mfgp_grad_rbf2_f64(Rbf2Spec sp, const double* __restrict__ X,
                                                           const double* __restrict__ Kinv, int ld,
                                                           const double* __restrict__ alpha, int N,
-                                                          double* __restrict__ partials) {
-    grad_rbf2_body(sp, X, Kinv, ld, alpha, N, partials);
+                                                          double* __restrict__ partials, int shard) {
+    grad_rbf2_body(sp, X, Kinv, ld, alpha, N, partials, shard);
 }
 // the B sets of a batched evaluation: blockIdx.y = set
 __global__ __launch_bounds__(256) void mfgp_grad_rbf2_batch_f64(Rbf2Batch specs, const double* __restrict__ X,
@@ -750,20 +762,28 @@ int grad_num_partials(int Np) {
     return nt * (nt + 1) / 2;
 }
 
-void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
-                 const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
-                 double* out) {
+void launch_grad_tiles(hipStream_t s, const KernSpecDev& spec, const double* X, const double* Kinv, int ld,
+                       const double* alpha, int N, int Np, double* partials, int shard_rank, int shard_size) {
     const int nb = grad_num_partials(Np);
     const size_t lds = kb_lds(spec.D) + (size_t)8 * sizeof(double);
+    const int shard = shard_size > 1 ? (shard_rank | (shard_size << 16)) : 0;
     Rbf2Spec f;
     if (rbf2_match(spec, f)) {
         hipLaunchKernelGGL(mfgp_grad_rbf2_f64, dim3(nb), dim3(256), kb_lds(spec.D) + (size_t)256 * 6 * sizeof(double), s, f, X,
-                           Kinv, ld, alpha, N, partials);
+                           Kinv, ld, alpha, N, partials, shard);
     } else {
         hipLaunchKernelGGL(mfgp_grad_tiles_f64, dim3(nb), dim3(256), lds, s, spec, X, Kinv, ld, alpha, N,
-                           partials);
+                           partials, shard);
     }
-    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(spec.np + 1), dim3(256), 0, s, spec, partials, nb, out);
+}
+void launch_grad_finish(hipStream_t s, const KernSpecDev& spec, const double* partials, int Np, double* out) {
+    hipLaunchKernelGGL(mfgp_grad_finish_f64, dim3(spec.np + 1), dim3(256), 0, s, spec, partials, grad_num_partials(Np), out);
+}
+void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
+                 const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
+                 double* out) {
+    launch_grad_tiles(s, spec, X, Kinv, ld, alpha, N, Np, partials, 0, 1);
+    launch_grad_finish(s, spec, partials, Np, out);
 }
 
 void launch_grad_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, const double* Kinv, long long kstride,

@@ -37,8 +37,8 @@ static int upload_tasks(mfgp_handle* h) {
 
 // One step of a plan.  nbatch > 0: over the handle's batch sets (mfgp_eval_batch) instead of its own slab -- the same launch
 // with one more grid dimension.  -> 0, or -1 when the planner asked for a kernel that does not exist (h->err says which).
-static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nbatch = 0) {
-    const GemmTask* const dtasks = nbatch > 0 ? h->dtasks_b : h->dtasks;
+static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nbatch = 0, const GemmTask* tasks = nullptr) {
+    const GemmTask* const dtasks = tasks ? tasks : (nbatch > 0 ? h->dtasks_b : h->dtasks);
     const bool batched = nbatch > 0;
     hipStream_t st = (s.strm == 1 && h->stream2) ? h->stream2 : h->stream;
     const long long bstride = batched ? 4LL * h->cap * h->cap : 0;
@@ -176,6 +176,10 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->dAug) hipFree(h->dAug);
     if (h->dtasks) hipFree(h->dtasks);
     if (h->dtasks_b) hipFree(h->dtasks_b);
+    if (h->dtasks_s) hipFree(h->dtasks_s);
+    if (h->dshard_off) hipFree(h->dshard_off);
+    if (h->dctl) hipFree(h->dctl);
+    if (h->hctl) hipHostFree(h->hctl);
     comm_release(h);
     if (h->dstage) hipFree(h->dstage);
     if (h->hres) hipHostFree(h->hres);
@@ -191,6 +195,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
 static int build_plans(mfgp_handle* h) {
     build_plan(h->pl, h->nblk, h->Np, (int64_t)h->cap * h->cap, plan_opts_from_env());
     h->plb_div = 0;      // the batch plan follows: rebuilt, under the same switches, when the next batch arrives
+    h->pls.nblk = 0;     // ... and so does the plan of a sharded evaluation
     while ((int)h->evpool.size() < h->pl.n_events) {
         hipEvent_t e;
         // the plan's events order kernels of ONE device across the handle's two streams: no system-scope fence (cache
@@ -567,6 +572,242 @@ int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const d
         if (grad)
             for (int i = 0; i < np + 1; ++i) grads[(size_t)b * (np + 1) + i] = r[64 + i];
     }
+    return 0;
+}
+
+// ---- sharded evaluation ------------------------------------------------------------------------------------------
+// One evaluation across the `size` ranks of the handle's communicator (one process per GPU).
+// Every rank runs the Cholesky in full -- its serial chain does not shard -- but only ITS share of the other two thirds of
+// the flops: the rows of X^T (the image of the identity) and, after ONE exchange of those rows, the rows of K^-1 and the
+// gradient's tile sums (plan.h Shard: 128-row blocks, serpentine block-cyclic).  No result bit differs from mfgp_eval:
+// every tile is computed by exactly the tasks the single evaluation runs, the tile sums of the gradient meet in ONE array
+// (sum over ranks of arrays that are zero where a rank holds nothing) and are finished in the same fixed order.
+static int ensure_shard_plan(mfgp_handle* h, int rank, int size) {
+    if (h->pls.nblk == h->nblk && h->pls.ld == h->Np && h->pls.shard.rank == rank && h->pls.shard.size == size &&
+        h->pls.stride == (int64_t)h->cap * h->cap)
+        return 0;
+    build_plan(h->pls, h->nblk, h->Np, (int64_t)h->cap * h->cap, h->pl.opts, 1, Shard{rank, size});
+    while ((int)h->evpool.size() < h->pls.n_events) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+        h->evpool.push_back(e);
+    }
+    const size_t need = h->pls.tasks.size();
+    if (need > h->tasks_s_cap) {
+        if (h->dtasks_s) HIPCHK(h, hipFree(h->dtasks_s));
+        h->tasks_s_cap = need + need / 2 + 1024;
+        HIPCHK(h, hipMalloc(&h->dtasks_s, h->tasks_s_cap * sizeof(GemmTask)));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->dtasks_s, h->pls.tasks.data(), need * sizeof(GemmTask), hipMemcpyHostToDevice, h->stream));
+    // the exchange's layout: block b (128 x (Np - 128 b) doubles of the upper part of S) at offset off[b] of its owner's chunk
+    std::vector<long long> off((size_t)h->nblk), fill((size_t)size, 0);
+    for (int b = 0; b < h->nblk; ++b) {
+        const int own = shard_owner(b, size);
+        off[(size_t)b] = fill[(size_t)own];
+        fill[(size_t)own] += 128LL * (h->Np - 128LL * b);
+    }
+    h->shard_chunk = *std::max_element(fill.begin(), fill.end());
+    // staging: the workspace matrix W wherever size x chunk fits it (always at sizes worth sharding: the chunks sum to ~Np^2 / 2);
+    // a few blocks on many ranks pad beyond that -- then a buffer of its own
+    if ((long long)size * h->shard_chunk > (long long)h->cap * h->cap && (size_t)size * (size_t)h->shard_chunk > h->stage_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->dstage) HIPCHK(h, hipFree(h->dstage));
+        h->dstage = nullptr;
+        h->stage_cap = (size_t)size * (size_t)h->shard_chunk;
+        HIPCHK(h, hipMalloc(&h->dstage, h->stage_cap * sizeof(double)));
+    }
+    if (h->nblk > h->shard_off_cap) {
+        if (h->dshard_off) HIPCHK(h, hipFree(h->dshard_off));
+        h->shard_off_cap = h->nblk + 64;
+        HIPCHK(h, hipMalloc(&h->dshard_off, (size_t)h->shard_off_cap * sizeof(long long)));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->dshard_off, off.data(), (size_t)h->nblk * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// the pass of rank `rank` of `size`; exchange = false: without the collectives (what one rank's GPU does, timed by
+// mfgp_dbg_eval_as_rank for the projections of DESIGN.md section 7 -- its results are NOT an evaluation's)
+static int sharded_pass(mfgp_handle* h, const double* theta, double noise, double jitter, bool want_grad, int rank, int size,
+                        bool exchange) {
+    int rc = ensure_shard_plan(h, rank, size);
+    if (rc) return rc;
+    rc = set_params(h, theta, noise, jitter);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    const int Np = (int)h->Np;
+    h->launches = 0;
+    *h->hinfo = 0;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], s));
+    launch_kbuild_tri(s, h->spec, h->dX, (int)h->N, Np, h->buf[BUF_A], Np);
+    h->launches++;
+    if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[1], s));
+    for (const Step& st : h->pls.steps)
+        if (run_step(h, st, false, 0, h->dtasks_s) != 0) return -1;
+    if (exchange && size > 1) {
+        // the rows of X^T to everybody: this rank's blocks packed into its chunk of the staging buffer (the workspace matrix W: the
+        // image of the identity it held is dead once the sweep has joined), ONE in-place ncclAllGather, the others' blocks unpacked
+        double* stage = (long long)size * h->shard_chunk <= (long long)h->cap * h->cap ? h->buf[BUF_W] : h->dstage;
+        launch_shard_rows_copy(s, h->buf[BUF_S], Np, h->nblk, stage, h->dshard_off, h->shard_chunk, rank, size, false);
+        rc = comm_allgather_chunks(h, stage, (size_t)h->shard_chunk, s);
+        if (rc) return rc;
+        launch_shard_rows_copy(s, h->buf[BUF_S], Np, h->nblk, stage, h->dshard_off, h->shard_chunk, rank, size, true);
+        h->launches += 2;
+    }
+    launch_mirror_lower(s, h->buf[BUF_S], Np, Np);                              // X (lower part) from X^T (upper part)
+    h->launches++;
+    if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[2], s));
+    launch_rowdot(s, h->buf[BUF_S], Np, h->dY, h->dz, Np, Np, 0);
+    launch_alpha_finish(s, h->buf[BUF_S], Np, h->dz, h->dalpha, Np, h->dlogdet, h->nblk, h->dres);
+    h->launches += 2;
+    if (h->stage_timing || (!want_grad && h->timing)) HIPCHK(h, hipEventRecord(h->ev[3], s));
+    if (want_grad) {
+        if (run_step(h, h->pls.kinv_step, true, 0, h->dtasks_s) != 0) return -1;   // this rank's rows of K^-1
+        if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[4], s));
+        const size_t npart = (size_t)grad_num_partials(Np) * (MFGP_MAX_THETA + 1);
+        HIPCHK(h, hipMemsetAsync(h->dpart, 0, npart * sizeof(double), s));
+        launch_grad_tiles(s, h->spec, h->dX, h->buf[BUF_A], Np, h->dalpha, (int)h->N, Np, h->dpart, rank, size);
+        if (exchange) {
+            rc = comm_allreduce_sum(h, h->dpart, npart, s);
+            if (rc) return rc;
+        }
+        launch_grad_finish(s, h->spec, h->dpart, Np, h->dres + 64);
+        h->launches += 3;
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+static int sharded_finish(mfgp_handle* h, bool want_grad);
+
+int32_t mfgp_eval_sharded(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, double* nlml,
+                          double* grad) {
+    int rc = check_ready(h, "mfgp_eval_sharded");
+    if (rc) return rc;
+    if (!theta) return fail(h, -1, "mfgp_eval_sharded: theta is NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = sharded_pass(h, theta, noise, jitter, want_grad != 0, h->comm_rank, h->comm_size, true);
+    if (rc) return rc;
+    rc = sharded_finish(h, want_grad != 0);
+    if (rc) return rc;
+    if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
+    if (want_grad && grad)
+        for (int i = 0; i < h->spec.np + 1; ++i) grad[i] = h->grad[i];
+    return 0;
+}
+
+// ---- leader / follower form -----------------------------------------------------------------------------------------
+// A fit's sequential evaluations are driven by ONE optimiser (scipy L-BFGS-B on the leader, rank 0 of the group); the other
+// ranks of the group have no optimiser of their own to keep in step: they SERVE -- mfgp_sharded_serve blocks, takes each
+// evaluation's hyper-parameters from the leader (one broadcast of a 64-double control block on the communicator), runs its
+// share, and returns when the leader releases the group (mfgp_sharded_release).
+constexpr int CTL_WORDS = 64;     // [0] op (1 evaluate, 0 release)  [1] want_grad  [2] noise  [3] jitter  [4] P  [5 ..] theta
+static_assert(5 + MFGP_MAX_THETA <= CTL_WORDS, "control block holds every parameter");
+
+static int ctl_exchange(mfgp_handle* h, double* ctl, bool leader) {
+    if (!h->dctl) {
+        HIPCHK(h, hipMalloc(&h->dctl, CTL_WORDS * sizeof(double)));
+        HIPCHK(h, hipHostMalloc(&h->hctl, CTL_WORDS * sizeof(double), hipHostMallocDefault));
+    }
+    hipStream_t s = h->stream;
+    if (leader) {
+        memcpy(h->hctl, ctl, CTL_WORDS * sizeof(double));
+        HIPCHK(h, hipMemcpyAsync(h->dctl, h->hctl, CTL_WORDS * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    const int rc = comm_bcast_words(h, h->dctl, CTL_WORDS, 0, s);
+    if (rc) return rc;
+    if (!leader) {
+        HIPCHK(h, hipMemcpyAsync(h->hctl, h->dctl, CTL_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        memcpy(ctl, h->hctl, CTL_WORDS * sizeof(double));
+    }
+    return 0;
+}
+
+static int sharded_finish(mfgp_handle* h, bool want_grad) {
+    const bool streamed_flag = h->pl.kinv_streamed;       // finish_eval's flop accounting looks at the handle's own plan:
+    h->pl.kinv_streamed = false;                          // a sharded pass never streams K^-1
+    const int rc = finish_eval(h, want_grad);
+    h->pl.kinv_streamed = streamed_flag;
+    h->kinv_valid = false;                                // (this rank holds only its own rows of K^-1)
+    return rc;
+}
+
+int32_t mfgp_sharded_lead(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, double* nlml,
+                          double* grad) {
+    int rc = check_ready(h, "mfgp_sharded_lead");
+    if (rc) return rc;
+    if (!theta) return fail(h, -1, "mfgp_sharded_lead: theta is NULL");
+    if (h->comm_rank != 0) return fail(h, -1, "mfgp_sharded_lead: only rank 0 of the handle's communicator leads");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int i = 0; i < h->spec.np; ++i)      // (checked BEFORE the followers are told: a refused call must not leave them mid-pass)
+        if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "parameters must be positive and finite");
+    if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "noise and jitter must be >= 0");
+    double ctl[CTL_WORDS] = {1.0, want_grad ? 1.0 : 0.0, noise, jitter, (double)h->spec.np};
+    for (int i = 0; i < h->spec.np; ++i) ctl[5 + i] = theta[i];
+    rc = ctl_exchange(h, ctl, true);
+    if (rc) return rc;
+    rc = sharded_pass(h, theta, noise, jitter, want_grad != 0, 0, h->comm_size, true);
+    if (rc) return rc;
+    rc = sharded_finish(h, want_grad != 0);
+    if (rc) return rc;
+    if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
+    if (want_grad && grad)
+        for (int i = 0; i < h->spec.np + 1; ++i) grad[i] = h->grad[i];
+    return 0;
+}
+
+int32_t mfgp_sharded_release(mfgp_handle* h) {
+    if (!h) return fail(h, -1, "mfgp_sharded_release: NULL");
+    if (h->comm_rank != 0) return fail(h, -1, "mfgp_sharded_release: only rank 0 of the handle's communicator leads");
+    HIPCHK(h, hipSetDevice(h->device));
+    double ctl[CTL_WORDS] = {0.0};
+    const int rc = ctl_exchange(h, ctl, true);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int32_t mfgp_sharded_serve(mfgp_handle* h, int64_t* served) {
+    int rc = check_ready(h, "mfgp_sharded_serve");
+    if (rc) return rc;
+    if (!h->comm || h->comm_rank == 0) return fail(h, -1, "mfgp_sharded_serve: for ranks > 0 of the handle's communicator");
+    HIPCHK(h, hipSetDevice(h->device));
+    int64_t n = 0;
+    for (;;) {
+        double ctl[CTL_WORDS];
+        rc = ctl_exchange(h, ctl, false);
+        if (rc) return rc;
+        if (ctl[0] == 0.0) break;
+        if ((int)ctl[4] != h->spec.np) return fail(h, -1, "mfgp_sharded_serve: the leader's kernel has another parameter count");
+        const bool g = ctl[1] != 0.0;
+        rc = sharded_pass(h, ctl + 5, ctl[2], ctl[3], g, h->comm_rank, h->comm_size, true);
+        if (rc) return rc;
+        rc = sharded_finish(h, g);      // > 0: not positive definite -- the leader sees the same pivot and decides what comes next
+        if (rc < 0) return rc;
+        ++n;
+    }
+    if (served) *served = n;
+    return 0;
+}
+
+// test / measurement hook: the device work of rank `rank` of `size` for one evaluation, WITHOUT the exchange steps; *ms = its
+// duration (HIP events).  The handle is left without a valid factorisation.
+int32_t mfgp_dbg_eval_as_rank(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, int32_t rank,
+                              int32_t size, double* ms) {
+    int rc = check_ready(h, "mfgp_dbg_eval_as_rank");
+    if (rc) return rc;
+    if (!theta || !ms || size < 1 || rank < 0 || rank >= size) return fail(h, -1, "mfgp_dbg_eval_as_rank: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const bool t0 = h->timing;
+    h->timing = true;
+    rc = sharded_pass(h, theta, noise, jitter, want_grad != 0, rank, size, false);
+    h->timing = t0;
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *ms = ev_ms(h->ev[0], h->ev[want_grad ? 5 : 3]);
+    h->factorized = h->kinv_valid = h->grad_valid = false;
     return 0;
 }
 

@@ -92,6 +92,16 @@ void launch_grad(hipStream_t s, const KernSpecDev& spec, const double* X,
                  const double* Kinv, int ld, const double* alpha, int N, int Np, double* partials,
                  double* out);
 int grad_num_partials(int Np);
+//   the two halves of launch_grad: the tile partials (shard_size > 1: only the tiles whose rows of K^-1 rank shard_rank holds;
+//   the caller zeroes `partials` first) and the fixed-order finish
+void launch_grad_tiles(hipStream_t s, const KernSpecDev& spec, const double* X, const double* Kinv, int ld,
+                       const double* alpha, int N, int Np, double* partials, int shard_rank, int shard_size);
+void launch_grad_finish(hipStream_t s, const KernSpecDev& spec, const double* partials, int Np, double* out);
+//   lower part of the mirrored inverse S <- transpose of its upper part (sharded evaluation, after the exchange of the rows of X^T)
+void launch_mirror_lower(hipStream_t s, double* S, int ld, int Np);
+//   pack this rank's blocks of the upper part of S into / unpack the other ranks' blocks out of the exchange's staging buffer
+void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* stage, const long long* off, long long chunk,
+                            int rank, int size, bool unpack);
 //   nbatch sets: K^-1 of set b at Kinv + b * kstride, alpha + b * astride, partials + b * pstride, out + b * ostride; thetas =
 //   device-readable copy of the sets' parameter vectors, tstride apart (the finishing kernel divides by them)
 void launch_grad_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, const double* Kinv, long long kstride,
@@ -169,6 +179,13 @@ struct mfgp_handle {
     double *bz = nullptr, *balpha = nullptr, *blogdet = nullptr, *bpart = nullptr;
     double *bhres = nullptr, *bdres = nullptr;   // BRES doubles per set: [0,1] scalars, [30] pivot status, [64..] gradient, [128..] theta
     static constexpr int BRES = 256;
+    long long* dshard_off = nullptr;     // offset of every 128-row block inside its owner's chunk of the exchange (device copy)
+    long long shard_chunk = 0;           // doubles per rank in the exchange's all-gather
+    int shard_off_cap = 0;
+    double *dctl = nullptr, *hctl = nullptr;   // control block of the leader / follower form of a sharded evaluation (device, pinned host)
+    mfgp::Plan pls;                      // this rank's plan of a sharded evaluation (mfgp_eval_sharded), cached per (rank, size)
+    mfgp::GemmTask* dtasks_s = nullptr;
+    size_t tasks_s_cap = 0;
     mfgp::Plan plb;                      // the batch's own plan: same macro panels (same arithmetic), 128-tiles from fewer tiles per set
     int plb_div = 0;                     // the t128 divisor plb was built for (0: none yet)
     mfgp::GemmTask* dtasks_b = nullptr;
@@ -192,5 +209,13 @@ inline int fail(mfgp_handle* h, int code, const std::string& msg) {
 }
 // releases the communicator of a handle (no-op without one); defined in comm_rccl.hip
 void comm_release(mfgp_handle* h);
+// collectives of a sharded evaluation on the handle's communicator and stream (no-ops for a communicator of one / none):
+//   -> 0 or a negative status (h->err set)
+//   in-place all-gather of equal chunks: rank r's `chunk` doubles already sit at base + r * chunk
+int comm_allgather_chunks(mfgp_handle* h, double* base, size_t chunk, hipStream_t s);
+//   element-wise sum of `buf` over the ranks, in place
+int comm_allreduce_sum(mfgp_handle* h, double* buf, size_t count, hipStream_t s);
+//   `count` doubles at device address `dev` from rank `root` to every rank, in place
+int comm_bcast_words(mfgp_handle* h, double* dev, size_t count, int root, hipStream_t s);
 
 }  // namespace mfgp

@@ -418,6 +418,7 @@ static void plan_kinv(Plan& p) {
         for (int j0 = 0; j0 <= std::min(nt - 1, i0 + BI - 1); j0 += BJ)
             for (int i = i0; i < std::min(nt, i0 + BI); ++i)
                 for (int j = j0; j < std::min(j0 + BJ, i + 1); ++j) {
+                    if (shard_owner(i * T / NB, p.shard.size) != p.shard.rank) continue;   // a sharded evaluation: own block rows only
                     GemmTask t{};
                     t.a_off = (int64_t)i * T * ld + (int64_t)i * T;
                     t.b_off = (int64_t)j * T * ld + (int64_t)i * T;
@@ -443,8 +444,9 @@ void plan_predv(Plan& p, int rows_p) {
     const int T = pick_tile(p, nb * rb);
     const int sc = NB / T;
     const int first = (int)p.tasks.size();
-    const int BI = 8, BR = 4;                                // super-blocks: BI rows of X  x  BR panel rows (traffic 13.5-15.1 GB
-                                                             // over the shapes tried at N = N* = 8192, time unchanged)
+    // super-blocks: BI rows of X  x  BR panel rows.  Fabric reads (FETCH_SIZE x 2) of the launch at N = N* = 8192 by shape,
+    // time unchanged throughout (round 4, gpurun_out/r04k): 8 x 4 14.2 GB, 16 x 4 14.3, 4 x 16 15.1, 4 x 8 13.0, 8 x 8 12.9
+    const int BI = 8, BR = 8;
     const int ni = nb * sc, nr = rb * sc;
     for (int i0 = ni - 1; i0 >= 0; i0 -= BI)                 // large i (= long K range) first
         for (int r0 = 0; r0 < nr; r0 += BR)
@@ -521,7 +523,8 @@ static void plan_sweep(Plan& p) {
     // bulk stream and fewer, larger workgroups disturb it less.
     const int CT = nb < 48 ? 32 : 64;
     const int chain_role_ct = CT == 32 ? 5 : chain_role;
-    p.kinv_streamed = opt(p.opts.kinv_stream, 1) != 0;
+    p.kinv_streamed = opt(p.opts.kinv_stream, 1) != 0 && p.shard.size <= 1;   // (sharded: K^-1 follows the exchange of the rows of X^T)
+    const auto mine = [&](int64_t row) { return shard_owner((int)(row / NB), p.shard.size) == p.shard.rank; };
     int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
     const bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
     // One macro panel (nothing runs beside the chain): K^-1 is accumulated column by column in the chain's own K = 128 launches
@@ -537,7 +540,7 @@ static void plan_sweep(Plan& p) {
     // Tiles are enumerated in SUPER-BLOCKS of bulk_bi x bulk_bj output tiles (bi row panels + bj column panels feed
     // bi*bj tiles): after the XCD-aware deal below the workgroups that run side by side on one XCD (own L2) share their
     // operand panels instead of each streaming its own pair from HBM / Infinity Cache.
-    const int bulk_bi = 4, bulk_bj = 4;   // (sweep fetch 22.8 -> 17.9 -> 16.8 GB from row-major over 4x4 super-blocks to the XCD-aware deal)
+    const int bulk_bi = 4, bulk_bj = 4;   // (round 4: 8 x 4 19.2 -> 17.2 GB of fabric reads per sweep at +0.8 % time, 8 x 8 18.1: not taken)  (sweep fetch 22.8 -> 17.9 -> 16.8 GB from row-major over 4x4 super-blocks to the XCD-aware deal)
     auto in_blocks = [&](int ilo, int ihi, int jlo, int jhi, auto&& fn) {   // fn(i, j) over [ilo,ihi) x [jlo,jhi)
         for (int i0 = ilo; i0 < ihi; i0 += bulk_bi)
             for (int j0 = jlo; j0 < jhi; j0 += bulk_bj)
@@ -562,20 +565,22 @@ static void plan_sweep(Plan& p) {
                      (int)((int64_t)(j + 1) * T - kc), TF_B_LOWER, 1.0, 0.0);
     };
     // X^T[i, c] = B[i, klo*NB : (c+1)*NB) X[c, same]^T for block rows i in [ilo, ihi): result into S (upper) + mirror
-    auto x_panel = [&](int T, int c, int klo, int ilo, int ihi) {
+    auto x_panel = [&](int T, int c, int klo, int ilo, int ihi, bool own_only = false) {
         const int sc = NB / T;
         const int64_t k0 = (int64_t)klo * NB;
         for (int i = ilo * sc; i < ihi * sc; ++i)
             for (int j = c * sc; j < (c + 1) * sc; ++j)
+                if (!own_only || mine((int64_t)i * T))
                 push(at(BUF_W, (int64_t)i * T, k0), at(BUF_S, (int64_t)j * T, k0), at(BUF_S, (int64_t)i * T, (int64_t)j * T),
                      at(BUF_S, (int64_t)j * T, (int64_t)i * T), (int)((int64_t)(j + 1) * T - k0), TF_B_LOWER, 1.0, 0.0);
     };
     // B[i,j] -= X^T[i, klo:khi] L[j, klo:khi]^T for block rows i in [ilo, ihi), block columns j in [jlo, jhi); a row that
     // lies inside [klo, khi) starts at its own diagonal block (X^T is upper triangular) and is the FIRST touch of its
     // B tiles (beta = 0).  Used K = 128 deep on the chain (inside the macro panel) and K = chunk deep on the bulk stream.
-    auto b_update = [&](int T, int ilo, int ihi, int jlo, int jhi, int klo, int khi) {
+    auto b_update = [&](int T, int ilo, int ihi, int jlo, int jhi, int klo, int khi, bool own_only = false) {
         const int sc = NB / T;
         in_blocks(ilo * sc, ihi * sc, jlo * sc, jhi * sc, [&](int i, int j) {
+            if (own_only && !mine((int64_t)i * T)) return;
             const bool inside = (int64_t)i * T >= (int64_t)klo * NB;
             const int64_t k0 = inside ? (int64_t)i * T : (int64_t)klo * NB;
             push(at(BUF_S, (int64_t)i * T, k0), at(BUF_L, (int64_t)j * T, k0), at(BUF_W, (int64_t)i * T, (int64_t)j * T), -1,
@@ -710,7 +715,7 @@ static void plan_sweep(Plan& p) {
                 const int T = pick_tile(p, n_cols + n_x);
                 const int first = (int)p.tasks.size();
                 a_update(T, lo, hi + 1, M0, M1);
-                for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
+                for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0, true);
                 cols_launch(T, first);
             } else {
                 if (have_cols) {
@@ -722,7 +727,7 @@ static void plan_sweep(Plan& p) {
                 if (have_x) {
                     const int T = pick_tile(p, n_x);
                     const int first = (int)p.tasks.size();
-                    for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0);
+                    for (int c = M0; c < M1; ++c) x_panel(T, c, M0, 0, M0, true);
                     if (launch(T, first, 1, 0)) bulk_steps.push_back(p.steps.size() - 1);
                 }
             }
@@ -743,8 +748,8 @@ static void plan_sweep(Plan& p) {
                 xcd_interleave(p.tasks, first, bulk_bi * bulk_bj);            // deal the super-blocks to the 8 XCDs (workgroup p runs on XCD p mod 8)
             };
             auto common = [&]() {
-                if (!last) b_update(T, 0, M1, M1, M2, M0, M1);                 // catch-up of the next macro's columns
-                if (!last && M2 < nb) b_update(T, 0, M1, M2, nb, M0, M1);      // the columns beyond
+                if (!last) b_update(T, 0, M1, M1, M2, M0, M1, true);           // catch-up of the next macro's columns
+                if (!last && M2 < nb) b_update(T, 0, M1, M2, nb, M0, M1, true);   // the columns beyond
                 if (a_lo < nb) a_update(T, a_lo, nb, M0, M1);
             };
             const int first = (int)p.tasks.size();
@@ -805,9 +810,11 @@ static void plan_sweep(Plan& p) {
     }
 }
 
-void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& opts, int t128_div) {
+void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& opts, int t128_div, const Shard& shard) {
     p = Plan{};
     p.opts = opts;
+    p.shard = shard;
+    if (shard.size > 1) p.opts.kind = 0;      // a sharded evaluation always runs the sweep
     p.t128_min = std::max(1, (opts.t128_min > 0 ? opts.t128_min : (nblk >= 56 ? 600 : 300)) / std::max(1, t128_div));
     p.nblk = nblk;
     p.ld = ld;

@@ -64,6 +64,19 @@ struct PlanOpts {
     int chain_slim = -1;   // MFGP_CHAIN_SLIM
     int t128_min = 0;      // MFGP_T128_MIN: tiles per launch from which 128-tiles are used
 };
+// Row ownership of a sharded evaluation (mfgp_eval_sharded): the work on the image of the identity / the rows of X^T and the rows
+// of K^-1 -- 2 N^3 / 3 of an evaluation's N^3 flops -- splits by 128-row block with no dependency between blocks; block b belongs
+// to rank shard_owner(b, size): block-cyclic in serpentine order (0 1 .. G-1 G-1 .. 1 0 ...), because the work of a block row
+// falls with its index (rows of X^T: ~ (nb - b)^2) or peaks in the middle (rows of K^-1: ~ b (nb - b)).
+struct Shard {
+    int rank = 0, size = 1;
+};
+inline int shard_owner(int blk, int size) {
+    if (size <= 1) return 0;
+    const int x = blk % (2 * size);
+    return x < size ? x : 2 * size - 1 - x;
+}
+
 struct Plan {
     int nblk = 0;
     int64_t ld = 0;                 // = padded size Np
@@ -78,13 +91,18 @@ struct Plan {
     int t128_min = 300;             // tiles per launch from which 128-tiles are used (64-tiles below)
     bool kinv_streamed = false;     // the steps accumulate K^-1 behind the chain
     PlanOpts opts;                  // the switches it was planned under
+    Shard shard;                    // size > 1: this rank's share of a sharded evaluation (see Shard)
 };
 
 PlanOpts plan_opts_from_env();
 // t128_div > 1: the plan of a BATCHED evaluation of about that many matrix sets per launch -- a launch carries t128_div times
 // the tiles, so the 128-tile threshold is reached that much earlier (tile sizes do not change any result bit: a tile's
 // elements accumulate over k in the same order in both kernels)
-void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& opts = PlanOpts(), int t128_div = 1);
+// shard.size > 1: the plan of ONE RANK of a sharded evaluation -- the Cholesky (chain, trailing updates of A) in full, the bulk
+// work on B / X^T and the stand-alone K^-1 launch for the rank's own block rows only, K^-1 never streamed (it needs every rank's
+// rows of X^T: it follows the exchange).  Tile sizes are chosen from the UNSHARDED tile counts; no result bit depends on them.
+void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& opts = PlanOpts(), int t128_div = 1,
+                const Shard& shard = Shard());
 // (re)plan the predictive-variance product for a panel of rows_p rows; keeps everything planned before it
 void plan_predv(Plan& p, int rows_p);
 

@@ -196,6 +196,53 @@ void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* l
     hipLaunchKernelGGL(mfgp_finish_solve_f64, dim3(1), dim3(256), 0, s, z, Np, logdet_part, nblk, scalars);
 }
 
+// lower part of the mirrored inverse S from its upper part: S[c][r] = S[r][c] for r < c, by 64x64 tiles through LDS (a sharded
+// evaluation receives the ROWS of X^T -- the upper part -- from their owners and rebuilds X, the lower part, here).  Grid:
+// the lower-triangle tiles (bi >= bj) as in the K build; tile (bi, bj) is written from tile (bj, bi).
+__global__ __launch_bounds__(256) void mfgp_mirror_lower_f64(double* __restrict__ S, int ld) {
+    __shared__ double t[64][65];
+    const int b = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+    while (bi * (bi + 1) / 2 > b) --bi;
+    const int bj = b - bi * (bi + 1) / 2;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) t[r][tx] = S[(int64_t)(bj * 64 + r) * ld + bi * 64 + tx];   // upper tile (bj, bi), row-wise
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        if (bi == bj && tx >= r) continue;                                                          // diagonal tile: strictly lower only
+        S[(int64_t)(bi * 64 + r) * ld + bj * 64 + tx] = t[tx][r];
+    }
+}
+// The exchange of a sharded evaluation moves only what the other ranks lack: for every 128-row block b of X^T its columns from
+// the diagonal on (the upper part of S), packed densely -- block b is 128 x (Np - 128 b) doubles at offset off[b] of its owner's
+// chunk -- so that ONE in-place ncclAllGather of equal chunks carries every rank's rows (the serpentine ownership makes the
+// chunks equal to within a block; they are padded to the largest).  pack: this rank's blocks S -> stage; unpack: the others'
+// blocks stage -> S.  One workgroup per (row of a block, block).
+__global__ __launch_bounds__(256) void mfgp_shard_rows_copy_f64(double* __restrict__ S, int ld, double* __restrict__ stage,
+                                                                const long long* __restrict__ off, long long chunk, int rank,
+                                                                int size, int unpack) {
+    const int b = blockIdx.y, r = blockIdx.x;
+    const int x = b % (2 * size), own = x < size ? x : 2 * size - 1 - x;        // plan.h shard_owner
+    if ((own == rank) == (unpack != 0)) return;
+    const int w = ld - b * 128;                                                    // (ld = Np)
+    double* rowS = S + (long long)(b * 128 + r) * ld + b * 128;
+    double* rowP = stage + (long long)own * chunk + off[b] + (long long)r * w;
+    const d2_t* src = reinterpret_cast<const d2_t*>(unpack ? rowP : rowS);
+    d2_t* dst = reinterpret_cast<d2_t*>(unpack ? rowS : rowP);
+    for (int k = threadIdx.x; k < w / 2; k += 256) dst[k] = src[k];
+}
+void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* stage, const long long* off, long long chunk,
+                            int rank, int size, bool unpack) {
+    hipLaunchKernelGGL(mfgp_shard_rows_copy_f64, dim3(128, nblk), dim3(256), 0, s, S, ld, stage, off, chunk, rank, size,
+                       unpack ? 1 : 0);
+}
+
+void launch_mirror_lower(hipStream_t s, double* S, int ld, int Np) {
+    const int nt = Np / 64;
+    hipLaunchKernelGGL(mfgp_mirror_lower_f64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, S, ld);
+}
+
 // ---- device-resident level chaining -------------------------------------------------
 // stencil rows t0 .. t0+n of the (rows*c, d) stack  T[i*c + j] = Xc[i] + offs[j]  (src/MFDataFusion.py:190-197:
 // the low-fidelity level is evaluated at x + i*tau for every stencil offset i); rows n .. n_p are zero padding.

@@ -161,6 +161,30 @@ def wire_decode(blob):
     return obj
 
 
+class ShardGroup:
+    """a group of ranks that shares ONE evaluation at a time on `engine` (its handle holds the group's RCCL communicator)"""
+
+    def __init__(self, engine, index, size):
+        self.engine, self.index, self.size = engine, int(index), int(size)
+
+    @property
+    def leads(self):
+        return self.index == 0
+
+    def run(self, model, fn):
+        """the leader runs `fn()` -- any sequence of optimiser runs on `model` -- with every evaluation of the model shared by
+        the group; the other members serve until it is through.  -> fn()'s result on the leader, None on the others."""
+        if not self.leads:
+            self.engine.sharded_serve()
+            return None
+        model._eval_hook = lambda th, nz, jit: self.engine.sharded_lead(th, nz, jit, want_grad=True)
+        try:
+            return fn()
+        finally:
+            model._eval_hook = None
+            self.engine.sharded_release()
+
+
 class RcclInitError(RuntimeError):
     """the RCCL communicator could not be created on every rank.  `.hung` says that this rank's ncclCommInitRank never
     returned: the engine handle is then still in use by the stuck thread and must not be touched again -- the only
@@ -394,6 +418,58 @@ class SocketComm:
         if required:
             raise RcclInitError(errs[0])
         return False
+
+    def shard_group(self, engine, members, init_timeout=120.0):
+        """collective over ALL ranks: an RCCL communicator of the ranks `members` (ascending, members[0] leads) inside `engine`'s
+        handle, for evaluations shared by that group (Engine.sharded_lead / sharded_serve: one optimiser on the leader, the
+        Cholesky on every member, the rows of L^-T / K^-1 split between them).  -> ShardGroup on the members (`.index` = rank
+        within the group), None on the other ranks and wherever the group could not be formed (agreed by all ranks: nobody is
+        left serving a leader that never calls).  The world communicator attached by `attach_engine` is reused when `members`
+        is every rank and `engine` is the engine it lives in."""
+        members = [int(m) for m in members]
+        if len(members) < 2 or not hasattr(engine, "sharded_lead"):
+            return None
+        if members == list(range(self.size)) and self._engine is engine and getattr(engine, "comm_size", 1) == self.size:
+            return ShardGroup(engine, self.rank, self.size)
+        if engine is self._engine:
+            return None              # one communicator per handle: the world's lives here
+        import threading
+        uid, err = None, None
+        if self.rank == members[0]:
+            try:
+                uid = engine.comm_unique_id()
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        uid, err = self.bcast_object((uid, err), src=members[0])
+        mine = self.rank in members
+        if uid is not None and mine:
+            box = {}
+
+            def init():
+                try:
+                    engine.comm_init(uid, members.index(self.rank), len(members))
+                    box["ok"] = True
+                except Exception as e:  # noqa: BLE001
+                    box["err"] = repr(e)
+            t = threading.Thread(target=init, daemon=True)
+            t.start()
+            t.join(init_timeout)
+            if t.is_alive():
+                err = "ncclCommInitRank (group %s) did not return within %.0f s on rank %d" % (members, init_timeout, self.rank)
+                if hasattr(engine, "poison"):
+                    engine.poison(err)
+            elif "err" in box:
+                err = box["err"]
+        errs = [e for e in self.allgather_object(err) if e]
+        if errs:
+            self.rccl_error = errs[0]
+            if mine and getattr(engine, "comm_size", 1) > 1:
+                try:
+                    engine.comm_destroy()
+                except Exception:  # noqa: BLE001
+                    pass
+            return None
+        return ShardGroup(engine, members.index(self.rank), len(members)) if mine else None
 
     def allgather_rows(self, arr):
         """concatenate per-rank row blocks (ragged allowed: counts are exchanged first, blocks padded)"""

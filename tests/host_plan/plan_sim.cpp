@@ -186,44 +186,21 @@ int leaf_compute(Sim& s, int blk) {
     return 0;
 }
 
-}  // namespace
 
-extern "C" {
-
-// report[0] = |L L^T - A|_F / |A|_F, [1] = max |X L - I|, [2] = max |S - S^T| over the lower/upper pairs that hold X,
-// [3] = max |K^-1 - X^T X| / max |X^T X| (want_grad only), [4] = number of races, [5] = steps, [6] = tasks, [7] = events
-// numeric = 0: race check only (any size); 1: also execute.  slack = extra rows of capacity (stride = (ld + slack)^2).
-// mutate (self-test of the checker): 1 = the first bulk launch forgets to wait for the chain; 2 = the main stream forgets
-// the final join; 3 = the second macro's first leaf forgets its event wait
-int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double* report, char* msg, int msglen) {
-    Sim s;
-    s.ld = (int64_t)nblk * NB;
-    s.stride = (s.ld + slack) * (s.ld + slack);
-    build_plan(s.p, nblk, s.ld, s.stride, plan_opts_from_env());
-    if (mutate == 1) {
-        for (Step& st : s.p.steps)
-            if (st.strm == 1 && st.wait_ev > 0) { st.wait_ev = 0; break; }
-    } else if (mutate == 2) {
-        for (Step& st : s.p.steps)
-            if (st.kind == 2) st.wait_ev = 0;
-    } else if (mutate == 3) {
-        int seen = 0;
-        for (Step& st : s.p.steps)
-            if (st.strm == 0 && st.wait_ev > 0 && st.kind != 2 && ++seen == 1) { st.wait_ev = 0; break; }
-    }
+// matrices pre-filled with NaN; the SPD test matrix where the K build writes (64-tiles of the lower triangle); race-check cells
+void prepare(Sim& s, bool numeric, std::vector<double>& A0, double* report) {
     const Plan& p = s.p;
     s.cpr = (int)(s.ld / CELL);
     s.cells.assign((size_t)4 * s.cpr * s.cpr, Cell());
-    for (int i = 0; i < 8; ++i) report[i] = 0.0;
-    report[5] = (double)p.steps.size();
-    report[6] = (double)p.n_fixed_tasks;
-    report[7] = (double)p.n_events;
-    if (msg && msglen) msg[0] = 0;
+    if (report) {
+        for (int i = 0; i < 8; ++i) report[i] = 0.0;
+        report[5] = (double)p.steps.size();
+        report[6] = (double)p.n_fixed_tasks;
+        report[7] = (double)p.n_events;
+    }
     const int64_t N = s.ld;
-    std::vector<double> A0;
     if (numeric) {
         s.mem.assign((size_t)4 * s.stride, std::numeric_limits<double>::quiet_NaN());
-        // SPD test matrix: smooth kernel + diagonal; only what the K build writes (64-tiles of the lower triangle)
         A0.assign((size_t)N * N, 0.0);
         for (int64_t i = 0; i < N; ++i)
             for (int64_t j = 0; j <= i; ++j) {
@@ -237,6 +214,21 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
             for (int64_t j = 0; j < N; ++j)
                 if (j / 64 <= i / 64) A[i * s.ld + j] = A0[(size_t)i * N + j];
     }
+}
+
+// the stand-alone K^-1 launch of a plan (numeric)
+void run_kinv(Sim& s) {
+    const Plan& p = s.p;
+    const Step& st = p.kinv_step;
+    for (int k = 0; k < st.count; ++k)
+        task_compute(s, p.tasks[st.first + k], st.tile, (int64_t)st.a * s.stride, (int64_t)st.b * s.stride,
+                     (int64_t)st.c * s.stride, 0);
+}
+
+// walk the steps in enqueue order: race check (+ execution when numeric); with_kinv: also the stand-alone K^-1 launch of a plan
+// that does not stream it.  -> 0, or < 0 with msg set
+int walk_steps(Sim& s, int numeric, int want_grad, bool with_kinv, char* msg, int msglen) {
+    const Plan& p = s.p;
     // ---- walk the steps in enqueue order ----
     Clock vc[NS] = {};
     std::vector<Clock> evclock(p.n_events + 1, Clock{{-1, -1, -1}});
@@ -291,12 +283,43 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
             snprintf(msg, msglen, "step %zu of stream %d is not joined into the main stream at the end of the plan", si, s.step_strm[si]);
             return -3;
         }
-    if (want_grad && !p.kinv_streamed && numeric) {   // the stand-alone K^-1 launch
-        const Step& st = p.kinv_step;
-        for (int k = 0; k < st.count; ++k)
-            task_compute(s, p.tasks[st.first + k], st.tile, (int64_t)st.a * s.stride, (int64_t)st.b * s.stride,
-                         (int64_t)st.c * s.stride, 0);
+    if (with_kinv && want_grad && !p.kinv_streamed && numeric) run_kinv(s);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// report[0] = |L L^T - A|_F / |A|_F, [1] = max |X L - I|, [2] = max |S - S^T| over the lower/upper pairs that hold X,
+// [3] = max |K^-1 - X^T X| / max |X^T X| (want_grad only), [4] = number of races, [5] = steps, [6] = tasks, [7] = events
+// numeric = 0: race check only (any size); 1: also execute.  slack = extra rows of capacity (stride = (ld + slack)^2).
+// mutate (self-test of the checker): 1 = the first bulk launch forgets to wait for the chain; 2 = the main stream forgets
+// the final join; 3 = the second macro's first leaf forgets its event wait
+int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double* report, char* msg, int msglen) {
+    Sim s;
+    s.ld = (int64_t)nblk * NB;
+    s.stride = (s.ld + slack) * (s.ld + slack);
+    build_plan(s.p, nblk, s.ld, s.stride, plan_opts_from_env());
+    if (mutate == 1) {
+        for (Step& st : s.p.steps)
+            if (st.strm == 1 && st.wait_ev > 0) { st.wait_ev = 0; break; }
+    } else if (mutate == 2) {
+        for (Step& st : s.p.steps)
+            if (st.kind == 2) st.wait_ev = 0;
+    } else if (mutate == 3) {
+        int seen = 0;
+        for (Step& st : s.p.steps)
+            if (st.strm == 0 && st.wait_ev > 0 && st.kind != 2 && ++seen == 1) { st.wait_ev = 0; break; }
     }
+    std::vector<double> A0;
+    prepare(s, numeric != 0, A0, report);
+    if (msg && msglen) msg[0] = 0;
+    {
+        const int rc = walk_steps(s, numeric, want_grad, true, msg, msglen);
+        if (rc < 0) return rc;
+    }
+    const int64_t N = s.ld;
     report[4] = (double)s.races;
     if (s.races && msg) snprintf(msg, msglen, "%d races; first: %s", s.races, s.first_race.c_str());
     if (!numeric) return s.races ? 1 : 0;
@@ -344,6 +367,101 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
         report[3] = e3 / mx;
     }
     return s.races ? 1 : 0;
+}
+
+// A SHARDED evaluation (mfgp_eval_sharded) of `size` ranks, every rank's plan executed on its own copy of the matrices:
+//   each rank: its plan (the Cholesky in full, B / X^T work for its own block rows) -- race-checked like any plan;
+//   exchange: every 128-row block of S from its owner to all (full rows), then lower part of S <- transpose of the upper part;
+//   each rank: the stand-alone K^-1 launch restricted to its block rows.
+// Checked against the UNSHARDED plan executed the same way: L, S (after the exchange) and every rank's own rows of K^-1 must be
+// BITWISE what one rank computes alone (same tasks, same arithmetic), on top of X L = I.
+// report[0] = races (all ranks), [1] = max |X L - I| (rank 0), [2] = number of words of L / S that differ from the single run
+// (all ranks), [3] = words of K^-1 (own rows, lower 128-tiles) that differ, [4] = tasks of the largest rank plan / tasks of the
+// unsharded plan
+int plan_sim_sharded(int nblk, int size, double* report, char* msg, int msglen) {
+    const PlanOpts opts = plan_opts_from_env();
+    const int64_t ld = (int64_t)nblk * NB, stride = ld * ld;
+    for (int i = 0; i < 8; ++i) report[i] = 0.0;
+    if (msg && msglen) msg[0] = 0;
+    Sim ref;
+    ref.ld = ld; ref.stride = stride;
+    {
+        PlanOpts o = opts;
+        o.kinv_stream = 0;                       // reference: K^-1 as the stand-alone launch (the streamed form is bitwise equal
+        build_plan(ref.p, nblk, ld, stride, o);  // on the GPU, not in this simulator, which adds a chunk's sum at its end)
+    }
+    std::vector<double> A0;
+    prepare(ref, true, A0, nullptr);
+    int rc = walk_steps(ref, 1, 1, true, msg, msglen);
+    if (rc < 0) return rc;
+    std::vector<Sim> rk((size_t)size);
+    size_t max_tasks = 0;
+    for (int r = 0; r < size; ++r) {
+        Sim& s = rk[(size_t)r];
+        s.ld = ld; s.stride = stride;
+        build_plan(s.p, nblk, ld, stride, opts, 1, Shard{r, size});
+        std::vector<double> dummy;
+        prepare(s, true, dummy, nullptr);
+        rc = walk_steps(s, 1, 1, false, msg, msglen);
+        if (rc < 0) return rc;
+        report[0] += s.races;
+        if (s.races && msg && !msg[0]) snprintf(msg, msglen, "rank %d: %d races; first: %s", r, s.races, s.first_race.c_str());
+        size_t nt = 0;
+        for (const Step& st : s.p.steps) if (st.kind == 1) nt += (size_t)st.count;
+        max_tasks = std::max(max_tasks, nt + (size_t)s.p.kinv_step.count);
+    }
+    {
+        size_t nt = 0;
+        for (const Step& st : ref.p.steps) if (st.kind == 1) nt += (size_t)st.count;
+        report[4] = (double)max_tasks / (double)(nt + (size_t)ref.p.kinv_step.count);
+    }
+    // exchange: row block b of S from its owner to everybody, then the lower part from the upper one
+    const int64_t so = (int64_t)BUF_S * stride;
+    for (int b = 0; b < nblk; ++b) {
+        const int own = shard_owner(b, size);
+        const double* src = rk[(size_t)own].mem.data() + so + (int64_t)b * NB * ld;
+        for (int r = 0; r < size; ++r)
+            if (r != own) memcpy(rk[(size_t)r].mem.data() + so + (int64_t)b * NB * ld, src, (size_t)NB * ld * sizeof(double));
+    }
+    for (int r = 0; r < size; ++r) {
+        double* S = rk[(size_t)r].mem.data() + so;
+        for (int64_t i = 0; i < ld; ++i)
+            for (int64_t k = i + 1; k < ld; ++k) S[k * ld + i] = S[i * ld + k];
+        run_kinv(rk[(size_t)r]);
+    }
+    // compare with the single-rank run
+    double diffLS = 0, diffK = 0;
+    const double* Lr = ref.mem.data() + (int64_t)BUF_L * stride;
+    const double* Sr = ref.mem.data() + so;
+    const double* Kr = ref.mem.data() + (int64_t)BUF_A * stride;
+    for (int r = 0; r < size; ++r) {
+        const double* L = rk[(size_t)r].mem.data() + (int64_t)BUF_L * stride;
+        const double* S = rk[(size_t)r].mem.data() + so;
+        const double* K = rk[(size_t)r].mem.data() + (int64_t)BUF_A * stride;
+        for (int64_t i = 0; i < ld; ++i)
+            for (int64_t j = 0; j < ld; ++j) {
+                if (j <= i && memcmp(&L[i * ld + j], &Lr[i * ld + j], 8) != 0) diffLS += 1;
+                if (memcmp(&S[i * ld + j], &Sr[i * ld + j], 8) != 0) diffLS += 1;
+                if (j / NB <= i / NB && shard_owner((int)(i / NB), size) == r && memcmp(&K[i * ld + j], &Kr[i * ld + j], 8) != 0 &&
+                    (j <= i || i / 64 == j / 64))
+                    diffK += 1;
+            }
+    }
+    report[2] = diffLS;
+    report[3] = diffK;
+    {
+        const double* L = rk[0].mem.data() + (int64_t)BUF_L * stride;
+        const double* S = rk[0].mem.data() + so;
+        double e1 = 0.0;
+        for (int64_t i = 0; i < ld; ++i)
+            for (int64_t j = 0; j <= i; ++j) {
+                double v = 0.0;
+                for (int64_t k = j; k <= i; ++k) v += S[i * ld + k] * L[k * ld + j];
+                e1 = std::max(e1, fabs(v - (i == j ? 1.0 : 0.0)));
+            }
+        report[1] = std::isnan(e1) ? 1e300 : e1;
+    }
+    return report[0] > 0 ? 1 : 0;
 }
 
 // out[0..7] = main-stream launches, bulk launches, waits on the main stream, records on the main stream, waits on bulk,

@@ -27,28 +27,33 @@ def lf(x):
     return cases.lf_2d(x)[:, None]
 
 
-def _model_run(comm, conc):
+def _model_run(comm, conc, restarts=6):
     import multifidelity_datafusion_gps_amd as mf
 
     class Budget(mf.NARGP):
         lf_max_iters = first_run_max_iters = restart_max_iters = 12
         eval_cap = 12
         restart_concurrency = conc
+        num_restarts = restarts
 
     rng = np.random.default_rng(7)
     X_lf = rng.uniform(size=(300, 2))
     model = Budget(2, hf, None, lf_X=X_lf, lf_Y=lf(X_lf), seed=11, comm=comm)
+    lf_theta = np.array([p.value for p in model.lf_model.parameters()])
+    lf_evals = model.lf_model.n_evals           # evaluations this rank's low-fidelity model issued for its one optimize() run
     model.fit(rng.uniform(size=(200, 2)))
     mean, var = model.predict(rng.uniform(size=(333, 2)))
     theta = np.array([p.value for p in model.hf_model.parameters()])
     evals = model.hf_model.n_evals
+    groups = sorted((g.size, g.index) for g in getattr(model, "_shard_groups", {}).values() if g is not None)
     # cfg5's panel form: one predictive-variance panel per acquisition, its rows sharded over the ranks and gathered; every
     # rank must acquire the same point
     model.adapt_maximizer = mf.adaptation_maximizers.PanelMaximizer(n_candidates=4096, seed=5)
     model.adapt(2, reoptimize=False)
     acquired = np.array(model.acquired_points).reshape(2, 2)
     model.close()
-    return dict(theta=theta, mean=mean, var=var, evals=evals, acquired=acquired)
+    return dict(theta=theta, mean=mean, var=var, evals=evals, acquired=acquired, groups=groups,
+                lf_theta=lf_theta, lf_evals=lf_evals)
 
 
 def _rowblock_run(comm):
@@ -131,6 +136,28 @@ def _rccl_worker(rank, world, port, q):
         res["fused"] = e.eval(theta, noise, 1e-8)
         res["sharded"] = sharding.eval_rowblock_allgather(e, comm, theta, noise)   # 768 padded rows: 6 blocks of 128 over the ranks
         res["model"] = _model_run(comm, 2)                 # e1 + e2 with the row gathers on RCCL
+        # two restarts only: with three ranks one of them is dealt none and SHARES first run -> restart 0 with rank 0 (chain group)
+        res["model_r2"] = _model_run(comm, 2, restarts=2)
+        # ONE evaluation sharded over the ranks (mfgp_eval_sharded: rows of L^-T and of K^-1 by 128-row block, grouped
+        # ncclBroadcast of the rows + ncclAllReduce of the gradient's tile sums): bitwise the single evaluation, at a size with
+        # several macro panels and at the north-star size
+        res["eval_sharded"] = {}
+        for n in (2100, 8192):
+            rng = np.random.default_rng(n)
+            X = rng.uniform(size=(n, 4))
+            Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+            Y = cases.hf_4d(X)
+            e.set_data(Xa, Y)
+            e.set_kernel(cases.composite(4, 1))
+            th, nz = np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+            f0, g0 = e.eval(th, nz, 1e-8)
+            m0, v0 = e.predict(Xa[:100])
+            comm.barrier()
+            f1, g1 = e.eval_sharded(th, nz, 1e-8)
+            m1, v1 = e.predict(Xa[:100])                  # the exchanged factor serves predictions on every rank
+            f2 = e.eval_sharded(th * 1.05, nz, 1e-8, want_grad=False)
+            f3 = e.eval(th * 1.05, nz, 1e-8, want_grad=False)
+            res["eval_sharded"][n] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), nograd=(f2, f3))
         comm.barrier()
         e.comm_destroy()                                   # every rank still alive
         comm.barrier()
@@ -147,6 +174,7 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
     in-place ncclAllGather on the device matrix) and mfgp_allgather_host between the processes."""
     from multifidelity_datafusion_gps_amd.sharding import LocalComm
     ref = _model_run(LocalComm(), 1)
+    ref_r2 = _model_run(LocalComm(), 1, restarts=2)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -173,6 +201,48 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
         np.testing.assert_array_equal(m["mean"], out[0]["model"]["mean"])
         np.testing.assert_array_equal(m["acquired"], ref["acquired"])           # panel rows over RCCL: the same acquisitions
         assert m["evals"] < ref["evals"]
+        # the sequential evaluations were SHARED (shard_sequential): the low-fidelity run by all ranks -- ONE optimiser, on rank 0,
+        # whose steps are bit for bit the single process's (the sharded evaluation is) -- and, with two restarts on three ranks,
+        # first run -> restart 0 by ranks 0 and 1
+        assert (world, r) in m["groups"]
+        np.testing.assert_array_equal(m["lf_theta"], ref["lf_theta"])
+        assert m["lf_evals"] == (ref["lf_evals"] if r == 0 else 0)            # ONE optimiser: the followers served, they issued nothing
+        m2 = o["model_r2"]
+        np.testing.assert_array_equal(m2["theta"], ref_r2["theta"])
+        np.testing.assert_allclose(m2["mean"], ref_r2["mean"], rtol=0, atol=1e-9)
+        if world == 3:
+            assert ((2, r) in m2["groups"]) == (r in (0, 1)), m2["groups"]
+        for n, es in o["eval_sharded"].items():            # bitwise NLML / gradient (and predictions) on every rank
+            (f0, g0, m0, v0), (f1, g1, m1, v1) = es["single"], es["sharded"]
+            assert f1 == f0 and np.array_equal(g1, g0), (r, n)
+            assert np.array_equal(m1, m0) and np.array_equal(v1, v0), (r, n)
+            assert es["nograd"][0] == es["nograd"][1]
+
+
+@pytest.mark.parametrize("N", [300, 1500, 2100, 4200])
+def test_sharded_evaluation_in_the_group_of_one_and_each_ranks_share(engine, N):
+    """mfgp_eval_sharded without a communicator (the group of one) is mfgp_eval bit for bit -- single-macro plans and
+    multi-macro ones -- and the device work of rank r of G alone (mfgp_dbg_eval_as_rank: no exchange) runs through for
+    every (r, G) and leaves the handle without a factorisation."""
+    rng = np.random.default_rng(N)
+    X = rng.uniform(size=(N, 4))
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    Y = cases.hf_4d(X)
+    engine.set_data(Xa, Y)
+    engine.set_kernel(cases.composite(4, 1))
+    theta, noise = np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    f0, g0 = engine.eval(theta, noise, 1e-8)
+    m0, v0 = engine.predict(Xa[:50])
+    f1, g1 = engine.eval_sharded(theta, noise, 1e-8)
+    m1, v1 = engine.predict(Xa[:50])
+    assert f1 == f0 and np.array_equal(g1, g0) and np.array_equal(m1, m0) and np.array_equal(v1, v0)
+    for G in (2, 3, 8):
+        for r in (0, G - 1):
+            assert engine.dbg_eval_as_rank(theta, noise, r, G) > 0.0
+    with pytest.raises(RuntimeError):
+        engine.predict(Xa[:5])                             # a lone rank's share is not a factorisation
+    f2, g2 = engine.eval(theta, noise, 1e-8)               # the handle is intact
+    assert f2 == f0 and np.array_equal(g2, g0)
 
 
 def test_rccl_calls_with_a_communicator_of_one(engine):
