@@ -112,6 +112,16 @@ def _blas_info():
     return {"vendor": "unknown", "version": None, "threads": os.cpu_count() or 1, "threading_layer": None}
 
 
+def _host_cpu():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def _pick_blas_threads():
     """OpenBLAS on a box whose CPU share is smaller than its core count (16 of 256 visible) is slowest at the default of one
     thread per visible core: time dpotrf + dpotri at N = 4096 under 8 / 16 / 32 / all threads once and keep the best.
@@ -128,16 +138,23 @@ def _pick_blas_threads():
     A = np.asfortranarray(M.dot(M.T) + n * np.eye(n))
     ncpu = os.cpu_count() or 1
     tried = {}
+    detail = {}
     for t in sorted({min(t, ncpu) for t in (8, 16, 32, ncpu)}):
         with threadpool_limits(limits=t, user_api="blas"):
-            best = np.inf
+            best, b1, b2 = np.inf, np.inf, np.inf
             for rep in range(3):
                 t0 = time.perf_counter()
                 L, i1 = lapack.dpotrf(A, lower=1, overwrite_a=0)
+                t1 = time.perf_counter()
                 _, i2 = lapack.dpotri(L, lower=1, overwrite_c=0)
+                t2 = time.perf_counter()
                 if rep > 0 and i1 == 0 and i2 == 0:
-                    best = min(best, time.perf_counter() - t0)
+                    best, b1, b2 = min(best, t2 - t0), min(b1, t1 - t0), min(b2, t2 - t1)
         tried[t] = round(n ** 3 / best / 1e9, 1)      # dpotrf n^3/3 + dpotri 2 n^3/3
+        # the two routines run at very different rates under OpenBLAS (dpotrf's panel recursion threads poorly, dpotri is
+        # dtrmm-like): both are reported so that the rates of _lapack_share at the full size can be held against them
+        detail[t] = {"dpotrf_gflops": round(n ** 3 / 3 / b1 / 1e9, 1), "dpotri_gflops": round(2 * n ** 3 / 3 / b2 / 1e9, 1)}
+    _pick_blas_threads.detail = detail
     return max(tried, key=tried.get), tried
 
 
@@ -229,7 +246,9 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=170.0):
         lap["share_of_one_hf_eval"] = round(lap["seconds_of_one_hf_eval"] / hf_eval_s, 3)
     total_s = n_lf_evals * lf_eval_s + n_hf_evals * hf_eval_s + lf_means_s + hf_predict_s
     return {"value": round(total_s * 1e3, 1), "unit": "ms", "cores": int(blas["threads"]), "kind": "port-extrapolated",
-            "blas": blas, "blas_threads_tried_gflops": tried, "measured_s": round(measured, 2),
+            "blas": blas, "blas_threads_tried_gflops": tried,
+            "blas_threads_tried_per_routine_n4096": getattr(_pick_blas_threads, "detail", None), "host_cpu": _host_cpu(),
+            "measured_s": round(measured, 2),
             "extrapolated_s": round(total_s, 1),
             "lf_eval_s": [round(t, 2) for t in lf_ts], "hf_eval_s": [round(t, 2) for t in hf_ts],
             "warmed_up": {"lf": True, "hf": True},

@@ -92,6 +92,42 @@ def test_the_checker_catches_a_dropped_dependency(simlib):
     assert no_leaf_wait[0] == 1 and no_leaf_wait[1][4] > 0
 
 
+_SHARD_DRIVER = r"""
+import ctypes, json, sys
+lib = ctypes.CDLL(sys.argv[1])
+lib.plan_sim_sharded.restype = ctypes.c_int
+lib.plan_sim_sharded.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+out = []
+for nb, size in json.loads(sys.argv[2]):
+    rep = (ctypes.c_double * 8)()
+    msg = ctypes.create_string_buffer(512)
+    rc = lib.plan_sim_sharded(nb, size, rep, msg, 512)
+    out.append([rc, list(rep), msg.value.decode()])
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_sharded_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
+    """mfgp_eval_sharded on the CPU: every rank's plan (the Cholesky in full, the work on the rows of L^-T / K^-1 for its own
+    128-row blocks) executed on its own copy of the matrices, the rows of X^T exchanged from their owners, the lower part
+    rebuilt from the upper one, every rank's K^-1 rows accumulated -- each rank's plan race-free, and L, S and the owned rows of
+    K^-1 BITWISE what one rank computes alone (same tasks, same arithmetic); the largest rank plan shrinks towards
+    1/3 + 2/(3 G) of the single plan's tasks as the matrix grows."""
+    import json
+    specs = [(3, 2), (5, 2), (8, 3), (9, 4), (14, 2), (14, 3), (16, 4)]
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _SHARD_DRIVER, simlib, json.dumps(specs)], env=e, capture_output=True, text=True,
+                       check=True)
+    for (nb, size), (rc, rep, msg) in zip(specs, json.loads(r.stdout)):
+        assert rc == 0 and rep[0] == 0, (nb, size, msg)
+        assert rep[1] < 1e-12, (nb, size, rep)               # X L = I after the exchange
+        assert rep[2] == 0 and rep[3] == 0, (nb, size, rep)    # no word of L / S / own K^-1 rows differs from the single run
+        assert rep[4] <= 1.0
+
+
 # ---- the same planner + checker under AddressSanitizer / UndefinedBehaviorSanitizer (CPU build; SURVEY section 5) -------------
 ASAN_BIN = os.path.join(ROOT, "tests", "host_plan", "plan_sim_asan")
 ASAN_SRC = SRC + [os.path.join(ROOT, "tests", "host_plan", "plan_sim_main.cpp")]

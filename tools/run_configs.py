@@ -1,6 +1,6 @@
 """Runs the five BASELINE.json configurations end to end on the GPU (synthetic data of SURVEY 8(d)) and prints one
 line each: sizes, wall time, per-evaluation stage times.  `--quick` shrinks the large ones for smoke runs."""
-import os as _os; _os.environ.setdefault("MFGP_STAGE_TIMING", "1")   # per-stage stamps at every size (a handle records none below Np = 4096 by default)
+import os as _os; _os.environ.setdefault("MFGP_HW_QUEUES", "2"); _os.environ.setdefault("MFGP_STAGE_TIMING", "1")   # per-stage stamps at every size (a handle records none below Np = 4096 by default)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,7 +19,8 @@ class BudgetNARGP(mf.NARGP):
     """fixed evaluation budget per L-BFGS-B run; a subclass because the data-driven LF level is fitted in the constructor"""
     lf_max_iters = first_run_max_iters = restart_max_iters = E
     eval_cap = E
-    restart_concurrency = int(os.environ.get("MFGP_RESTART_CONC", "2"))
+    restart_lockstep = os.environ.get("MFGP_RESTART_LOCKSTEP", "1") != "0"      # the default: lock-stepped runs over batched evaluations
+    restart_concurrency = int(os.environ.get("MFGP_RESTART_CONC", "2"))          # (MFGP_RESTART_LOCKSTEP=0: round 3's concurrent restarts)
 
 
 def col(f):
