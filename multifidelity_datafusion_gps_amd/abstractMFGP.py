@@ -40,9 +40,11 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
                                 # batched pass evaluates all of them (engine.LockstepEvaluator, mfgp_eval_batch) -- same runs, same
                                 # steps bit for bit, same winner; takes precedence over restart_concurrency where the engine has
                                 # eval_batch (the HIP engine has; a double without it gets the reference's sequential order)
-    lockstep_width = None       # live slots per round (None: half this rank's runs, rounded up -- 4 for the recipe's 1 + 6 runs: the
-                                # sequential pair first run -> restart 0 in one slot, the five randomized restarts 2 + 2 + 1 in three
-                                # more, so every round carries 3-4 evaluations instead of 6 for one half of the fit and 1 for the other)
+    lockstep_width = None       # live slots per rank.  None: from N = 6144 half the rank's runs, rounded up -- 4 for the recipe's 1 + 6 runs:
+                                # the sequential pair first run -> restart 0 in one slot, the five randomized restarts 2 + 2 + 1 in
+                                # three more, so every round carries 4, then 3 evaluations (a pass is convex in its size there: 6 then
+                                # 1 costs more); below, where a pass is bound by the serial chain and nearly flat in its size, all runs
+                                # at once (6 slots on two lanes: N = 512 55 -> 37 ms, 2048 140 -> 121, profiles/r04_midsize_fit.txt)
     lockstep_lanes = None       # engine handles the live slots are dealt to (each lane batches ITS slots' evaluations: a lane's serial
                                 # chain then overlaps another lane's bulk work, and the hosts' L-BFGS-B steps of one lane the GPU pass
                                 # of another).  None: 2 below N = 6144 (fits 8-15 % faster than on one lane at N = 1024 .. 4096,
@@ -267,7 +269,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             return
         own = 1 if rank == 0 else 0
         n_runs = len(mine_bg) + 2 * own
-        width = int(self.lockstep_width) if self.lockstep_width else (n_runs + 1) // 2
+        width = int(self.lockstep_width) if self.lockstep_width else ((n_runs + 1) // 2 if len(model.X) >= 6144 else max(n_runs - 1, 1))
         n_bg_slots = min(len(mine_bg), max(width - own, 1 if mine_bg else 0))
         n_slots = n_bg_slots + own
         # deal the slots to the lanes: lane 0 = the model's own handle (slot 0, the sequential pair, lives there)

@@ -201,7 +201,7 @@ def test_concurrent_and_lockstep_restarts_give_the_sequential_result(n_hf):
             lanes = model.last_lockstep_lanes
             assert len(lanes) == {"lockstep": 2, "lockstep_1lane": 1, "lockstep_w7": 3, "lockstep_w2": 2}[mode]
             assert sum(ls.evals for ls in lanes) == sum(r.n_evals for r in model.hf_model.optimization_runs)
-            assert max(max(ls.round_sizes) for ls in lanes) == {"lockstep": 2, "lockstep_1lane": 4, "lockstep_w7": 2, "lockstep_w2": 1}[mode]
+            assert max(max(ls.round_sizes) for ls in lanes) == {"lockstep": 3, "lockstep_1lane": 6, "lockstep_w7": 2, "lockstep_w2": 1}[mode]
         mean, var = model.predict(X_hf[:20])                                       # the winner is installed and factorised
         out[mode] += (mean, var)
         model.close()

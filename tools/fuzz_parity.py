@@ -65,7 +65,11 @@ def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
         cond = tol.cond_bound(st["K"], c["noise"])
         cf = tol.cond_factor(cond)
         kss = orc.cov_diag(c["parts"], c["theta"], 1)[0]
-        err = dict(nlml=abs(nlml - st["nlml"]) / max(1.0, abs(st["nlml"])) / (tol.NLML_REL * cf),
+        # NLML = (N log 2pi + logdet + y^T alpha) / 2 can pass through zero for random hyper-parameters while its three terms stay
+        # large: the error is held against the magnitude of the terms, not of their sum (the fixed-parameter tests of the suite
+        # assert rel 1e-10 of |NLML| itself: there it is not near a crossing)
+        nlml_scale = max(1.0, abs(st["nlml"]), 0.5 * (c["N"] * orc.LOG_2_PI + abs(st["logdet"]) + abs(float(c["Y"] @ st["alpha"]))))
+        err = dict(nlml=abs(nlml - st["nlml"]) / nlml_scale / (tol.NLML_REL * cf),
                    grad=(np.abs(grad - st["grad"]) / tol.grad_scale(st["grad"])).max() / (tol.GRAD_REL * cf),
                    mean=np.abs(m - mu).max() / (tol.PRED_ABS * ys * cf),
                    var=np.abs(v - var).max() / (tol.PRED_ABS * ys * cf),
