@@ -74,7 +74,7 @@ def one_step(args, comm, engines, data):
         restart_max_iters = args.evals
         num_restarts = args.restarts
         restart_concurrency = args.concurrency
-        restart_lockstep = bool(args.lockstep)
+        restart_lockstep = None if args.lockstep < 0 else bool(args.lockstep)
         lockstep_lanes = args.lanes if args.lanes > 0 else None
         lockstep_width = args.width if args.width > 0 else None
         restart_aux = args.aux if args.aux > 0 else None
@@ -432,9 +432,10 @@ def main():
     ap.add_argument("--evals", type=int, default=20, help="objective evaluations per L-BFGS-B run")
     ap.add_argument("--restarts", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--lockstep", type=int, default=1,
-                    help="1 (default): the HF level's 1 + 6 runs as lock-stepped runs over batched evaluations (mfgp_eval_batch); "
-                         "0: round 3's concurrent restarts on auxiliary handles (--concurrency)")
+    ap.add_argument("--lockstep", type=int, default=-1,
+                    help="-1 (default): the package's default by size (one GPU, N >= 6144: concurrent restarts on auxiliary handles; "
+                         "else lock step); 1: the HF level's 1 + 6 runs as lock-stepped runs over batched evaluations "
+                         "(mfgp_eval_batch); 0: concurrent restarts (--concurrency)")
     ap.add_argument("--lanes", type=int, default=0, help="engine handles the lock-stepped runs are dealt to (0: the model's default: 1 at N >= 6144, else 2)")
     ap.add_argument("--width", type=int, default=0, help="live lock-step slots per rank (0: half the rank's runs, rounded up)")
     ap.add_argument("--concurrency", type=int, default=2,
@@ -489,7 +490,9 @@ def main():
     # serialise (tools/queue_pairs.py: of four handles created back to back, 0 + 3 and 1 + 2 share).  --aux-order reversed creates
     # hf#2 before hf#1, so that the first auxiliary handle lands on the lane the main handle (hf) is NOT on.
     lanes = args.lanes if args.lanes > 0 else (2 if args.n < 6144 else 1)
-    n_aux = (lanes - 1) if args.lockstep else (args.concurrency if args.concurrency > 1 else 0)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    lockstep = bool(args.lockstep) if args.lockstep >= 0 else (args.n < 6144 or world_env > 1)      # the model's by-size rule
+    n_aux = (lanes - 1) if lockstep else max(args.concurrency, 2)
     js = list(range(1, n_aux + 1))
     for j in (reversed(js) if args.aux_order == "reversed" else js):
         engines["hf#%d" % j] = Engine(local_rank)
@@ -601,9 +604,10 @@ def main():
                        "gpu_ms_per_evaluation": (round(tot["total_ms"] / tot["timed_evals"], 3) if tot["timed_evals"] else None),
                        "wall_ms_per_evaluation": round(ms_per_step * args.steps / max(evals, 1), 3),
                        "restarts_run_as": ("lock-stepped runs over batched evaluations (mfgp_eval_batch): %d lanes, %s live slots"
-                                           % (lanes, args.width or "auto")) if args.lockstep
-                                          else "concurrent restarts on %d auxiliary handles" % args.concurrency,
-                       "restart_concurrency": None if args.lockstep else args.concurrency, "collectives": collectives,
+                                           % (lanes, args.width or "auto")) if lockstep
+                                          else "concurrent restarts on %d auxiliary handles (the default from N = 6144 on one GPU; "
+                                               "lock step over batched evaluations below)" % max(args.concurrency, 2),
+                       "restart_concurrency": None if lockstep else max(args.concurrency, 2), "collectives": collectives,
                        "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
                        "sharding": "randomized restarts + predictive rows over ranks; LF run on rank 0 (the others adopt its optimum); "
@@ -623,7 +627,7 @@ def main():
                          if traffic_sweep is not None else "null: " + traffic_why,
                          "launches": int(evals), "flops_per_launch": tot["cholinv_flops"] / max(evals, 1),
                          "achieved_is": "all sweep flops of the timed region / its wall time (several evaluations are in flight at once -- "
-                                        "batched passes on %d lanes -- so per-launch intervals overlap)" % (lanes if args.lockstep else 1 + args.concurrency),
+                                        "%s -- so per-launch intervals overlap)" % ("batched passes on %d lanes" % lanes if lockstep else "%d free-running evaluations" % (1 + max(args.concurrency, 2))),
                          "per_launch_overlapped": {"avg_launch_ms": round(tot["cholinv_ms"] / max(evals, 1), 4),
                                                    "achieved": round(sweep_tf_launch, 2),
                                                    "note": "HIP events around each sweep on its engine's stream; the interval "

@@ -46,6 +46,24 @@ int main(int argc, char** argv) {
     double* var = malloc(sizeof(double) * Ns);
     if ((rc = mfgp_predict(h, Xs, Ns, mean, var, 1, 1))) die(h, "mfgp_predict", rc);
     for (long i = 0; i < Ns; ++i) printf("pred %.17g %.17g\n", mean[i], var[i]);
+    /* round 4: three hyper-parameter points in ONE batched pass (mfgp_eval_batch) -- set 0 is the point above: its numbers must be
+     * the very same bits; and the build id of the library (the hash profiles/ files are stamped with) */
+    {
+        const int np_ = mfgp_num_params(parts, P);
+        double thetas[3 * 2 * MFGP_MAX_PARTS], noises[3], jit[3] = {1e-8, 1e-8, 1e-8}, f[3], g[3 * (2 * MFGP_MAX_PARTS + 1)];
+        int32_t st[3];
+        for (int b = 0; b < 3; ++b) {
+            noises[b] = noise * (1.0 + 0.5 * b);
+            for (int i = 0; i < np_; ++i) thetas[b * np_ + i] = theta[i] * (1.0 + 0.1 * b);
+        }
+        if ((rc = mfgp_eval_batch(h, 3, thetas, noises, jit, 1, f, g, st))) die(h, "mfgp_eval_batch", rc);
+        int same = (f[0] == nlml) && st[0] == 0 && st[1] == 0 && st[2] == 0;
+        for (int i = 0; i <= np_; ++i) same = same && (g[i] == grad[i]);
+        printf("batch_set0_bitwise %d\n", same);
+        printf("batch_nlml %.17g %.17g %.17g\n", f[0], f[1], f[2]);
+        if ((rc = mfgp_predict(h, Xs, Ns, mean, var, 1, 1))) die(h, "mfgp_predict after batch", rc);   /* the handle's own factorisation survives */
+        printf("build_id %s\n", mfgp_build_id());
+    }
     /* error behaviour: a call that cannot succeed reports, it does not crash */
     rc = mfgp_predict(h, NULL, Ns, mean, var, 1, 1);
     printf("null_predict_rc %d (%s)\n", rc, mfgp_last_error(h));

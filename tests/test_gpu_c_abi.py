@@ -42,5 +42,13 @@ def test_plain_c_client_matches_oracle(tmp_path):
     mu, var = orc.predict_stable(parts, theta, noise, X, st, Xs)
     np.testing.assert_allclose(pred[:, 0], mu, rtol=0, atol=1e-9 * max(1.0, np.abs(Y).max()))
     np.testing.assert_allclose(pred[:, 1], var, rtol=0, atol=1e-9)
+    # mfgp_eval_batch from plain C: set 0 bitwise the single evaluation, the other sets against the oracle at their points
+    assert [l for l in lines if l.startswith("batch_set0_bitwise")][0].split()[1] == "1"
+    fb = [float(v) for v in [l for l in lines if l.startswith("batch_nlml")][0].split()[1:]]
+    for b in (1, 2):
+        st_b = orc.inference(parts, np.array(theta) * (1.0 + 0.1 * b), noise * (1.0 + 0.5 * b), X, Y, want_grad=False)
+        assert fb[b] == pytest.approx(st_b["nlml"], rel=1e-10)
+    from multifidelity_datafusion_gps_amd import build
+    assert [l for l in lines if l.startswith("build_id")][0].split()[1] == build.source_hash()
     rc_line = [l for l in lines if l.startswith("null_predict_rc")][0]
     assert int(rc_line.split()[1]) < 0 and "NULL" in rc_line

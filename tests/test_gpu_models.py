@@ -239,6 +239,16 @@ def test_batched_evaluation_is_bitwise_the_single_evaluation(engine):
             assert f[b] == fb and np.array_equal(g[b], gb), (N, b)
         f2, _, st2 = engine.eval_batch(thetas[:2], noises[:2], 1e-8, want_grad=False)     # fewer sets, no gradient
         assert not st2.any() and np.array_equal(f2, f[:2])
+    # kernel structures outside the RBF fast path (Matern factors, ARD lengthscales): K build and gradient run one launch per set
+    gparts = cases.composite(4, 1, cases.M52, cases.RBF | cases.ARD, cases.M32)
+    engine.set_kernel(gparts)
+    gth = np.exp(rng.uniform(np.log(0.5), np.log(2.0), size=(3, 9)))
+    fg, gg, sg = engine.eval_batch(gth, noises[:3], 1e-8)
+    assert not sg.any()
+    for b in range(3):
+        fb, gb = engine.eval(gth[b], noises[b], 1e-8)
+        assert fg[b] == fb and np.array_equal(gg[b], gb), b
+    engine.set_kernel(parts)
     # one set not positive definite (duplicate rows, no noise, no jitter): its status only
     Xd = Xa.copy(); Xd[5] = Xd[3]
     engine.set_data(Xd, Y)

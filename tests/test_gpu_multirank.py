@@ -158,6 +158,15 @@ def _rccl_worker(rank, world, port, q):
             f2 = e.eval_sharded(th * 1.05, nz, 1e-8, want_grad=False)
             f3 = e.eval(th * 1.05, nz, 1e-8, want_grad=False)
             res["eval_sharded"][n] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), nograd=(f2, f3))
+        # a kernel structure outside the RBF fast path (Matern factors, ARD): the generic gradient kernel's ownership filter
+        e.set_kernel(cases.composite(4, 1, cases.M52, cases.RBF | cases.ARD, cases.M32))
+        thg = np.array([1.1, 1.3, 0.7, 0.8, 0.6, 1.2, 0.9, 0.5, 0.9])
+        f0, g0 = e.eval(thg, nz, 1e-8)
+        m0, v0 = e.predict(Xa[:100])
+        comm.barrier()
+        f1, g1 = e.eval_sharded(thg, nz, 1e-8)
+        m1, v1 = e.predict(Xa[:100])
+        res["eval_sharded"]["matern_ard_8192"] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), nograd=(0.0, 0.0))
         comm.barrier()
         e.comm_destroy()                                   # every rank still alive
         comm.barrier()
