@@ -23,9 +23,10 @@ if argv and argv[0] == "--evals":
     evals = int(argv[1]); argv = argv[2:]
 MODES = [("sequential", dict(restart_lockstep=False, restart_concurrency=1)),
          ("concurrent 2", dict(restart_lockstep=False, restart_concurrency=2)),
-         ("lockstep 1 lane", dict(restart_lockstep=True, lockstep_lanes=1)), ("lockstep 2 lanes", dict(restart_lockstep=True, lockstep_lanes=2)),
-         ("2 lanes w6", dict(restart_lockstep=True, lockstep_lanes=2, lockstep_width=6)),
-         ("3 lanes w6", dict(restart_lockstep=True, lockstep_lanes=3, lockstep_width=6))]
+         ("lockstep 1 lane", dict(restart_lockstep=True, lockstep_lanes=1)),
+         ("lockstep 2 lanes (default)", dict(restart_lockstep=True, lockstep_lanes=2)),
+         ("2 lanes w4", dict(restart_lockstep=True, lockstep_lanes=2, lockstep_width=4)),
+         ("3 lanes", dict(restart_lockstep=True, lockstep_lanes=3))]
 print("# python3 tools/midsize_fit.py --evals %d ...: one fit of the reference's ARD recipe (1 + 6 L-BFGS-B runs, %d evaluations each), HF level only timed" % (evals, evals))
 for n_hf in [int(a) for a in argv] or [1024]:
     line = "N_hf=%d (N_lf=%d):" % (n_hf, 2 * n_hf)
@@ -43,7 +44,10 @@ for n_hf in [int(a) for a in argv] or [1024]:
         th = np.array([p.value for p in m.hf_model.parameters()])
         if ref is None:
             ref = th
-        line += "  %s: %.0f ms (%d evals)%s" % (name, dt * 1e3, m.hf_model.n_evals, "" if np.array_equal(th, ref) else " DIFFERENT theta")
+        lanes = getattr(m, "last_lockstep_lanes", None) if kw.get("restart_lockstep") else None
+        eng = (" [in eval_batch: %s ms, rounds %s]" % ("/".join("%.0f" % (l.engine_s * 1e3) for l in lanes), "/".join(str(l.rounds) for l in lanes))
+               if lanes and os.environ.get("MIDSIZE_DETAIL") else "")
+        line += "  %s: %.0f ms (%d evals)%s%s" % (name, dt * 1e3, m.hf_model.n_evals, eng, "" if np.array_equal(th, ref) else " DIFFERENT theta")
         m.close()
     print(line, flush=True)
 print("# identical fitted hyper-parameters in every column (bit for bit) unless a column says otherwise")
