@@ -950,4 +950,75 @@ int lab_run(int variant, int n, int K, int flags, double beta, int reps, double*
     hipEventDestroy(e0); hipEventDestroy(e1);
     return err == hipSuccess ? 0 : -3;
 }
+
+// Traffic experiment (round 4): the SAME kernel and the same (n/tile)^2 tasks, enumerated differently.
+//   order 0: row-major (i, j)
+//   order 1: every task reads operand panels 0 / 0 (C tiles stay distinct): the launch with no operand traffic to speak of
+//   order 2: XCD-aware deal of bi x bj super-blocks: workgroup p runs on XCD p mod 8; XCD x walks super-blocks x, x + 8, ...
+//   order 3: as 2, but the tiles of a super-block are dealt k-phase-shifted: tile t starts its K loop at chunk (t * K / (bi*bj)) -- not
+//            expressible with this task format, so: unused
+// Timed over `reps` back-to-back launches (make that >= 1 s for the power-managed steady state).
+int lab_run_order(int variant, int n, int K, int order, int bi, int bj, int reps, double* ms) {
+    using namespace lab;
+    if (variant < 0 || variant >= NVAR) return -1;
+    const Variant& v = g_variants[variant];
+    if (!v.k || v.tile <= 0 || v.tile > 128) return -1;
+    const int tile = v.tile;
+    if (n % tile || K % 32 || K > n) return -1;
+    const int nt = n / tile;
+    if (order == 2 && (bi <= 0 || bj <= 0 || nt % bi || nt % bj)) return -1;
+    double *S = nullptr, *Cm = nullptr;
+    GemmTask* dt = nullptr;
+    const size_t bytes = (size_t)n * n * 8;
+    if (hipMalloc(&S, bytes) != hipSuccess || hipMalloc(&Cm, bytes) != hipSuccess) return -2;
+    hipLaunchKernelGGL(lab_fill, dim3(2048), dim3(256), 0, 0, S, (int64_t)n * n, 1u);
+    hipLaunchKernelGGL(lab_fill, dim3(2048), dim3(256), 0, 0, Cm, (int64_t)n * n, 2u);
+    auto mk = [&](int i, int j) {
+        GemmTask t{};
+        t.a_off = order == 1 ? 0 : (int64_t)i * tile * n;
+        t.b_off = order == 1 ? 0 : (int64_t)j * tile * n;
+        t.c_off = (int64_t)i * tile * n + (int64_t)j * tile;
+        t.c2_off = -1;
+        t.klen = K; t.flags = 0; t.alpha = 1.0; t.beta = 1.0;
+        return t;
+    };
+    std::vector<GemmTask> ts;
+    if (order != 2) {
+        for (int i = 0; i < nt; ++i)
+            for (int j = 0; j < nt; ++j) ts.push_back(mk(i, j));
+    } else {
+        std::vector<std::vector<GemmTask>> per(8);
+        int sb = 0;
+        for (int I = 0; I < nt / bi; ++I)
+            for (int J = 0; J < nt / bj; ++J, ++sb)
+                for (int i = 0; i < bi; ++i)
+                    for (int j = 0; j < bj; ++j) per[sb % 8].push_back(mk(I * bi + i, J * bj + j));
+        size_t longest = 0;
+        for (auto& q : per) longest = std::max(longest, q.size());
+        for (size_t s2 = 0; s2 < longest; ++s2)
+            for (int x = 0; x < 8; ++x) {
+                if (s2 < per[x].size()) ts.push_back(per[x][s2]);
+                else { ts.clear(); hipFree(S); hipFree(Cm); return -4; }   // uneven deal: the positions would shift XCDs
+            }
+    }
+    if (hipMalloc(&dt, ts.size() * sizeof(GemmTask)) != hipSuccess) return -2;
+    hipMemcpy(dt, ts.data(), ts.size() * sizeof(GemmTask), hipMemcpyHostToDevice);
+    const size_t lds = v.lds ? (size_t)v.lds : (size_t)2 * (tile + tile) * 32 * 8;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() { hipLaunchKernelGGL(v.k, dim3((unsigned)ts.size()), dim3(v.threads), lds, 0, dt, S, S, Cm, nullptr, n); };
+    launch();
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) launch();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float t_ms = 0.f;
+    hipEventElapsedTime(&t_ms, e0, e1);
+    *ms = t_ms / reps;
+    const hipError_t err = hipGetLastError();
+    hipFree(S); hipFree(Cm); hipFree(dt);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return err == hipSuccess ? 0 : -3;
+}
 }
