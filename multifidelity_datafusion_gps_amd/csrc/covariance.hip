@@ -22,7 +22,8 @@ constexpr int XP = KT + 2;    // LDS pitch of the transposed X blocks
 // relative error 2.2e-16 over [-745, 0] (measured against numpy on 4e6 points).  The K-build and the gradient
 // reduction are co-limited by exp throughput, not by HBM, so this is their main lever.
 __device__ __forceinline__ double exp_nonpos(double x) {
-    x = fmax(x, -745.0);
+    x = fmax(x, -746.0);      // n = -1076 below: p 2^-1076 < 2^-1075 rounds to an exact 0 (a clamp at -745 would return the smallest
+                              // denormal for EVERY x <= -745 -- harmless in K, but a gradient weight r^2 / l^3 can be 1e300)
     const double n = rint(x * 1.4426950408889634);
     double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
@@ -42,6 +43,13 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     p = __builtin_fma(p, r, 1.0);
     return ldexp(p, (int)n);
 }
+
+// 1 / l^2 of a lengthscale, finite: below l ~ 1e-154 the reciprocal overflows, and 0 * inf on the diagonal (r = 0) would poison K with
+// NaN where GPy's 0 / l = 0 gives the variance (the optimiser's softplus domain reaches l ~ 1e-308: a line search gone astray, handled
+// like any other point).  SCALED_R2_MAX bounds a scaled squared distance wherever it multiplies a covariance that has already
+// underflowed to 0 (gradient weights, Matern polynomials): 0 * 1e300 = 0, 0 * inf = NaN.  Neither touches a value in the normal range.
+constexpr double SCALED_R2_MAX = 1e300;
+__host__ __device__ __forceinline__ double inv_sq(double l) { return fmin(1.0 / (l * l), 1.7976931348623157e308); }
 
 // stage rows [row0, row0+64) of X (row-major, D columns) transposed into LDS: sx[d*XP + r]
 __device__ __forceinline__ void stage_rows(const double* __restrict__ X, int64_t row0, int D, double* sx) {
@@ -85,7 +93,7 @@ __device__ __forceinline__ void pair_r2_ard(const KernSpecDev& sp, const double*
 #pragma unroll
     for (int e = 0; e < 16; ++e) r2[e] = 0.0;
     for (int d = c0; d < c1; ++d) {
-        const double l = sp.theta[lbase + (d - c0)], w = 1.0 / (l * l);
+        const double w = inv_sq(sp.theta[lbase + (d - c0)]);
         const d2_t xi0 = *reinterpret_cast<const d2_t*>(sxi + d * XP + 4 * ty);
         const d2_t xi1 = *reinterpret_cast<const d2_t*>(sxi + d * XP + 4 * ty + 2);
         const d2_t xa = *reinterpret_cast<const d2_t*>(sxj + d * XP + 2 * tx);
@@ -106,9 +114,8 @@ __device__ __forceinline__ void pair_r2_ard(const KernSpecDev& sp, const double*
 __device__ __forceinline__ double factor_r2(const KernSpecDev& sp, int f, const double* sxi, const double* sxj, int ty, int tx,
                                             double (&r2)[16]) {
     if (sp.nl[f] == 1) {
-        const double l = sp.theta[sp.toff[f] + 1];
         pair_r2(sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], r2);
-        return 1.0 / (l * l);
+        return inv_sq(sp.theta[sp.toff[f] + 1]);
     }
     pair_r2_ard(sp, sxi, sxj, ty, tx, sp.c0[f], sp.c1[f], sp.toff[f] + 1, r2);
     return 1.0;
@@ -126,13 +133,13 @@ __device__ __forceinline__ void apply_factor(int type, double var, double inv_l2
     } else if (type == MFGP_KERN_MATERN32) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const double s3r = 1.7320508075688772 * sqrt(r2[e] * inv_l2);
+            const double s3r = 1.7320508075688772 * sqrt(fmin(r2[e] * inv_l2, SCALED_R2_MAX));
             prod[e] *= var * (1.0 + s3r) * exp_nonpos(-s3r);
         }
     } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const double rs2 = r2[e] * inv_l2;
+            const double rs2 = fmin(r2[e] * inv_l2, SCALED_R2_MAX);
             const double s5r = 2.23606797749979 * sqrt(rs2);
             prod[e] *= var * (1.0 + s5r + (5.0 / 3.0) * rs2) * exp_nonpos(-s5r);
         }
@@ -148,27 +155,6 @@ __device__ __forceinline__ void finish_term(double (&prod)[16], double (&expo)[1
 #pragma unroll
     for (int e = 0; e < 16; ++e) expo[e] = 0.0;
     varprod = 1.0;
-}
-
-// g = (dk/dl) * l / k of one factor for the 16 pairs
-__device__ __forceinline__ void factor_logderiv(int type, double inv_l2, const double (&r2)[16], double (&g)[16]) {
-    if (type == MFGP_KERN_RBF) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) g[e] = r2[e] * inv_l2;
-    } else if (type == MFGP_KERN_MATERN32) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const double rs2 = r2[e] * inv_l2;
-            g[e] = 3.0 * rs2 / (1.0 + 1.7320508075688772 * sqrt(rs2));
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const double rs2 = r2[e] * inv_l2;
-            const double s5r = 2.23606797749979 * sqrt(rs2);
-            g[e] = (5.0 / 3.0) * rs2 * (1.0 + s5r) / (1.0 + s5r + (5.0 / 3.0) * rs2);
-        }
-    }
 }
 
 // K of the 16 pairs: factor-major (runtime loop over factors, each re-accumulating its own r^2 from LDS:
@@ -379,7 +365,7 @@ static bool rbf2_match(const KernSpecDev& s, Rbf2Spec& o) {
     o = Rbf2Spec{};
     o.D = s.D;
     o.diag_add = s.theta[s.np] + s.theta[s.np + 1];
-    auto half_inv_l2 = [&](int f) { const double l = s.theta[2 * f + 1]; return 0.5 * (1.0 / (l * l)); };
+    auto half_inv_l2 = [&](int f) { return 0.5 * inv_sq(s.theta[2 * f + 1]); };
     if (s.nf == 1) {
         o.b0 = s.c0[0]; o.b1 = s.c1[0];
         o.v1 = s.theta[0]; o.cb = half_inv_l2(0);
@@ -576,7 +562,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
             double rho[16];
             const double inv_l2 = factor_r2(sp, f, sxi, sxj, ty, tx, r2);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) r2[e] *= inv_l2;      // scaled squared distance s
+            for (int e = 0; e < 16; ++e) r2[e] = fmin(r2[e] * inv_l2, SCALED_R2_MAX);      // scaled squared distance s
             factor_logderiv_over_s(sp.type[f], r2, rho);
             if (sp.nl[f] == 1) {
                 double sl = 0.0;
@@ -591,7 +577,7 @@ __global__ __launch_bounds__(256) void mfgp_grad_tiles_f64(KernSpecDev sp, const
                     pair_r2_ard(sp, sxi, sxj, ty, tx, d, d + 1, sp.toff[f] + 1 + (d - sp.c0[f]), col);
                     double sl = 0.0;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) sl = __builtin_fma(rho[e], col[e], sl);
+                    for (int e = 0; e < 16; ++e) sl = __builtin_fma(rho[e], fmin(col[e], SCALED_R2_MAX), sl);
                     block_sum_to(sl, sred, out + sp.toff[f] + 1 + (d - sp.c0[f]));
                 }
             }

@@ -26,8 +26,14 @@ class OracleEngine:
     def eval(self, theta, noise, jitter=1e-8, want_grad=True):
         self.n_evals += 1
         self.theta, self.noise = np.asarray(theta, float), float(noise)
-        self.st = orc.inference(self.parts, self.theta, self.noise, self.X, self.Y, want_grad=True, const_jitter=jitter)
+        # IEEE specials are part of the arithmetic at the edge of the parameter domain (r / l overflows to inf, exp(-inf) = 0), as in
+        # GPy; what comes out of them is asserted in tests/test_host_logic.py::test_evaluations_at_the_edge_of_the_parameter_domain
+        with np.errstate(all="ignore"):
+            self.st = self._inference(jitter)
         return (self.st["nlml"], self.st["grad"]) if want_grad else self.st["nlml"]
+
+    def _inference(self, jitter):
+        return orc.inference(self.parts, self.theta, self.noise, self.X, self.Y, want_grad=True, const_jitter=jitter)
 
     def nlml_grad(self):
         return self.st["grad"]

@@ -370,6 +370,20 @@ def test_cfg5_at_its_stated_size_512_to_8192(engine_cls):
             assert model.hf_model.objective_function() == pytest.approx(st["nlml"], rel=1e-7 if target < 4096 else 3e-7)
             np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-6 * max(1.0, np.abs(Y).max()))
             np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-6)
+            # (3) which side loses those digits: the quad-precision values (oracle/quad_truth.c; 2 s at 1024 rows, 25 s at 4096) --
+            # the HIP state after thousands of rank-1 appends against the TRUE numbers at the STATED add_noise tolerances
+            if target in (1024, 4096):
+                from oracle import quad_truth
+                tr = quad_truth.evaluate(parts, theta, noise, Xa, Y, Xsa, jitter=model.hf_model._jitter_used, want_grad=False)
+                ys = max(1.0, np.abs(Y).max())
+                err_n = abs(model.hf_model.objective_function() - tr["nlml"]) / abs(tr["nlml"])
+                err_o = abs(st["nlml"] - tr["nlml"]) / abs(tr["nlml"])
+                tol._record("cfg5_vs_quad/n%d" % target, "nlml_rel", err_n / tol.NLML_REL_ADDNOISE)
+                tol._record("cfg5_vs_quad/n%d" % target, "oracle_nlml_rel", err_o / tol.NLML_REL_ADDNOISE)
+                assert err_n <= tol.NLML_REL_ADDNOISE, (err_n, err_o)
+                tol.check_pred(mean[:, 0], tr["mean"], ys, tol.PRED_ABS_ADDNOISE, label="cfg5_vs_quad/n%d" % target, what="mean")
+                tol.check_pred(np.maximum(var[:, 0] - noise, 1e-15), np.maximum(tr["var"], 1e-15), ys, tol.PRED_ABS_ADDNOISE,
+                               label="cfg5_vs_quad/n%d" % target, what="var")
             print("cfg5 N_hf = %d: nlml %.6f (oracle %.6f, fresh %.6f), %.1f s so far"
                   % (target, model.hf_model.objective_function(), st["nlml"], nlml_fresh, time.perf_counter() - t0))
         if target < 8192:

@@ -5,6 +5,7 @@ import pytest
 
 from oracle import gp_oracle as orc
 from tests import cases
+from tests import tolerances as tol
 
 pytestmark = pytest.mark.gpu
 
@@ -26,16 +27,16 @@ def test_gpregression_objective_gradient_and_transform_match_oracle():
     x = m.optimizer_array.copy()
     f, g = m._objective_grads(x)
     fo, go = orc.objective_transformed(c["parts"], x, c["X"], c["Y"])
-    assert f == pytest.approx(fo, rel=1e-10)
-    np.testing.assert_allclose(g, go, rtol=0, atol=1e-8 * np.abs(go).max())
+    tol.check_nlml(f, fo, label="gpregression/objective")
+    tol.check_grad(g, go, label="gpregression/gradient")          # optimizer-space gradient, per component
     # fixing the noise removes it from the optimizer vector; regex access like the reference's ARD
     m[".*Gaussian_noise"] = 0.05
     m[".*Gaussian_noise"].fix()
     assert len(m.optimizer_array) == 6
     f2, g2 = m._objective_grads(m.optimizer_array)
     fo2, go2 = orc.objective_transformed(c["parts"], m.optimizer_array, c["X"], c["Y"], fixed_noise=0.05)
-    assert f2 == pytest.approx(fo2, rel=1e-10)
-    np.testing.assert_allclose(g2, go2, rtol=0, atol=1e-8 * np.abs(go2).max())
+    tol.check_nlml(f2, fo2, label="gpregression/objective_fixed_noise")
+    tol.check_grad(g2, go2, label="gpregression/gradient_fixed_noise")
     m.close()
 
 
@@ -53,8 +54,8 @@ def test_ard_lengthscales_on_the_gpu_match_the_oracle_and_the_cpu_driver():
     assert len(x) == 13
     f, g = m._objective_grads(x)
     fo, go = orc.objective_transformed(c["parts"], x, c["X"], c["Y"])
-    assert f == pytest.approx(fo, rel=1e-10)
-    np.testing.assert_allclose(g, go, rtol=0, atol=1e-8 * np.abs(go).max())
+    tol.check_nlml(f, fo, label="gpregression_ard/objective")
+    tol.check_grad(g, go, label="gpregression_ard/gradient")
     c1 = cases.make_case("rbf_ard_3d_n50")
     m1 = gp.GPRegression(c1["X"], c1["Y"][:, None], kernel=gp.RBF(3, ARD=True))
     f0 = m1.objective_function()
@@ -64,13 +65,19 @@ def test_ard_lengthscales_on_the_gpu_match_the_oracle_and_the_cpu_driver():
     fo1, go1 = orc.objective_transformed(c1["parts"], run.x_opt, c1["X"], c1["Y"])
     assert run.f_opt < f0 and run.f_opt == pytest.approx(fo1, rel=1e-9)
     x0 = orc.logexp_finv(np.ones(5))
-    _, f_cpu, _ = fmin_l_bfgs_b(lambda x_: orc.objective_transformed(c1["parts"], x_, c1["X"], c1["Y"]), x0, maxfun=200, maxiter=200)
+    # (a bare scipy driver on GPy's formulas: its line search visits a lengthscale where they give 0 / 0 -- which points those
+    # are, and what the engine returns there instead, is pinned by tests/test_host_logic.py::test_evaluations_at_the_edge_... and
+    # tests/test_gpu_edge.py)
+    with np.errstate(all="ignore"):
+        _, f_cpu, _ = fmin_l_bfgs_b(lambda x_: orc.objective_transformed(c1["parts"], x_, c1["X"], c1["Y"]), x0, maxfun=200, maxiter=200)
     assert run.f_opt <= f_cpu + 0.5
     mean, var = m1.predict(c1["Xs"])
     st = orc.inference(c1["parts"], m1._theta(), m1.likelihood.variance.value, c1["X"], c1["Y"], want_grad=False)
     mu, v = orc.predict_stable(c1["parts"], m1._theta(), m1.likelihood.variance.value, c1["X"], st, c1["Xs"])
-    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-8 * max(1.0, np.abs(c1["Y"]).max()))
-    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-8)
+    cf = tol.cond_factor(tol.cond_bound(orc.cov(c1["parts"], m1._theta(), c1["X"]), float(m1.likelihood.variance.value)))
+    ys = max(1.0, np.abs(c1["Y"]).max())
+    tol.check_pred(mean[:, 0], mu, ys, tol.PRED_ABS * cf, label="ard_fit/mean", what="mean")
+    tol.check_pred(var[:, 0], v, ys, tol.PRED_ABS * cf, label="ard_fit/var", what="var")
     m.close(); m1.close()
 
 
@@ -121,8 +128,10 @@ def test_models_fit_predict_like_reference_scripts(method):
     Xa = model.hf_model.X
     st = orc.inference(parts, theta, 1e-6, Xa, model.hf_Y)
     mu, v = orc.predict_stable(parts, theta, 1e-6, Xa, st, model._augment_data(X_test))
-    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-6)
-    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-6)
+    cf = tol.cond_factor(tol.cond_bound(orc.cov(parts, theta, Xa), 1e-6))
+    ys = max(1.0, np.abs(model.hf_Y).max())
+    tol.check_pred(mean[:, 0], mu, ys, tol.PRED_ABS * cf, label="fit_add_noise/" + method, what="mean")
+    tol.check_pred(var[:, 0], v, ys, tol.PRED_ABS * cf, label="fit_add_noise/" + method, what="var")
     if method == "GPDFC":
         assert len(model.lengthscale_hyperparams()) == 3
     model.close()
@@ -285,8 +294,10 @@ def test_adapt_without_reoptimisation_uses_rank1_append():
     nz = model.hf_model.likelihood.variance.value
     st = orc.inference(parts, th, nz, model.hf_model.X, model.hf_Y)
     mu, v = orc.predict_stable(parts, th, nz, model.hf_model.X, st, model._augment_data(Xt))
-    np.testing.assert_allclose(mean[:, 0], mu, rtol=0, atol=1e-6)
-    np.testing.assert_allclose(var[:, 0], v, rtol=0, atol=1e-6)
+    cf = tol.cond_factor(tol.cond_bound(orc.cov(parts, th, model.hf_model.X), float(nz)))
+    ys = max(1.0, np.abs(model.hf_Y).max())
+    tol.check_pred(mean[:, 0], mu, ys, tol.PRED_ABS * cf, label="adapt_appends", what="mean")
+    tol.check_pred(var[:, 0], v, ys, tol.PRED_ABS * cf, label="adapt_appends", what="var")
     model.close()
 
 

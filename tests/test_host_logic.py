@@ -331,3 +331,26 @@ def test_bench_never_starts_the_power_sampler_under_a_profiler():
     assert not bench.under_profiler({"LD_PRELOAD": "/usr/local/graft/lib/libasan.so.libclang_rt.asan.graft-execguard.so"})   # the pool's own guard
     for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB"):
         assert bench.under_profiler({k: "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"})
+
+
+def test_evaluations_at_the_edge_of_the_parameter_domain():
+    """the CPU double visits non-finite arithmetic in the ARD / adaptation tests (warnings in a green run) and
+    nothing said what comes out.  This does, through the host layer, with RuntimeWarnings as errors: NaN / inf parameters are FAILED
+    evaluations (DBL_MAX and the previous gradient, paramz' convention); a softplus image of 1e-304 is an ordinary point for the
+    isotropic kernels (r / l overflows to inf, exp(-inf) = 0: K = variance * I, finite objective, zero lengthscale gradient); and
+    the places where GPy's OWN formulas produce NaN there (ARD: X / l = inf, inf - inf; Matern at r = inf: inf * 0) are listed --
+    the HIP engine returns the finite limit at those (tests/test_gpu_edge.py)."""
+    from tests import edge_points as ep
+    from tests.oracle_engine import OracleEngine
+    nan_in_the_double = set()
+    for kind in ep.KINDS:
+        res = ep.evaluate(kind, OracleEngine())
+        assert np.isfinite(res["sane"][0]) and np.all(np.isfinite(res["sane"][1]))
+        assert res["nan"][0] == ep.F_FAILED and res["inf"][0] == ep.F_FAILED
+        for name, (f, g) in res.items():
+            if not (np.isfinite(f) and np.all(np.isfinite(g))) and name not in ("nan", "inf"):
+                nan_in_the_double.add((kind, name))
+    assert nan_in_the_double == {
+        ("rbf", "tiniest lengthscale"), ("matern32", "tiniest lengthscale"),
+        ("matern52_ard", "tiny lengthscale"), ("matern52_ard", "tiniest lengthscale"), ("matern52_ard", "all tiny"),
+        ("rbf_ard", "tiny lengthscale"), ("rbf_ard", "tiniest lengthscale"), ("rbf_ard", "all tiny")}, sorted(nan_in_the_double)
