@@ -370,6 +370,22 @@ def stop_power_watch(proc, wall0, wall1):
 EXIT_PEER_LOST = 4    # a rank whose peer vanished mid-collective (the launcher reports the rank that vanished, not this one)
 
 
+def sharding_note(world, restarts, rccl_ranks):
+    """what an N-rank job shards, in words (config.sharding of the JSON line)"""
+    if world == 1:
+        return "one rank: nothing is sharded"
+    from multifidelity_datafusion_gps_amd.abstractMFGP import AbstractMFGP
+    assign = AbstractMFGP.assign_restarts(restarts, world)
+    chain = [0] + [r for r in range(1, world) if not assign[r]]
+    shared = rccl_ranks == world
+    return ("predictive rows by contiguous blocks over the ranks; the randomized restarts dealt to the ranks %s (each rank runs its own in lock step "
+            "over batched evaluations); the LF run: one optimiser on rank 0, %s; the sequential pair first HF run -> restart 0: rank 0%s"
+            % (assign, "every evaluation shared by all ranks (mfgp_eval_sharded: Cholesky replicated, rows of L^-T / K^-1 by 128-row block, one "
+                       "all-gather + one all-reduce)" if shared else "the others adopt its optimum",
+               (", its evaluations shared with ranks %s, which were dealt no restart" % chain[1:]) if (shared and len(chain) > 1 and not assign[0])
+               else " alone (every other rank has restarts of its own)"))
+
+
 def launch_ranks(n_ranks, argv, script=None):
     """the --gpus N > 1 job started as a plain process: N child processes of this script, one rank per GPU.  Runs BEFORE
     this process imports the engine or touches HIP (it never does).  Children inherit stdout / stderr, so rank 0's JSON
@@ -613,8 +629,7 @@ def main():
                        "restart_concurrency": None if lockstep else max(args.concurrency, 2), "collectives": collectives,
                        "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
-                       "sharding": "randomized restarts + predictive rows over ranks; LF run on rank 0 (the others adopt its optimum); "
-                                   "first HF run -> restart 0 on rank 0 only"},
+                       "sharding": sharding_note(world, args.restarts, int(engines["lf"].comm_size))},
             # the dominant work: ONE sweep per evaluation = Cholesky + triangular inverse%s, timed with HIP events on the
             # engine's main stream around the sweep (the bulk stream joins before the closing event)
             "roofline": {"kernel": "factorisation sweep per evaluation: mfgp_leaf_cholinv_f64 + mfgp_gemm_nt_f64_{t128,t64,chain} on v_mfma_f64_4x4x4_4b "
