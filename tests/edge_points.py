@@ -68,8 +68,8 @@ def evaluate(kind, engine):
 
 
 def cond_factors(kind):
-    """-> {point name: factor on the stated tolerances (tests/tolerances.py) from the cond(Ky) bound at that point}; the cap where
-    the bound is not a number"""
+    """-> {point name: (factor on the stated tolerances (tests/tolerances.py) from the cond(Ky) bound at that point}; the cap where
+    the bound is not a number, and the bound itself)}"""
     from oracle import gp_oracle as orc
     from tests import tolerances as tol
     from tests.oracle_engine import OracleEngine
@@ -77,12 +77,13 @@ def cond_factors(kind):
     m = gp.GPRegression(X, Y, kernel=kern, engine=OracleEngine())
     out = {}
     for name, x in points(len(m.optimizer_array)).items():
-        cf = tol.COND_CAP
+        cf, cond = tol.COND_CAP, np.inf
         if np.all(np.isfinite(x)):
             m.optimizer_array = np.array(x)
             with np.errstate(all="ignore"):
                 K = orc.cov(m._parts, m._theta(), m.X)
                 if np.all(np.isfinite(K)):
-                    cf = tol.cond_factor(tol.cond_bound(K, float(m.likelihood.variance.value)))
-        out[name] = cf
+                    cond = tol.cond_bound(K, float(m.likelihood.variance.value))
+                    cf = tol.cond_factor(cond)
+        out[name] = (cf, cond)
     return out

@@ -31,7 +31,7 @@ def _check_fitted_level(model, Xs, mean, var, label):
     Xsa = model._augment_data(Xs)
     mu, v_inv = orc.predict(parts, theta, noise, Xa, st, Xsa)
     _, v_tri = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
-    tol.check_nlml(model.hf_model.objective_function(), st["nlml"], rel=tol.NLML_REL * cf, label=label)
+    tol.check_nlml(model.hf_model.objective_function(), st["nlml"], rel=tol.nlml_rel(tol.cond_bound(st["K"], noise)), label=label)
     g = model.hf_model._engine.eval(theta, noise, model.hf_model._jitter_used, want_grad=True)[1]
     tol.check_grad(g, st["grad"], rel=tol.GRAD_REL * cf, label=label)
     ys = np.abs(Y).max()

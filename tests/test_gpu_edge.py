@@ -24,8 +24,8 @@ def test_edge_of_the_parameter_domain(engine_cls, kind):
             assert f == ep.F_FAILED
             continue
         if np.isfinite(fr) and np.all(np.isfinite(gr)):
-            cf = cfs[name]
-            assert abs(f - fr) <= tol.NLML_REL * cf * max(1.0, abs(fr)), (kind, name, f, fr, cf)
+            cf, cond = cfs[name]
+            assert abs(f - fr) <= tol.nlml_rel(cond) * max(1.0, abs(fr)), (kind, name, f, fr, cond)
             # optimizer-space gradient (the softplus factor is part of it); 1e-280: entries that are themselves ~1e-290
             scale = np.maximum(np.abs(gr), tol.GRAD_FLOOR * np.linalg.norm(gr))
             assert np.all(np.abs(g - gr) <= tol.GRAD_REL * cf * scale + 1e-280), (kind, name, g, gr, cf)

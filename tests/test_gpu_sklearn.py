@@ -68,7 +68,7 @@ def test_hip_outputs_against_scikit_learn(engine, name):
     gpr = sk.GaussianProcessRegressor(kernel=k, alpha=noise + 1e-8, optimizer=None, normalize_y=False).fit(X, Y)
     lml, g_sk = gpr.log_marginal_likelihood(gpr.kernel_.theta, eval_gradient=True)
     cf = tol.cond_factor(tol.cond_bound(Ksk, noise))
-    tol.check_nlml(nlml, -lml, rel=tol.NLML_REL * cf, label="sklearn/" + name)
+    tol.check_nlml(nlml, -lml, rel=tol.nlml_rel(tol.cond_bound(Ksk, noise)), label="sklearn/" + name)
 
     # scikit-learn's hyper-parameter vector: per factor [log const, log length_scale[0..D-1]] in kernel-tree order
     sizes = [h.n_elements for h in gpr.kernel_.hyperparameters]

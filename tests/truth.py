@@ -76,8 +76,8 @@ def check_against_truth(label, case, tr, nlml=None, grad=None, mean=None, var=No
         # an NLML near zero is a sum of terms that are not: the relative bound is on the terms' magnitude (tools/fuzz_parity.py)
         scale = max(abs(tr["nlml"]), 0.5 * (case["X"].shape[0] * np.log(2 * np.pi) + abs(tr["logdet"])))
         err = abs(nlml - tr["nlml"]) / scale
-        tol._record(label, "nlml_rel", err / (tol.NLML_REL * cf))
-        assert err <= tol.NLML_REL * cf, (nlml, tr["nlml"], err)
+        tol._record(label, "nlml_rel", err / tol.nlml_rel(cond))
+        assert err <= tol.nlml_rel(cond), (nlml, tr["nlml"], err)
     if grad is not None:
         tol.check_grad(grad, tr["grad"], rel=tol.GRAD_REL * cf, label=label)
     if mean is not None:

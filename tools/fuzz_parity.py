@@ -3,7 +3,9 @@ structures (single / composite, RBF / Matern-3/2 / -5/2, isotropic / ARD), rando
 engine against the numpy/LAPACK oracle on NLML, gradient (per component), predictive mean and variance (against BOTH of the
 oracle's predictive forms: GPy's explicit inverse and the triangular one) -- and, every few cases, a rank-1 append against a
 fresh factorisation.  Errors are reported in units of the stated tolerances (tests/tolerances.py) times the case's conditioning
-factor: <= 1 passes.  usage: fuzz_parity.py [seconds=120] [seed=0] [nmax=3000]"""
+factor: <= 1 passes.  usage: fuzz_parity.py [seconds=120] [seed=0] [nmax=3000] [truth]
+With `truth` as the fourth argument both fp64 paths are held against the quad-precision values instead (oracle/quad_truth.c; keep nmax
+around 700: the 113-bit evaluation costs N^3)."""
 import os
 import sys
 import time
@@ -69,7 +71,7 @@ def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
         # large: the error is held against the magnitude of the terms, not of their sum (the fixed-parameter tests of the suite
         # assert rel 1e-10 of |NLML| itself: there it is not near a crossing)
         nlml_scale = max(1.0, abs(st["nlml"]), 0.5 * (c["N"] * orc.LOG_2_PI + abs(st["logdet"]) + abs(float(c["Y"] @ st["alpha"]))))
-        err = dict(nlml=abs(nlml - st["nlml"]) / nlml_scale / (tol.NLML_REL * cf),
+        err = dict(nlml=abs(nlml - st["nlml"]) / nlml_scale / tol.nlml_rel(cond),
                    grad=(np.abs(grad - st["grad"]) / tol.grad_scale(st["grad"])).max() / (tol.GRAD_REL * cf),
                    mean=np.abs(m - mu).max() / (tol.PRED_ABS * ys * cf),
                    var=np.abs(v - var).max() / (tol.PRED_ABS * ys * cf),
@@ -99,7 +101,59 @@ def run(seconds=120.0, seed=0, nmax=3000, max_cases=None, verbose=True):
     return n, bad, worst
 
 
+def run_truth(seconds=120.0, seed=0, nmax=700, verbose=True):
+    """The same random cases, but BOTH fp64 paths against the quad-precision evaluation (oracle/quad_truth.c): errors of the HIP
+    engine and of the numpy/LAPACK oracle from the true values, in units of the stated tolerances x the cond factor."""
+    from oracle import quad_truth
+    rng = np.random.default_rng(seed)
+    e = Engine(0)
+    t0, n, bad = time.time(), 0, []
+    worst = {w: dict(nlml=0.0, grad=0.0, mean=0.0, var=0.0) for w in ("hip", "oracle")}
+    worst["oracle"]["var_explicit_over_bound"] = 0.0
+    while time.time() - t0 < seconds:
+        c = random_case(rng, nmax)
+        if c["N"] < 2:
+            continue
+        tr = quad_truth.evaluate(c["parts"], c["theta"], c["noise"], c["X"], c["Y"], c["Xs"], want_K=True)
+        st = orc.inference(c["parts"], c["theta"], c["noise"], c["X"], c["Y"])
+        mu, var = orc.predict_stable(c["parts"], c["theta"], c["noise"], c["X"], st, c["Xs"], include_noise=False)
+        _, var_inv = orc.predict(c["parts"], c["theta"], c["noise"], c["X"], st, c["Xs"], include_noise=False)
+        e.set_data(c["X"], c["Y"]); e.set_kernel(c["parts"])
+        nlml, grad = e.eval(c["theta"], c["noise"], 1e-8)
+        m, v = e.predict(c["Xs"], include_noise=False)
+        ys = max(1.0, np.abs(c["Y"]).max())
+        cond = tol.cond_bound(tr["K"], c["noise"]); cf = tol.cond_factor(cond)
+        scale = max(1.0, abs(tr["nlml"]), 0.5 * (c["N"] * orc.LOG_2_PI + abs(tr["logdet"]) + abs(float(c["Y"] @ tr["alpha"]))))
+        tv = np.maximum(tr["var"], 1e-15)
+        for who, (f_, g_, m_, v_) in (("hip", (nlml, grad, m, v)), ("oracle", (st["nlml"], st["grad"], np.ravel(mu), np.ravel(var)))):
+            err = dict(nlml=abs(f_ - tr["nlml"]) / scale / tol.nlml_rel(cond),
+                       grad=(np.abs(g_ - tr["grad"]) / tol.grad_scale(tr["grad"])).max() / (tol.GRAD_REL * cf),
+                       mean=np.abs(m_ - tr["mean"]).max() / (tol.PRED_ABS * ys * cf),
+                       var=np.abs(np.maximum(v_, 1e-15) - tv).max() / (tol.PRED_ABS * ys * cf))
+            for k, x in err.items():
+                worst[who][k] = max(worst[who][k], float(x))
+            if any(not (x <= 1.0) for x in err.values()):
+                bad.append((who, n, c["N"], c["D"], c["parts"], [float(x) for x in c["theta"]], c["noise"], {k: float(x) for k, x in err.items()}))
+                if verbose:
+                    print("MISMATCH", bad[-1], flush=True)
+        kss = orc.cov_diag(c["parts"], c["theta"], 1)[0]
+        worst["oracle"]["var_explicit_over_bound"] = max(worst["oracle"]["var_explicit_over_bound"], float(
+            np.abs(np.maximum(np.ravel(var_inv), 1e-15) - tv).max() / tol.explicit_inverse_bound(cond, kss, ys, tol.PRED_ABS * cf)))
+        n += 1
+        if verbose and n % 50 == 0:
+            print("%d cases, %.0f s" % (n, time.time() - t0), flush=True)
+    e.close()
+    if verbose:
+        print("fuzz_parity (against quad precision): %d cases in %.0f s (seed %d, N <= %d), %d outside the stated tolerances" % (n, time.time() - t0, seed, nmax, len(bad)))
+        for who in ("hip", "oracle"):
+            print("  %-6s worst error / (stated tolerance x cond factor): %s" % (who, {k: "%.2e" % x for k, x in worst[who].items()}))
+    return n, bad, worst
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 4 and sys.argv[4] == "truth":
+        _, _bad, _ = run_truth(float(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+        sys.exit(1 if _bad else 0)
     _, _bad, _ = run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
                      int(sys.argv[3]) if len(sys.argv) > 3 else 3000)
     sys.exit(1 if _bad else 0)

@@ -34,7 +34,7 @@ tv = np.maximum(tr["var"], 1e-15)
 print("cond(Ky) bound %.2e -> tolerance factor %.1f" % (cond, cf))
 print("%-34s %12s %12s   (stated tolerance)" % ("error against the quad values", "HIP", "fp64 oracle"))
 print("%-34s %12.2e %12.2e   (1e-13 k**)" % ("K, max abs", np.abs(Kh - tr["K"]).max(), np.abs(Ko - tr["K"]).max()))
-print("%-34s %12.2e %12.2e   (%.1e)" % ("NLML, relative", abs(nlml - tr["nlml"]) / abs(tr["nlml"]), abs(st["nlml"] - tr["nlml"]) / abs(tr["nlml"]), tol.NLML_REL * cf))
+print("%-34s %12.2e %12.2e   (%.1e)" % ("NLML, relative", abs(nlml - tr["nlml"]) / abs(tr["nlml"]), abs(st["nlml"] - tr["nlml"]) / abs(tr["nlml"]), tol.nlml_rel(cond)))
 print("%-34s %12.2e %12.2e   (%.1e)" % ("mean, max abs", np.abs(mean - tr["mean"]).max(), np.abs(np.ravel(mu) - tr["mean"]).max(), tol.PRED_ABS * cf * ys))
 print("%-34s %12.2e %12.2e   (%.1e)" % ("variance (triangular), max abs", np.abs(np.maximum(var, 1e-15) - tv).max(), np.abs(np.ravel(v_tri) - tv).max(), tol.PRED_ABS * cf * ys))
 print("%-34s %12s %12.2e   (explicit-inverse bound %.1e)" % ("variance (GPy's explicit inverse)", "-", np.abs(np.ravel(v_exp) - tv).max(), tol.explicit_inverse_bound(cond, kss, ys)))
