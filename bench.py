@@ -508,7 +508,7 @@ def main():
     # creation ORDER matters: HIP maps the handles' streams onto its hardware queues by creation, and handles that share a queue
     # serialise (tools/queue_pairs.py: of four handles created back to back, 0 + 3 and 1 + 2 share).  --aux-order reversed creates
     # hf#2 before hf#1, so that the first auxiliary handle lands on the lane the main handle (hf) is NOT on.
-    lanes = args.lanes if args.lanes > 0 else (2 if args.n < 6144 else 1)
+    lanes = args.lanes if args.lanes > 0 else (2 if 768 <= args.n < 6144 else 1)      # the model's by-size rule
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     lockstep = bool(args.lockstep) if args.lockstep >= 0 else (args.n < 6144 or world_env > 1)      # the model's by-size rule
     n_aux = (lanes - 1) if lockstep else max(args.concurrency, 2)

@@ -52,12 +52,16 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
                                 # at once (6 slots on two lanes: N = 512 55 -> 37 ms, 2048 140 -> 121, profiles/r04_midsize_fit.txt)
     lockstep_lanes = None       # engine handles the live slots are dealt to (each lane batches ITS slots' evaluations: a lane's serial
                                 # chain then overlaps another lane's bulk work, and the hosts' L-BFGS-B steps of one lane the GPU pass
-                                # of another).  None: 2 below N = 6144 (fits 8-15 % faster than on one lane at N = 1024 .. 4096,
-                                # profiles/r04_midsize_fit.txt), 1 from there (N = 8192: the job sits at the socket's power cap
-                                # either way; one lane of 4 evaluations measured 1 % ahead of 2 x 2)
+                                # of another).  None: 2 for 768 <= N < 6144 (fits 8-10 % faster than on one lane at N = 1024 .. 4096,
+                                # profiles/r04_midsize_fit.txt), 1 below (a second lane's thread costs more than it overlaps) and
+                                # from 6144 (N = 8192: the job sits at the socket's power cap either way; one lane of 4 evaluations
+                                # measured 1 % ahead of 2 x 2)
     shard_sequential = True     # multi-GPU: the fit's SEQUENTIAL evaluations -- the low-fidelity run (all ranks would idle through it)
                                 # and first run -> restart 0 (beside the ranks that were dealt no restart) -- are shared by a group
                                 # of ranks (mfgp_eval_sharded: same numbers bit for bit, the rows of L^-T / K^-1 split); needs RCCL
+    lockstep_threads = False    # True: the lock-stepped runs as one THREAD each on scipy's blocking fmin_l_bfgs_b (the form that does not
+                                # need scipy's private L-BFGS-B core; taken by itself when that core cannot be driven by reverse
+                                # communication -- lbfgsb.available()); False: one loop per lane over run generators (same runs, same steps)
     restart_lend_main = False   # the main engine joins the restarts' pool once its sequential runs are through
     restart_aux = None          # auxiliary engine handles of the concurrent restarts (None: restart_concurrency of them)
     diagonal_points = 1000      # resolution of the box diagonal the adaptation loop predicts on every step (:318)
@@ -285,16 +289,23 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         n_bg_slots = min(len(mine_bg), max(width - own, 1 if mine_bg else 0))
         n_slots = n_bg_slots + own
         # deal the slots to the lanes: lane 0 = the model's own handle (slot 0, the sequential pair, lives there)
-        want_lanes = int(self.lockstep_lanes) if self.lockstep_lanes else (2 if len(model.X) < 6144 else 1)
+        # (lanes by size, measured with the run generators: below N ~ 768 a pass is so short that a second lane only adds its thread's
+        # hand-offs -- N = 256: 19 ms on one lane, 30-36 on two; 512: 25-27 / 24-31 -- from 1024 the second lane's passes fill the first
+        # one's idle phases: 1024: 49 / 44, 2048: 141 / 130, 4096: 586 / 544; at N = 8192 one lane measured 1 % ahead)
+        want_lanes = int(self.lockstep_lanes) if self.lockstep_lanes else (2 if 768 <= len(model.X) < 6144 else 1)
         n_lanes = max(1, min(want_lanes, n_slots))
-        # (round-robin; giving lane 0 the sequential pair ALONE was measured and is no better: its single evaluations then share the
-        # GPU with the other lane's batch of five -- N = 2048: 126 against 121 ms per fit, 4096: 592 / 587)
+        # (round-robin; giving lane 0 the sequential pair ALONE was measured twice and is within the run-to-run spread: its single
+        # evaluations then share the GPU with the other lane's batch of five -- N = 2048: 126 / 121 ms per fit with a thread per run,
+        # 124 / 130 with the run generators; 4096: 592 / 587, 527 / 544; 1024: 47 / 44)
         per_lane = [[k for k in range(n_slots) if k % n_lanes == j] for j in range(n_lanes)]
         tag = self._level_of(model)
         engines = [model._engine] + [self._engine("%s#%d" % (tag, j)) for j in range(1, n_lanes)]
         for e in engines[1:]:
             e.set_data(model.X, model.Y[:, 0])
             e.set_kernel(model._parts)
+        if gp._lbfgsb.available() and not self.lockstep_threads:
+            self._lockstep_by_programs(model, engines, per_lane, mine_bg, own, rank, size)
+            return
         lanes = [gp.LockstepEvaluator(e, len(sl)) for e, sl in zip(engines, per_lane)]
         lockstep = lanes[0] if lanes else None
         handle = None
@@ -321,6 +332,63 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         if handle is not None:
             runs += handle.result()
         self.last_lockstep = lockstep
+        self.last_lockstep_lanes = lanes
+        if size > 1:
+            runs = [r for part in self.comm.allgather_object(runs) for r in part]
+        self._install_winner(model, runs, rank, size)
+
+    def _lockstep_by_programs(self, model, engines, per_lane, mine_bg, own, rank, size):
+        """The lock-stepped runs WITHOUT a thread per run: every run is a generator of engine evaluation requests
+        (engine.GPRegression._run_gen: scipy's L-BFGS-B core by reverse communication), every lane one loop over its runs
+        (engine.LockstepLane.drive) -- lane 0 in the calling thread, each further lane in one thread of its own, so that one lane's
+        L-BFGS-B steps run beside the other's batched pass.  Slot 0's program is the sequential pair: first run (noise pinned), the
+        noise freed, restart 0 from there."""
+        import collections
+        import threading
+        free_all = list(model.parameters())                 # every parameter is free during the restarts
+        starts = model.restart_starts(mine_bg, free_all, self._restart_rng())
+        todo = collections.deque(mine_bg)
+        todo_lock = threading.Lock()
+
+        def take_index():
+            with todo_lock:
+                return todo.popleft() if todo else None
+
+        out, first = {}, []
+
+        def sequential_pair():
+            yield from model.optimize_program(self.first_run_max_iters)
+            self._free_noise(model)
+            yield from model.optimize_program(self.restart_max_iters, first)     # restart 0 continues from the current point
+
+        if not own:
+            self._free_noise(model)
+        lanes = [gp.LockstepLane(e) for e in engines]
+        programs = [[sequential_pair() if (own and k == 0) else model.restart_program(take_index, starts, free_all, self.restart_max_iters, out)
+                     for k in slots] for slots in per_lane]
+        errors = []
+
+        def drive(lane, progs):
+            try:
+                lane.drive(progs)
+            except BaseException as ex:  # noqa: BLE001 - re-raised by the calling thread below
+                errors.append(ex)
+
+        threads = [threading.Thread(target=drive, args=(ln, pr), daemon=True) for ln, pr in zip(lanes[1:], programs[1:])]
+        for t in threads:
+            t.start()
+        try:
+            lanes[0].drive(programs[0])
+        finally:
+            for t in threads:
+                t.join()
+            model._dirty = True        # no handle's own factorisation is at a point the batches evaluated
+            model._have_grad = False
+        if errors:
+            raise errors[0]
+        runs = [(first[0].f_opt, first[0].x_opt, 0)] if first else []
+        runs += [out[i] for i in mine_bg]
+        self.last_lockstep = lanes[0]
         self.last_lockstep_lanes = lanes
         if size > 1:
             runs = [r for part in self.comm.allgather_object(runs) for r in part]

@@ -30,6 +30,7 @@ import numpy as np
 from scipy import optimize as _sciopt
 
 from . import _lib
+from . import lbfgsb as _lbfgsb
 from ._lib import KERN_ARD, KERN_MATERN32, KERN_MATERN52, KERN_RBF, NotPositiveDefinite
 
 _LIM_VAL = 36.0
@@ -440,6 +441,55 @@ class LockstepEvaluator:
         self._cv.notify_all()
 
 
+class LockstepLane:
+    """Several independent L-BFGS-B runs on ONE engine handle, advanced in lock step by ONE loop: every live run is a generator
+    (`GPRegression._run_gen` and the programs built from it) that yields the engine evaluation it needs next; a round collects the
+    requests of all live runs, evaluates them as one batched pass (`Engine.eval_batch`) and sends every run its own result.  No
+    thread per run, no hand-off per evaluation (the form of `LockstepEvaluator`, kept for a scipy whose L-BFGS-B core cannot be
+    driven by reverse communication): the host side of a round is the runs' own L-BFGS-B steps and nothing else.  Same statistics
+    as LockstepEvaluator (rounds, evals, round_sizes, engine_s)."""
+
+    def __init__(self, engine):
+        self._eng = engine
+        self.rounds = 0
+        self.evals = 0
+        self.round_sizes = []
+        self.engine_s = 0.0
+
+    def drive(self, programs):
+        """run the generators to their end; a program that raises ends every program of the lane (the exception propagates)"""
+        live = {}
+        for k, prog in enumerate(programs):
+            try:
+                live[k] = (prog, next(prog))
+            except StopIteration:
+                pass
+        cap = getattr(self._eng, "MAX_BATCH", 16)
+        while live:
+            slots = sorted(live)
+            results = {}
+            t0 = time.perf_counter()
+            for c0 in range(0, len(slots), cap):
+                sl = slots[c0:c0 + cap]
+                part = [live[k][1] for k in sl]
+                nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
+                                                           [r[2] for r in part], want_grad=True)
+                for j, k in enumerate(sl):
+                    results[k] = (int(status[j]), float(nlml[j]), np.array(grads[j]))
+            self.engine_s += time.perf_counter() - t0
+            self.rounds += 1
+            self.evals += len(slots)
+            self.round_sizes.append(len(slots))
+            for k in slots:
+                prog = live[k][0]
+                st, f, g = results[k]
+                try:
+                    req = prog.throw(NotPositiveDefinite(st)) if st != 0 else prog.send((f, g))
+                    live[k] = (prog, req)
+                except StopIteration:
+                    del live[k]
+
+
 class GPRegression:
     """Exact GP regression with a Gaussian likelihood on the HIP engine (GPy.models.GPRegression stand-in)."""
 
@@ -642,8 +692,13 @@ class GPRegression:
         m0 = self._main_evals   # this run's own evaluations (self.n_evals also counts background restarts running beside it)
         fun, budget = _capped(self._objective_grads, self.eval_cap, x0)
         try:
-            x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(fun, x0, maxfun=int(max_iters), maxiter=int(max_iters),
-                                                    iprint=1 if messages else -1)
+            if _lbfgsb.available() and not messages:
+                # scipy's L-BFGS-B core driven directly (lbfgsb.py: the same steps as fmin_l_bfgs_b, bit for bit, checked once per
+                # process; ~20 us less Python per evaluation -- a fit at the reference's own sizes is thousands of evaluations)
+                x_opt, f_opt, d = _lbfgsb.minimize(fun, x0, maxfun=int(max_iters), maxiter=int(max_iters))
+            else:
+                x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(fun, x0, maxfun=int(max_iters), maxiter=int(max_iters),
+                                                        iprint=1 if messages else -1)
         except _BudgetExhausted:
             x_opt, f_opt, d = budget["x"], budget["f"], {"task": "STOP: evaluation cap reached"}
         self.optimizer_array = x_opt
@@ -651,11 +706,14 @@ class GPRegression:
         self.optimization_runs.append(run)
         return run
 
-    # ---- stateless objective: lets independent L-BFGS-B runs proceed concurrently on separate engines --------
-    def _stateless_objective(self, eng, free, evaluate=None):
-        """-> f_fp(x) evaluating NLML and its optimizer-space gradient on `eng` WITHOUT touching the model's
-        Param objects (free = the parameters x stands for; every other parameter keeps its current value).
-        `evaluate(theta, noise, jitter) -> (nlml, grad)` replaces eng.eval where given (a LockstepEvaluator slot)."""
+    def _stateless_objective_gen(self, free, counter=None):
+        """-> f_gen(x): the NLML and its optimizer-space gradient at x as a GENERATOR that does not evaluate anything itself: it yields
+        the engine evaluations it needs -- (theta, noise, jitter) -- and is sent their results (nlml, grad), or has the engine's
+        NotPositiveDefinite thrown in (GPy's jitter retries: up to five more requests); its return value is (f, g).  Nothing of the
+        model's Param objects is touched (free = the parameters x stands for; every other parameter keeps the value it has NOW).
+        Whoever drives the generator decides how the requests are evaluated: one by one on an engine handle (`_stateless_objective`)
+        or, for several runs in lock step, in one batched pass per round (`LockstepLane`).  `counter`: a one-element list that
+        counts the engine evaluations asked for."""
         # index tables built once: the per-evaluation work is a handful of small-array operations (it runs under the GIL, beside
         # the other runs of a lock-stepped fit: every microsecond here is GPU idle time times the number of runs)
         params = self.parameters()
@@ -668,7 +726,7 @@ class GPRegression:
         shared = len(set(theta_idx.tolist())) != len(theta_idx)      # a Param object used by several factors: gradients add up
         state = {"fails": 0, "g": None}
 
-        def f_fp(x):
+        def f_gen(x):
             vals = base.copy()
             pv = _logexp_f(np.asarray(x, dtype=np.float64))
             vals[free_idx] = pv
@@ -679,10 +737,9 @@ class GPRegression:
                 _check_parameters(theta, noise)
                 while True:
                     try:
-                        if evaluate is not None:
-                            nlml, g = evaluate(theta, noise, CONST_JITTER + jitter_extra)
-                        else:
-                            nlml, g = eng.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=True)
+                        if counter is not None:
+                            counter[0] += 1
+                        nlml, g = yield (theta, noise, CONST_JITTER + jitter_extra)
                         self.n_evals += 1
                         break
                     except NotPositiveDefinite:
@@ -709,7 +766,52 @@ class GPRegression:
             state["g"] = gf
             return nlml, np.clip(gf, -1e100, 1e100)
 
+        return f_gen
+
+    # ---- stateless objective: lets independent L-BFGS-B runs proceed concurrently on separate engines --------
+    def _stateless_objective(self, eng, free, evaluate=None):
+        """-> f_fp(x): `_stateless_objective_gen` driven on the spot -- every request evaluated by `eng.eval`, or by
+        `evaluate(theta, noise, jitter) -> (nlml, grad)` where given (a LockstepEvaluator slot)."""
+        f_gen = self._stateless_objective_gen(free)
+
+        def f_fp(x):
+            gen = f_gen(x)
+            try:
+                req = next(gen)
+                while True:
+                    try:
+                        res = evaluate(*req) if evaluate is not None else eng.eval(req[0], req[1], req[2], want_grad=True)
+                    except NotPositiveDefinite as ex:
+                        req = gen.throw(ex)
+                    else:
+                        req = gen.send(res)
+            except StopIteration as stop:
+                return stop.value
+
         return f_fp
+
+    def _run_gen(self, free, x0, max_iters, counter=None):
+        """one L-BFGS-B run (scipy's core by reverse communication: lbfgsb.Lbfgsb; controls, `eval_cap` and result as
+        fmin_l_bfgs_b(f_fp, x0, maxfun = maxiter = max_iters) behind `_capped`) as a generator of engine evaluation requests;
+        returns (x_opt, f_opt, task)"""
+        f_gen = self._stateless_objective_gen(free, counter)
+        run = _lbfgsb.Lbfgsb(x0, maxfun=int(max_iters), maxiter=int(max_iters))
+        cap, n = self.eval_cap, 0
+        best_f, best_x = np.inf, np.array(x0, dtype=np.float64)
+        while True:
+            x = run.ask()
+            if x is None:
+                break
+            if cap:
+                if n >= cap:
+                    run.stop(best_x, best_f)
+                    break
+                n += 1
+            f, g = yield from f_gen(x)
+            if cap and f < best_f:
+                best_f, best_x = float(f), np.array(x, dtype=np.float64)
+            run.tell(f, g)
+        return np.array(run.x), float(run.f), run.message
 
     def start_background_restarts(self, indices, engines, free=None, rand_gen=None, max_iters=1000, spare=0):
         """Run the randomized restarts `indices` (each: N(0,1) start in optimizer space, L-BFGS-B with
@@ -778,6 +880,50 @@ class GPRegression:
                 finally:
                     ex.shutdown(wait=True)
         return _Handle()
+
+    def restart_starts(self, indices, free, rand_gen=None):
+        """-> {index: start of randomized restart `index` in optimizer space}: the N(0,1) draw of paramz' randomize() taken through
+        the parameter domain and back, as randomize() + optimize() do (bit-identical start); drawn in index order (deterministic
+        with a seeded rand_gen(i))"""
+        starts = {}
+        for i in indices:
+            gen = rand_gen(i) if callable(rand_gen) else None
+            draw = gen(size=len(free)) if gen is not None else np.random.normal(size=len(free))
+            starts[i] = _logexp_finv(_logexp_f(draw))
+        return starts
+
+    def restart_program(self, take_index, starts, free, max_iters, out):
+        """one slot of a lock-stepped fit as a generator of engine evaluation requests (LockstepLane.drive): it takes the next
+        randomized restart still waiting (`take_index() -> index or None`), runs it (`_run_gen`), records it, and goes on until
+        none is left.  out[index] = (f_opt, x_opt, index)."""
+        while True:
+            i = take_index()
+            if i is None:
+                return
+            counter = [0]
+            x_opt, f_opt, task = yield from self._run_gen(free, starts[i], max_iters, counter)
+            self.optimization_runs.append(_OptRun(x_opt, f_opt, counter[0], task, background=True))
+            out[i] = (f_opt, x_opt, i)
+
+    def optimize_program(self, max_iters, result=None):
+        """`optimize(max_iters=...)` of THIS model as a generator of engine evaluation requests: the run starts at the model's
+        current point over its currently free parameters and installs its optimum in the model at the end, as optimize() does --
+        but its evaluations are requests to whoever drives the generator (a LockstepLane), through the stateless objective (the
+        same arithmetic as the model's own, bit for bit: it is what the randomized restarts run on).  The engine handle's own
+        factorisation is not at any of the points evaluated: the model is left dirty.  result: a list that receives the _OptRun."""
+        x0 = self.optimizer_array.copy()
+        if x0.size == 0:
+            return
+        counter = [0]
+        x_opt, f_opt, task = yield from self._run_gen(self._free_params(), x0, max_iters, counter)
+        self.optimizer_array = x_opt
+        self._main_evals += counter[0]
+        run = _OptRun(x_opt, f_opt, counter[0], task)
+        self.optimization_runs.append(run)
+        self._dirty = True
+        self._have_grad = False
+        if result is not None:
+            result.append(run)
 
     def start_lockstep_restarts(self, indices, lanes, free=None, rand_gen=None, max_iters=1000):
         """The randomized restarts `indices` as lock-stepped runs.  `lanes` = [(LockstepEvaluator, [slot, ...]), ...]: one thread

@@ -45,3 +45,26 @@ class OracleEngine:
 
     def timings(self):
         return {}
+
+
+class BatchOracleEngine(OracleEngine):
+    """the double with `eval_batch` (B evaluations, one after the other): what makes the host layer take its lock-stepped paths on
+    the CPU (tests/test_lockstep_host.py).  Kept apart from OracleEngine: the recorded call sequences of the reference-L3 fixtures
+    are those of the sequential order."""
+    MAX_BATCH = 16
+
+    def eval_batch(self, thetas, noises, jitters=1e-8, want_grad=True):
+        thetas = np.atleast_2d(np.asarray(thetas, float))
+        B = len(thetas)
+        noises = np.broadcast_to(np.asarray(noises, float), (B,))
+        jitters = np.broadcast_to(np.asarray(jitters, float), (B,))
+        nlml, grads, status = np.zeros(B), np.zeros((B, thetas.shape[1] + 1)), np.zeros(B, dtype=np.int32)
+        for b in range(B):
+            self.n_evals += 1
+            try:
+                with np.errstate(all="ignore"):
+                    st = orc.inference(self.parts, thetas[b], float(noises[b]), self.X, self.Y, want_grad=True, const_jitter=float(jitters[b]))
+                nlml[b], grads[b] = st["nlml"], st["grad"]
+            except np.linalg.LinAlgError:
+                status[b] = 1
+        return nlml, (grads if want_grad else None), status

@@ -193,7 +193,7 @@ def test_concurrent_and_lockstep_restarts_give_the_sequential_result(n_hf):
     rng = np.random.default_rng(21)
     X_hf = rng.uniform(size=(n_hf, 2))
     out = {}
-    for mode in ("sequential", "concurrent", "lockstep", "lockstep_1lane", "lockstep_w7", "lockstep_w2"):
+    for mode in ("sequential", "concurrent", "lockstep", "lockstep_1lane", "lockstep_w7", "lockstep_w2", "lockstep_threads"):
         model = mf.NARGP(2, hf2, lf2, seed=5)
         model.first_run_max_iters = model.restart_max_iters = 40
         model.eval_cap = 12 if n_hf > 200 else None
@@ -201,6 +201,7 @@ def test_concurrent_and_lockstep_restarts_give_the_sequential_result(n_hf):
         model.restart_concurrency = 3 if mode == "concurrent" else 1
         model.lockstep_width = {"lockstep_w7": 7, "lockstep_w2": 2}.get(mode)
         model.lockstep_lanes = {"lockstep_1lane": 1, "lockstep_w7": 3}.get(mode, 2)
+        model.lockstep_threads = mode == "lockstep_threads"      # a thread per run on scipy's blocking call (the fallback form)
         model.fit(X_hf)
         runs = sorted((r.f_opt, tuple(r.x_opt)) for r in model.hf_model.optimization_runs)
         out[mode] = (np.array([p.value for p in model.hf_model.parameters()]), runs, model.hf_model.n_evals)
@@ -208,9 +209,11 @@ def test_concurrent_and_lockstep_restarts_give_the_sequential_result(n_hf):
             assert any(k.startswith("hf#") for k in model._engines)
         if mode.startswith("lockstep"):
             lanes = model.last_lockstep_lanes
-            assert len(lanes) == {"lockstep": 2, "lockstep_1lane": 1, "lockstep_w7": 3, "lockstep_w2": 2}[mode]
+            from multifidelity_datafusion_gps_amd import engine as gp
+            assert isinstance(lanes[0], gp.LockstepEvaluator if mode == "lockstep_threads" else gp.LockstepLane)
+            assert len(lanes) == {"lockstep": 2, "lockstep_1lane": 1, "lockstep_w7": 3, "lockstep_w2": 2, "lockstep_threads": 2}[mode]
             assert sum(ls.evals for ls in lanes) == sum(r.n_evals for r in model.hf_model.optimization_runs)
-            assert max(max(ls.round_sizes) for ls in lanes) == {"lockstep": 3, "lockstep_1lane": 6, "lockstep_w7": 2, "lockstep_w2": 1}[mode]
+            assert max(max(ls.round_sizes) for ls in lanes) == {"lockstep": 3, "lockstep_1lane": 6, "lockstep_w7": 2, "lockstep_w2": 1, "lockstep_threads": 3}[mode]
         mean, var = model.predict(X_hf[:20])                                       # the winner is installed and factorised
         out[mode] += (mean, var)
         model.close()

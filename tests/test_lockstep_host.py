@@ -1,0 +1,87 @@
+"""The lock-stepped restarts on the CPU (the double with eval_batch, tests/oracle_engine.py::BatchOracleEngine): the recipe's 1 + 6
+L-BFGS-B runs (src/abstractMFGP.py:131-137) as generators over scipy's L-BFGS-B core by reverse communication (lbfgsb.py,
+engine.LockstepLane), as threads over scipy's blocking fmin_l_bfgs_b (engine.LockstepEvaluator), and in the reference's sequential
+order -- the same runs, the same evaluations, the same fitted parameters, bit for bit.  (On the GPU: tests/test_gpu_models.py.)"""
+import numpy as np
+import pytest
+
+import multifidelity_datafusion_gps_amd as mf
+from multifidelity_datafusion_gps_amd import engine as gp
+from multifidelity_datafusion_gps_amd import lbfgsb
+from tests import cases
+from tests.oracle_engine import BatchOracleEngine, OracleEngine
+
+
+def col(f):
+    return lambda x: f(x)[:, None]
+
+
+def test_reverse_communication_driver_is_fmin_l_bfgs_b():
+    """lbfgsb.Lbfgsb against scipy.optimize.fmin_l_bfgs_b on GP objectives: same points asked for, same end, same counts and status"""
+    from scipy.optimize import fmin_l_bfgs_b
+    assert lbfgsb.available()
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(40, 3))
+    Y = (np.sin(6.0 * X[:, 0]) + 0.1 * X[:, 1])[:, None]
+    for kern, budget in ((gp.RBF(3), 300), (gp.RBF(3, ARD=True), 300), (gp.Matern52(3), 300), (gp.RBF(3, ARD=True), 17), (gp.Matern32(3), 5)):
+        m = gp.GPRegression(X, Y, kernel=kern, engine=OracleEngine())
+        x0 = m.optimizer_array.copy()
+        seen_a, seen_b = [], []
+
+        def fa(x):
+            seen_a.append(np.array(x))
+            return m._objective_grads(x)
+
+        def fb(x):
+            seen_b.append(np.array(x))
+            return m._objective_grads(x)
+        xa, va, da = fmin_l_bfgs_b(fa, x0, maxfun=budget, maxiter=budget)
+        xb, vb, db = lbfgsb.minimize(fb, x0, maxfun=budget, maxiter=budget)
+        assert np.array_equal(xa, xb) and va == vb
+        assert (da["funcalls"], da["nit"], da["warnflag"], da["task"]) == (db["funcalls"], db["nit"], db["warnflag"], db["task"])
+        assert len(seen_a) == len(seen_b) and all(np.array_equal(p, q) for p, q in zip(seen_a, seen_b))
+
+
+def _fit(mode, n_hf=40, evals=25, cap=None, seed=3):
+    kw = {"sequential": dict(restart_lockstep=False, restart_concurrency=1),
+          "programs, 1 lane": dict(restart_lockstep=True, lockstep_lanes=1),
+          "programs, 2 lanes": dict(restart_lockstep=True, lockstep_lanes=2),
+          "programs, 3 lanes, 4 live": dict(restart_lockstep=True, lockstep_lanes=3, lockstep_width=4),
+          "threads, 2 lanes": dict(restart_lockstep=True, lockstep_lanes=2, lockstep_threads=True)}[mode]
+    M = type("M", (mf.NARGP,), dict(first_run_max_iters=evals, restart_max_iters=evals, eval_cap=cap, **kw))
+    engines = {k: BatchOracleEngine() for k in ("hf", "lf", "hf#1", "hf#2")}
+    m = M(2, col(cases.hf_2d), col(cases.lf_2d), seed=seed, engines=engines)
+    rng = np.random.default_rng(1)
+    m.fit(rng.uniform(size=(n_hf, 2)))
+    theta = np.array([p.value for p in m.hf_model.parameters()])
+    runs = sorted((round(r.f_opt, 12), tuple(np.round(r.x_opt, 12))) for r in m.hf_model.optimization_runs)
+    mean, var = m.predict(rng.uniform(size=(16, 2)))
+    lanes = getattr(m, "last_lockstep_lanes", None)
+    return theta, runs, m.hf_model.n_evals, mean, var, lanes, sum(r.n_evals for r in m.hf_model.optimization_runs)
+
+
+@pytest.mark.parametrize("cap", [None, 12])
+def test_lockstep_programs_threads_and_the_sequential_order_give_the_same_fit(cap):
+    ref = _fit("sequential", cap=cap)
+    assert len(ref[1]) == 7                                    # first run + restart 0 + five randomized restarts
+    for mode in ("programs, 1 lane", "programs, 2 lanes", "programs, 3 lanes, 4 live", "threads, 2 lanes"):
+        got = _fit(mode, cap=cap)
+        assert np.array_equal(got[0], ref[0]), mode            # fitted hyper-parameters, bit for bit
+        assert got[1] == ref[1], mode                          # every run ended where it ends alone
+        assert got[2] == ref[2], mode                          # and took the evaluations it takes alone
+        assert np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4]), mode
+        lanes = got[5]
+        # every evaluation of the seven runs went through a lane's batched passes (the model's own count has one more: the
+        # factorisation at the winner that the fit ends with)
+        assert sum(ln.evals for ln in lanes) == got[6] == ref[6] == ref[2] - 1, mode
+        assert all(max(ln.round_sizes) <= 6 for ln in lanes if ln.round_sizes), mode
+    one = _fit("programs, 1 lane", cap=cap)[5]
+    assert len(one) == 1 and max(one[0].round_sizes) == 6      # the sequential pair + five restarts in one pass per round
+
+
+def test_lockstep_falls_back_to_threads_without_the_private_core(monkeypatch):
+    ref = _fit("programs, 2 lanes")
+    monkeypatch.setattr(lbfgsb, "_checked", False)             # as if scipy's core could not be driven by reverse communication
+    got = _fit("programs, 2 lanes")
+    assert isinstance(got[5][0], gp.LockstepEvaluator)
+    assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]

@@ -24,7 +24,10 @@ if argv and argv[0] == "--evals":
 MODES = [("sequential", dict(restart_lockstep=False, restart_concurrency=1)),
          ("concurrent 2", dict(restart_lockstep=False, restart_concurrency=2)),
          ("lockstep 1 lane", dict(restart_lockstep=True, lockstep_lanes=1)),
-         ("lockstep 2 lanes (default)", dict(restart_lockstep=True, lockstep_lanes=2)),
+         ("lockstep 2 lanes", dict(restart_lockstep=True, lockstep_lanes=2)),
+         ("lockstep, lanes by size (default)", dict(restart_lockstep=True)),
+         ("2 lanes, a thread per run", dict(restart_lockstep=True, lockstep_lanes=2, lockstep_threads=True)),
+
          ("2 lanes w4", dict(restart_lockstep=True, lockstep_lanes=2, lockstep_width=4)),
          ("3 lanes", dict(restart_lockstep=True, lockstep_lanes=3))]
 print("# python3 tools/midsize_fit.py --evals %d ...: one fit of the reference's ARD recipe (1 + 6 L-BFGS-B runs, %d evaluations each), HF level only timed" % (evals, evals))
