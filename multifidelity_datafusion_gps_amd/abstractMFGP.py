@@ -296,7 +296,9 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         n_lanes = max(1, min(want_lanes, n_slots))
         # (round-robin; giving lane 0 the sequential pair ALONE was measured twice and is within the run-to-run spread: its single
         # evaluations then share the GPU with the other lane's batch of five -- N = 2048: 126 / 121 ms per fit with a thread per run,
-        # 124 / 130 with the run generators; 4096: 592 / 587, 527 / 544; 1024: 47 / 44)
+        # 124 / 130 with the run generators; 4096: 592 / 587, 527 / 544; 1024: 47 / 44.  Stream priorities do not rescue it: with the
+        # restarts' handle one level down (chain normal / bulk low beside chain high / bulk normal) the sequential pair's evaluations
+        # speed up (N = 2048: 1.31 -> 1.1 ms) and the background lane starves: 124 -> 193 ms per fit, 4096: 539 -> 628)
         per_lane = [[k for k in range(n_slots) if k % n_lanes == j] for j in range(n_lanes)]
         tag = self._level_of(model)
         engines = [model._engine] + [self._engine("%s#%d" % (tag, j)) for j in range(1, n_lanes)]
