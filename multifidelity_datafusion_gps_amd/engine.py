@@ -344,6 +344,11 @@ _G_CLIP_FAILED = 1e10                  # returns DBL_MAX, not inf -- an infinite
                                        # interpolation into NaN steps -- and the previous gradient clipped to +-1e10]
 
 
+# what a failed evaluation raises (paramz Model._objective_grads catches exactly these [GPy-recall]): thrown INTO the objective generator
+# by whoever drives it, so that the objective's own policy (jitter retries, DBL_MAX and the previous gradient) deals with them
+_EVAL_ERRORS = (np.linalg.LinAlgError, ZeroDivisionError, ValueError)
+
+
 def _check_parameters(theta, noise):
     """a NaN / infinite / non-positive parameter (a line search gone astray) is a FAILED evaluation, handled like a failed
     Cholesky (GPy: the NaNs end in jitchol's LinAlgError), not an argument error of the engine"""
@@ -472,19 +477,24 @@ class LockstepLane:
             for c0 in range(0, len(slots), cap):
                 sl = slots[c0:c0 + cap]
                 part = [live[k][1] for k in sl]
-                nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
-                                                           [r[2] for r in part], want_grad=True)
+                try:
+                    nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
+                                                               [r[2] for r in part], want_grad=True)
+                except _EVAL_ERRORS as ex:           # the pass as a whole failed: a failed evaluation of every run in it
+                    for k in sl:
+                        results[k] = ex
+                    continue
                 for j, k in enumerate(sl):
-                    results[k] = (int(status[j]), float(nlml[j]), np.array(grads[j]))
+                    results[k] = NotPositiveDefinite(int(status[j])) if status[j] != 0 else (float(nlml[j]), np.array(grads[j]))
             self.engine_s += time.perf_counter() - t0
             self.rounds += 1
             self.evals += len(slots)
             self.round_sizes.append(len(slots))
             for k in slots:
                 prog = live[k][0]
-                st, f, g = results[k]
+                res = results[k]
                 try:
-                    req = prog.throw(NotPositiveDefinite(st)) if st != 0 else prog.send((f, g))
+                    req = prog.throw(res) if isinstance(res, BaseException) else prog.send(res)
                     live[k] = (prog, req)
                 except StopIteration:
                     del live[k]
@@ -496,6 +506,7 @@ class GPRegression:
     _allowed_failures = 10  # paramz tolerates this many failed objective evaluations per model [GPy-recall]
 
     eval_cap = None   # hard cap on objective evaluations per optimize() / restart (None: scipy's maxfun semantics only)
+    fast_optimize = True   # optimize() through the run generator (False: through the model's own Param objects, evaluation by evaluation)
 
     def __init__(self, X, Y, kernel=None, noise_var=1.0, initialize=True, engine=None, name="GP regression"):
         X = np.ascontiguousarray(X, dtype=np.float64)
@@ -689,12 +700,29 @@ class GPRegression:
         x0 = self.optimizer_array.copy()
         if x0.size == 0:
             return None
+        if _lbfgsb.available() and not messages and self._eval_hook is None and self.fast_optimize:
+            # The run as a generator of engine evaluation requests (optimize_program: scipy's L-BFGS-B core by reverse communication,
+            # the objective on index tables instead of Param objects), every request evaluated on the spot.  The same steps as the
+            # path below, bit for bit (tests/test_reference_l3.py replays the recorded evaluations of whole fits through it); per
+            # evaluation ~50 us less Python -- a fit at the reference's own sizes is thousands of evaluations of ~55 us of GPU time.
+            got = []
+            prog = self.optimize_program(max_iters, got)
+            try:
+                req = next(prog)
+                while True:
+                    try:
+                        res = self._engine.eval(req[0], req[1], req[2], want_grad=True)
+                    except _EVAL_ERRORS as ex:       # a failed Cholesky (jitter retry) or any other failed evaluation: the objective's call
+                        req = prog.throw(ex)
+                    else:
+                        req = prog.send(res)
+            except StopIteration:
+                pass
+            return got[0]
         m0 = self._main_evals   # this run's own evaluations (self.n_evals also counts background restarts running beside it)
         fun, budget = _capped(self._objective_grads, self.eval_cap, x0)
         try:
             if _lbfgsb.available() and not messages:
-                # scipy's L-BFGS-B core driven directly (lbfgsb.py: the same steps as fmin_l_bfgs_b, bit for bit, checked once per
-                # process; ~20 us less Python per evaluation -- a fit at the reference's own sizes is thousands of evaluations)
                 x_opt, f_opt, d = _lbfgsb.minimize(fun, x0, maxfun=int(max_iters), maxiter=int(max_iters))
             else:
                 x_opt, f_opt, d = _sciopt.fmin_l_bfgs_b(fun, x0, maxfun=int(max_iters), maxiter=int(max_iters),
@@ -737,13 +765,15 @@ class GPRegression:
                 _check_parameters(theta, noise)
                 while True:
                     try:
-                        if counter is not None:
-                            counter[0] += 1
                         nlml, g = yield (theta, noise, CONST_JITTER + jitter_extra)
                         self.n_evals += 1
+                        if counter is not None:
+                            counter[0] += 1
                         break
                     except NotPositiveDefinite:
                         self.n_evals += 1
+                        if counter is not None:
+                            counter[0] += 1
                         tries += 1
                         diag_mean = sum(float(np.prod(vals[t])) for t in term_idx) + noise + CONST_JITTER
                         if tries > 5 or not np.isfinite(diag_mean):
@@ -781,7 +811,7 @@ class GPRegression:
                 while True:
                     try:
                         res = evaluate(*req) if evaluate is not None else eng.eval(req[0], req[1], req[2], want_grad=True)
-                    except NotPositiveDefinite as ex:
+                    except _EVAL_ERRORS as ex:
                         req = gen.throw(ex)
                     else:
                         req = gen.send(res)

@@ -85,3 +85,40 @@ def test_lockstep_falls_back_to_threads_without_the_private_core(monkeypatch):
     got = _fit("programs, 2 lanes")
     assert isinstance(got[5][0], gp.LockstepEvaluator)
     assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]
+
+
+def test_a_failing_engine_is_a_failed_evaluation_on_every_path():
+    """an engine that raises (the CPU double's "not positive definite, even with jitter"; a ValueError) is a FAILED evaluation --
+    DBL_MAX and the previous gradient, up to paramz' ten in a row -- whether the run goes through the model's own objective, the
+    run generator on one handle, or a lane's batched passes; and all three take the same steps"""
+    class Flaky(BatchOracleEngine):
+        fail_at = (4, 11)
+
+        def eval(self, theta, noise, jitter=1e-8, want_grad=True):
+            if self.n_evals + 1 in self.fail_at:
+                self.n_evals += 1
+                raise np.linalg.LinAlgError("not positive definite, even with jitter.")
+            return super().eval(theta, noise, jitter, want_grad)
+
+        def eval_batch(self, thetas, noises, jitters=1e-8, want_grad=True):
+            if self.n_evals + 1 in self.fail_at:
+                self.n_evals += len(np.atleast_2d(thetas))
+                raise ValueError("engine refused the batch")
+            return super().eval_batch(thetas, noises, jitters, want_grad)
+
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(30, 3))
+    Y = (np.sin(5.0 * X[:, :1]) + X[:, 1:2] * X[:, 2:])
+    ends = {}
+    for fast in (True, False):
+        m = gp.GPRegression(X, Y, kernel=gp.Matern52(3, ARD=True), engine=Flaky())
+        m.fast_optimize = fast
+        run = m.optimize(max_iters=40)
+        ends[fast] = (run.x_opt, run.f_opt, m.n_evals, run.n_evals, run.status)
+        assert m._engine.n_evals > m.n_evals and run.f_opt < 1e300   # the engine failed once, nothing escaped, the run has an optimum
+    assert np.array_equal(ends[True][0], ends[False][0]) and ends[True][1:] == ends[False][1:]
+    m = gp.GPRegression(X, Y, kernel=gp.Matern52(3, ARD=True), engine=Flaky())
+    lane = gp.LockstepLane(m._engine)
+    got = []
+    lane.drive([m.optimize_program(40, got)])
+    assert np.array_equal(got[0].x_opt, ends[True][0]) and got[0].f_opt == ends[True][1]
