@@ -41,9 +41,11 @@ for n_hf in [int(a) for a in argv] or [1024]:
         m = M(4, col(cases.hf_4d), None, lf_X=X_lf, lf_Y=col(cases.lf_4d)(X_lf), seed=3)
         X = rng.uniform(size=(n_hf, 4))
         m.fit(X)                      # warm: plans, allocations
-        t0 = time.perf_counter()
-        m.fit(X)
-        dt = time.perf_counter() - t0
+        dt = np.inf
+        for _ in range(3 if n_hf <= 1024 else 1):      # (small fits: best of three -- a 15 ms fit feels every scheduling hiccup of the host)
+            t0 = time.perf_counter()
+            m.fit(X)
+            dt = min(dt, time.perf_counter() - t0)
         th = np.array([p.value for p in m.hf_model.parameters()])
         if ref is None:
             ref = th
