@@ -452,9 +452,8 @@ def main():
     ap.add_argument("--restarts", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--lockstep", type=int, default=-1,
-                    help="-1 (default): the package's default by size (one GPU, N >= 6144: concurrent restarts on auxiliary handles; "
-                         "else lock step); 1: the HF level's 1 + 6 runs as lock-stepped runs over batched evaluations "
-                         "(mfgp_eval_batch); 0: concurrent restarts (--concurrency)")
+                    help="-1 (default) and 1: the package's default -- the HF level's 1 + 6 runs as lock-stepped runs over batched "
+                         "evaluations (mfgp_eval_batch); 0: round 3's concurrent restarts on auxiliary handles (--concurrency)")
     ap.add_argument("--lanes", type=int, default=0, help="engine handles the lock-stepped runs are dealt to (0: the model's default: 1 at N >= 6144, else 2)")
     ap.add_argument("--width", type=int, default=0, help="live lock-step slots per rank (0: half the rank's runs, rounded up)")
     ap.add_argument("--concurrency", type=int, default=2,
@@ -510,7 +509,7 @@ def main():
     # hf#2 before hf#1, so that the first auxiliary handle lands on the lane the main handle (hf) is NOT on.
     lanes = args.lanes if args.lanes > 0 else (2 if 768 <= args.n < 6144 else 1)      # the model's by-size rule
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    lockstep = bool(args.lockstep) if args.lockstep >= 0 else (args.n < 6144 or world_env > 1)      # the model's by-size rule
+    lockstep = bool(args.lockstep) if args.lockstep >= 0 else True      # the model's default
     n_aux = (lanes - 1) if lockstep else max(args.concurrency, 2)
     js = list(range(1, n_aux + 1))
     for j in (reversed(js) if args.aux_order == "reversed" else js):
@@ -624,8 +623,8 @@ def main():
                        "wall_ms_per_evaluation": round(ms_per_step * args.steps / max(evals, 1), 3),
                        "restarts_run_as": ("lock-stepped runs over batched evaluations (mfgp_eval_batch): %d lanes, %s live slots"
                                            % (lanes, args.width or "auto")) if lockstep
-                                          else "concurrent restarts on %d auxiliary handles (the default from N = 6144 on one GPU; "
-                                               "lock step over batched evaluations below)" % max(args.concurrency, 2),
+                                          else "concurrent restarts on %d auxiliary handles (round 3's mode; the default is lock step "
+                                               "over batched evaluations)" % max(args.concurrency, 2),
                        "restart_concurrency": None if lockstep else max(args.concurrency, 2), "collectives": collectives,
                        "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),

@@ -37,14 +37,14 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     eval_cap = None             # hard cap on objective evaluations per L-BFGS-B run (benchmarks: exact budgets)
     restart_concurrency = 1     # 1: the reference's sequential order (the default: this layer then drives the engine call for call like the reference); >1: that many randomized restarts run concurrently with the first run / restart 0 -- same runs, same winner, 1.7-2 x faster fits at N = 256 .. 2048 (tools/midsize_fit.py)
     restart_lockstep = None     # the 1 + num_restarts runs of a fit as LOCK-STEPPED runs: every round one batched pass evaluates all
-                                # live runs of a lane (engine.LockstepEvaluator, mfgp_eval_batch) -- same runs, same steps bit for bit,
-                                # same winner as the sequential order.  None = by size: lock step below N = 6144, where one evaluation
-                                # leaves most of the GPU idle (fits 1.5-2.7 x faster); from there, on ONE GPU, the randomized restarts
-                                # as concurrent threads on two auxiliary handles (round 3's mode: at N = 8192 every mode delivers the
-                                # same ~10.5 ms per evaluation at the socket's power cap, and free-running threads hide the hosts'
-                                # L-BFGS-B steps: 1 767 ms against 1 782-1 793 in lock step on the same box); lock step again on several
-                                # ranks (a rank then holds one or two runs: nothing to hide).  True / False force it.  An engine
-                                # without eval_batch (a test double) gets the reference's sequential order.
+                                # live runs of a lane (engine.LockstepLane, mfgp_eval_batch) -- same runs, same steps bit for bit, same
+                                # winner as the sequential order.  None = True: below N ~ 6144 one evaluation leaves most of the GPU
+                                # idle and fits are 1.5-3 x faster; at N = 8192 every mode delivers the same ~10.5 ms per evaluation
+                                # at the socket's power cap (lock step by run generators 1 762-1 773 ms per bench step, round 3's
+                                # concurrent threads on two auxiliary handles 1 770-1 772 on the same box, alternating; with a thread
+                                # per run lock step had been 1-1.5 % behind).  False: the reference's sequential order, or
+                                # `restart_concurrency` > 1 concurrent restarts.  An engine without eval_batch (a test double) gets
+                                # the reference's sequential order.
     lockstep_width = None       # live slots per rank.  None: from N = 6144 half the rank's runs, rounded up -- 4 for the recipe's 1 + 6 runs:
                                 # the sequential pair first run -> restart 0 in one slot, the five randomized restarts 2 + 2 + 1 in
                                 # three more, so every round carries 4, then 3 evaluations (a pass is convex in its size there: 6 then
@@ -240,14 +240,9 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         threads WHILE the main thread does the first run and restart 0; same runs, same winner rule."""
         self._pin_noise(model)
         batched = num_restarts >= 2 and hasattr(model._engine, "eval_batch")
-        lock = self.restart_lockstep
-        if lock is None:
-            lock = len(model.X) < 6144 or self.comm.size > 1
+        lock = True if self.restart_lockstep is None else bool(self.restart_lockstep)
         if batched and lock:
             self._ard_lockstep(model, num_restarts)
-            return
-        if batched and self.restart_lockstep is None and int(self.restart_concurrency) <= 1:
-            self._ard_concurrent(model, num_restarts, 2)       # (the by-size default above N = 6144 on one GPU)
             return
         if int(self.restart_concurrency) <= 1:
             model.optimize(max_iters=self.first_run_max_iters)
