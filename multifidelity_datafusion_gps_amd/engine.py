@@ -537,6 +537,8 @@ class GPRegression:
         self.optimization_runs = []
         self._eval_hook = None     # (theta, noise, jitter) -> (nlml, grad): evaluations routed through a LockstepEvaluator
         self.n_evals = 0           # objective(+gradient) evaluations issued to the GPU
+        import threading
+        self._evals_lock = threading.Lock()   # n_evals is bumped by every thread that evaluates for this model (lanes, background restarts)
         self._main_evals = 0       # ... of those, the ones issued through this object's own state (not by background restarts)
         self.update_model = True
 
@@ -627,11 +629,11 @@ class GPRegression:
                     res = res if want_grad else res[0]
                 else:
                     res = self._engine.eval(theta, noise, CONST_JITTER + jitter_extra, want_grad=want_grad)
-                self.n_evals += 1
+                self._count_eval()
                 self._main_evals += 1
                 break
             except NotPositiveDefinite:
-                self.n_evals += 1
+                self._count_eval()
                 self._main_evals += 1
                 tries += 1
                 diag_mean = self.kern.Kdiag_value() + noise + CONST_JITTER
@@ -645,6 +647,10 @@ class GPRegression:
         self._have_grad = want_grad
         self._jitter_used = CONST_JITTER + jitter_extra
         self._dirty = False
+
+    def _count_eval(self):
+        with self._evals_lock:       # (+= on an attribute is a read and a write: two lanes' threads would lose counts now and then)
+            self.n_evals += 1
 
     def objective_function(self):
         self._ensure(False)
@@ -766,12 +772,12 @@ class GPRegression:
                 while True:
                     try:
                         nlml, g = yield (theta, noise, CONST_JITTER + jitter_extra)
-                        self.n_evals += 1
+                        self._count_eval()
                         if counter is not None:
                             counter[0] += 1
                         break
                     except NotPositiveDefinite:
-                        self.n_evals += 1
+                        self._count_eval()
                         if counter is not None:
                             counter[0] += 1
                         tries += 1
