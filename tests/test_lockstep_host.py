@@ -122,3 +122,47 @@ def test_a_failing_engine_is_a_failed_evaluation_on_every_path():
     got = []
     lane.drive([m.optimize_program(40, got)])
     assert np.array_equal(got[0].x_opt, ends[True][0]) and got[0].f_opt == ends[True][1]
+
+
+def test_reverse_communication_driver_on_random_functions_and_budgets():
+    """300 seeded random problems -- dimension 1 .. 12, budgets 1 .. 60, smooth bowls, Rosenbrock chains, functions that now and then
+    answer DBL_MAX with a stale gradient (a failed GP evaluation) or NaN: the ask / tell driver and fmin_l_bfgs_b ask for the same points
+    and end the same way, bit for bit"""
+    from scipy.optimize import fmin_l_bfgs_b
+    rng = np.random.default_rng(2024)
+    for case in range(300):
+        n = int(rng.integers(1, 13))
+        budget = int(rng.integers(1, 61))
+        kind = int(rng.integers(0, 4))
+        A = rng.standard_normal((n, n))
+        A = A @ A.T + 0.1 * np.eye(n)
+        b = rng.standard_normal(n)
+        bad_every = int(rng.integers(3, 9))
+        x0 = rng.standard_normal(n) * 2.0
+
+        def make():
+            seen = []
+
+            def f(x):
+                seen.append(np.array(x))
+                if kind == 0:
+                    return float(0.5 * x @ A @ x - b @ x), A @ x - b
+                if kind == 1 and n >= 2:
+                    a_, b_ = x[:-1], x[1:]
+                    g = np.zeros_like(x)
+                    g[:-1] += -400.0 * a_ * (b_ - a_ * a_) - 2.0 * (1.0 - a_)
+                    g[1:] += 200.0 * (b_ - a_ * a_)
+                    return float(np.sum(100.0 * (b_ - a_ * a_) ** 2 + (1.0 - a_) ** 2)), g
+                val, g = float(np.sum(np.cosh(x)) + 0.5 * x @ A @ x), np.sinh(x) + A @ x
+                if len(seen) % bad_every == 0:
+                    return (np.finfo(float).max, np.clip(g, -1e10, 1e10)) if kind == 2 else (float("nan"), g)
+                return val, g
+            return f, seen
+        fa, sa = make()
+        fb, sb = make()
+        xa, va, da = fmin_l_bfgs_b(fa, x0, maxfun=budget, maxiter=budget)
+        xb, vb, db = lbfgsb.minimize(fb, x0, maxfun=budget, maxiter=budget)
+        same_f = (va == vb) or (np.isnan(va) and np.isnan(vb))
+        assert np.array_equal(xa, xb, equal_nan=True) and same_f, (case, n, budget, kind)
+        assert (da["funcalls"], da["nit"], da["warnflag"], da["task"]) == (db["funcalls"], db["nit"], db["warnflag"], db["task"]), (case, kind)
+        assert len(sa) == len(sb) and all(np.array_equal(p, q, equal_nan=True) for p, q in zip(sa, sb)), (case, kind)
