@@ -293,7 +293,9 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         # evaluations then share the GPU with the other lane's batch of five -- N = 2048: 126 / 121 ms per fit with a thread per run,
         # 124 / 130 with the run generators; 4096: 592 / 587, 527 / 544; 1024: 47 / 44.  Stream priorities do not rescue it: with the
         # restarts' handle one level down (chain normal / bulk low beside chain high / bulk normal) the sequential pair's evaluations
-        # speed up (N = 2048: 1.31 -> 1.1 ms) and the background lane starves: 124 -> 193 ms per fit, 4096: 539 -> 628)
+        # speed up (N = 2048: 1.31 -> 1.1 ms) and the background lane starves: 124 -> 193 ms per fit, 4096: 539 -> 628.  Nor does a CU
+        # mask on the restarts' handle (6, 5 or 4 of every 8 CUs): the sequential pair's lane gains what the masked lane loses and the
+        # masked lane becomes the longer one -- N = 2048: 115 -> 120 / 131 / 152 ms, 4096: 533 -> 587 / 661 / 780, 1024: 54 -> 45-48)
         per_lane = [[k for k in range(n_slots) if k % n_lanes == j] for j in range(n_lanes)]
         tag = self._level_of(model)
         engines = [model._engine] + [self._engine("%s#%d" % (tag, j)) for j in range(1, n_lanes)]
