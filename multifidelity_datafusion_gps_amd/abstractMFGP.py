@@ -280,7 +280,9 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             return
         own = 1 if rank == 0 else 0
         n_runs = len(mine_bg) + 2 * own
-        width = int(self.lockstep_width) if self.lockstep_width else ((n_runs + 1) // 2 if len(model.X) >= 6144 else max(n_runs - 1, 1))
+        # (a rank without the sequential pair holds runs of equal length: all of them live -- two rounds of B / 2 cost more than one of B)
+        width = int(self.lockstep_width) if self.lockstep_width else (
+            n_runs if not own else ((n_runs + 1) // 2 if len(model.X) >= 6144 else max(n_runs - 1, 1)))
         n_bg_slots = min(len(mine_bg), max(width - own, 1 if mine_bg else 0))
         n_slots = n_bg_slots + own
         # deal the slots to the lanes: lane 0 = the model's own handle (slot 0, the sequential pair, lives there)
