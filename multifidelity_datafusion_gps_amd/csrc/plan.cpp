@@ -521,7 +521,10 @@ static void plan_sweep(Plan& p) {
     // MFMAs per SIMD (5.3 us) behind 8 serial K-steps; as 32x32 tiles (4 waves, 16 KB of LDS, four times the workgroups, four
     // K-steps) the same work spreads over four times as many SIMDs (N = 1024 0.60 -> 0.53 ms, 2048 1.20 -> 1.03, 4096 2.93 -> 2.80).  Chain-bound sizes only: at N >= 6144 the chain hides behind the
     // bulk stream and fewer, larger workgroups disturb it less.
-    const int CT = nb < 48 ? 32 : 64;
+    // A BATCHED pass of three or more sets carries that many times the workgroups per chain launch: from N = 4096 the 64-tiles win
+    // there too (B = 4: 7.17 -> 6.86 ms per pass, B = 6: 10.05 -> 9.71, B = 8: 12.87 -> 12.55; B = 3 level); below they lose (N = 2048,
+    // B = 4: 1.47 -> 1.57; 1024: 0.51 -> 0.57).  The tile edge changes no result bit.
+    const int CT = (nb < 48 && !(p.batch_div >= 3 && nb >= 32)) ? 32 : 64;
     const int chain_role_ct = CT == 32 ? 5 : chain_role;
     p.kinv_streamed = opt(p.opts.kinv_stream, 1) != 0 && p.shard.size <= 1;   // (sharded: K^-1 follows the exchange of the rows of X^T)
     const auto mine = [&](int64_t row) { return shard_owner((int)(row / NB), p.shard.size) == p.shard.rank; };
@@ -816,6 +819,7 @@ void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& o
     p.shard = shard;
     if (shard.size > 1) p.opts.kind = 0;      // a sharded evaluation always runs the sweep
     p.t128_min = std::max(1, (opts.t128_min > 0 ? opts.t128_min : (nblk >= 56 ? 600 : 300)) / std::max(1, t128_div));
+    p.batch_div = std::max(1, t128_div);
     p.nblk = nblk;
     p.ld = ld;
     p.stride = stride;

@@ -89,6 +89,7 @@ struct Plan {
     int predv_rows = 0;
     int n_events = 0;               // events the steps refer to (1-based ids 1..n_events)
     int t128_min = 300;             // tiles per launch from which 128-tiles are used (64-tiles below)
+    int batch_div = 1;              // matrix sets per launch this plan was made for (1: a single evaluation)
     bool kinv_streamed = false;     // the steps accumulate K^-1 behind the chain
     PlanOpts opts;                  // the switches it was planned under
     Shard shard;                    // size > 1: this rank's share of a sharded evaluation (see Shard)

@@ -300,7 +300,8 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
     Sim s;
     s.ld = (int64_t)nblk * NB;
     s.stride = (s.ld + slack) * (s.ld + slack);
-    build_plan(s.p, nblk, s.ld, s.stride, plan_opts_from_env());
+    const char* bdiv = getenv("PLAN_SIM_BATCH_DIV");     // the plan of a BATCHED pass of about that many sets (tile sizes by set class)
+    build_plan(s.p, nblk, s.ld, s.stride, plan_opts_from_env(), bdiv ? atoi(bdiv) : 1);
     if (mutate == 1) {
         for (Step& st : s.p.steps)
             if (st.strm == 1 && st.wait_ev > 0) { st.wait_ev = 0; break; }

@@ -84,6 +84,21 @@ def test_schedules_of_the_bench_sizes_are_race_free(simlib, env):
         assert rc == 0 and rep[4] == 0, (spec, msg)
 
 
+@pytest.mark.parametrize("div", [3, 5, 9])
+def test_batch_plans_are_race_free_and_factorise(simlib, div):
+    """the plan of a BATCHED pass (mfgp_eval_batch: tile sizes chosen for `div` times the workgroups per launch -- 128-tiles sooner,
+    64-tile chain steps from 32 block columns) through the same checker: arithmetic at small block counts, races at the block counts
+    where a batch plan differs from the single one"""
+    env = {"PLAN_SIM_BATCH_DIV": str(div)}
+    specs = [(nb, 1, g, 0, 0) for nb in (3, 8, 13) for g in (0, 1)]
+    for (nb, _, g, _, _), (rc, rep, msg) in zip(specs, _run(simlib, specs, env)):
+        assert rc == 0, (nb, g, msg)
+        assert rep[0] < 1e-14 and rep[1] < 1e-12 and rep[2] == 0.0, (nb, g, rep)
+    specs = [(nb, 0, 1, 0, 0) for nb in (14, 24, 31, 32, 33, 40, 47, 48, 56, 64)]
+    for spec, (rc, rep, msg) in zip(specs, _run(simlib, specs, env)):
+        assert rc == 0 and rep[4] == 0, (spec, msg)
+
+
 def test_the_checker_catches_a_dropped_dependency(simlib):
     ok, no_chain_wait, no_join, no_leaf_wait = _run(simlib, [(16, 0, 1, 0, m) for m in (0, 1, 2, 3)])
     assert ok[0] == 0
