@@ -596,7 +596,8 @@ def main():
         # Rate the GPU delivered on the sweeps over the timed region: several evaluations are in flight at once (the concurrent
         # restarts), so per-launch event times overlap; the aggregate = all sweep flops / timed wall time (conservative: the
         # wall time also holds the K builds, solves, gradient reductions and the predicts).
-        sweep_tf = tot["cholinv_flops"] / dt / 1e12
+        # (with MFGP_KINV_STREAM=0 the K^-1 product is a stand-alone launch counted in kinv_flops: the same Np^3 per evaluation either way)
+        sweep_tf = (tot["cholinv_flops"] + tot["kinv_flops"]) / dt / 1e12
         sweep_tf_launch = _rate(tot["cholinv_flops"], tot["cholinv_ms"]) / 1e12
         sweep_tf_alone = _rate(clf["cholinv_flops"], clf["cholinv_ms"]) / 1e12
         kb_gbs = _rate(tot["kbuild_bytes"], tot["kbuild_ms"]) / 1e9
@@ -712,7 +713,7 @@ def main():
                             "curve itself has not been measured on hardware"}
             except Exception as ex:  # noqa: BLE001 - diagnostic only
                 out["serial_floor_sharded_projection"] = {"error": repr(ex)[:200]}
-        if not streamed:
+        if not streamed and 0 < kinv_tf <= FP64_PEAK_TFLOPS:     # (a batched pass has no stamp around its K^-1 launch: nothing to report then)
             out["roofline_kinv"] = {"kernel": "mfgp_kinv_syrk_f64 (stand-alone K^-1 launch)", "bound": "mfma",
                                     "achieved": round(kinv_tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(kinv_tf / FP64_PEAK_TFLOPS, 4)}

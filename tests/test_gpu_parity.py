@@ -6,7 +6,8 @@ Stated fp64 tolerances (the oracle is "parity unpinned" w.r.t. G
   K entries      abs <= 2e-13 * sigma^2 * (1 + 1/l^2)  (GPy's |x|^2+|x'|^2-2x.x' form loses ~eps|x|^2/l^2; ours does not)
   logdet, NLML   rel <= 1e-10 (noise >= 1e-4 var), <= 1e-7 in the add_noise regime (noise = 1e-6)
   gradient       PER COMPONENT |dg_k| <= 1e-8 * max(|g_k|, 1e-3 |g|_2) (1e-5 in the add_noise regime) -- tests/tolerances.py
-  mean / var     abs <= 1e-9 * max(1, |y|_inf) (1e-6 in the add_noise regime); the variance against BOTH predictive forms of the
+  mean / var     abs <= 1e-9 * max(1, |y|_inf) (add_noise regime: 1e-7 against the quad-precision values, cond-derived against the fp64
+                 oracle -- tests/tolerances.py); the variance against BOTH predictive forms of the
                  oracle: GPy's explicit-inverse form (`predict`: what the reference returns) and the triangular one
   L, alpha only through residuals: |L L^T - Ky|_F / |Ky|_F <= 1e-14 N ; |Ky alpha - y| / |y| <= 1e-12 * cond-ish
 """
@@ -18,6 +19,7 @@ import pytest
 from oracle import gp_oracle as orc
 from tests import cases
 from tests import tolerances as tol
+from tests import truth
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -62,11 +64,21 @@ def test_golden_vectors(engine, name):
     assert np.linalg.norm(L @ L.T - Ky) / np.linalg.norm(Ky) <= 1e-14 * N
     alpha = engine.get_alpha()
     assert np.linalg.norm(Ky @ alpha - g["Y"]) / np.linalg.norm(g["Y"]) <= 1e-11 * (1 if tight else 1e3)
-    tol.check_nlml(nlml, float(g["nlml"]), rel=tol.NLML_REL if tight else tol.NLML_REL_ADDNOISE, label="golden/" + name)
     tol.check_grad(grad, g["grad"], rel=tol.GRAD_REL if tight else tol.GRAD_REL_ADDNOISE, label="golden/" + name)
     ys = np.abs(g["Y"]).max()
-    tol.check_pred(mean, g["mean"], ys, tol.PRED_ABS if tight else 1e-6, label="golden/" + name, what="mean")
-    tol.check_pred(var, g["var"], ys, tol.PRED_ABS if tight else 1e-6, label="golden/" + name, what="var_explicit_inverse")
+    if tight:
+        tol.check_nlml(nlml, float(g["nlml"]), label="golden/" + name)
+        tol.check_pred(mean, g["mean"], ys, label="golden/" + name, what="mean")
+        tol.check_pred(var, g["var"], ys, label="golden/" + name, what="var_explicit_inverse")
+    else:
+        # add_noise regime: the committed vector is the fp64 oracle's (explicit-inverse variance, GPy's form) -- a second ROUNDED
+        # evaluation: tolerances derived from cond(Ky) -- and the stated 1e-7 figures are asserted against the quad-precision values
+        cond = tol.cond_bound(g["K"], noise)
+        tol.check_nlml(nlml, float(g["nlml"]), rel=tol.fp64_pair_nlml_rel(cond), label="golden/" + name)
+        tol.check_pred(mean, g["mean"], 1.0, tol.fp64_pair_pred_abs(cond, ys), label="golden/" + name, what="mean")
+        tol.check_pred(var, g["var"], 1.0, tol.explicit_inverse_bound(cond, vmax, ys, base=tol.PRED_ABS_ADDNOISE),
+                       label="golden/" + name, what="var_explicit_inverse")
+        truth.check_add_noise_state("golden_vs_quad/" + name, parts, theta, noise, g["X"], g["Y"], g["Xs"], nlml, mean, var)
 
 
 @pytest.mark.parametrize("name", cases.MID_GOLDEN_CASES)
@@ -110,9 +122,9 @@ def _extended_precision_variance(K, noise, Kx, kss):
 
 def test_add_noise_regime_against_both_predictive_forms(engine):
     """sigma_n^2 = 1e-6 (what MultifidelityDataFusion.predict installs with add_noise=True, src/MFDataFusion.py:154-155):
-    the stated tolerance (1e-6 max(1, |y|)) must cover the distance to what the REFERENCE returns -- GPy's explicit-inverse
-    form, oracle `predict` -- and not only to the better-conditioned triangular form the other tests compare with
-    (`predict_stable`).  An extended-precision evaluation says which of the three is closest to the exact value."""
+    the distance to what the REFERENCE returns -- GPy's explicit-inverse form, oracle `predict` -- must stay within that form's own
+    error bound (tolerances.explicit_inverse_bound), and the distance to the better-conditioned triangular form (`predict_stable`)
+    within the fp64 pair bound; the stated 1e-7 is asserted against the extended-precision value.  An extended-precision evaluation says which of the three is closest to the exact value."""
     g = np.load(os.path.join(GOLD, "rbf_addnoise_n60.npz"))
     parts = [tuple(int(v) for v in p) for p in g["parts"]]
     theta, noise = g["theta"], float(g["noise"])
@@ -123,16 +135,21 @@ def test_add_noise_regime_against_both_predictive_forms(engine):
     st = orc.inference(parts, theta, noise, g["X"], g["Y"], want_grad=False)
     mu_e, var_e = orc.predict(parts, theta, noise, g["X"], st, g["Xs"], include_noise=False)           # GPy's form
     mu_s, var_s = orc.predict_stable(parts, theta, noise, g["X"], st, g["Xs"], include_noise=False)    # triangular form
-    tol = 1e-6 * max(1.0, np.abs(g["Y"]).max())
-    np.testing.assert_allclose(mean, mu_e, rtol=0, atol=tol)
-    np.testing.assert_allclose(var, np.maximum(var_e, 1e-15), rtol=0, atol=tol)      # vs what the reference returns
-    np.testing.assert_allclose(var, var_s, rtol=0, atol=tol)
+    ys = max(1.0, np.abs(g["Y"]).max())
+    cond = tol.cond_bound(st["K"], noise)
+    kss = orc.cov_diag(parts, theta, 1)[0]
+    pair = tol.fp64_pair_pred_abs(cond, ys)                  # two fp64 evaluations: c eps cond(Ky), tests/tolerances.py
+    np.testing.assert_allclose(mean, mu_e, rtol=0, atol=pair)
+    np.testing.assert_allclose(var, np.maximum(var_e, 1e-15), rtol=0,                # vs what the reference returns
+                               atol=tol.explicit_inverse_bound(cond, kss, ys, base=tol.PRED_ABS_ADDNOISE))
+    np.testing.assert_allclose(var, var_s, rtol=0, atol=pair)
     exact = np.maximum(_extended_precision_variance(st["K"], noise, orc.cov(parts, theta, g["X"], g["Xs"]),
                                                     orc.cov_diag(parts, theta, 1)[0]), 1e-15)
     d_hip, d_gpy, d_tri = (np.abs(v - exact).max() for v in (var, np.maximum(var_e, 1e-15), var_s))
     print("add_noise regime, max |var - extended precision|: HIP %.2e, explicit inverse (GPy form) %.2e, triangular %.2e"
           % (d_hip, d_gpy, d_tri))
-    assert d_hip <= tol and d_hip <= 10 * max(d_gpy, d_tri, 1e-14)    # the HIP path is not the outlier of the three
+    # the STATED add_noise tolerance, against the (extended-precision) value -- and the HIP path is not the outlier of the three
+    assert d_hip <= tol.PRED_ABS_ADDNOISE * ys and d_hip <= 10 * max(d_gpy, d_tri, 1e-14)
 
 
 def test_kinv_and_state_machine(engine):

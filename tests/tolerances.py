@@ -8,7 +8,11 @@ Normal-noise regime (sigma_n^2 >= 1e-4 sigma^2):
                      every component is a sum of N^2 terms of the size of the largest one)
     mean, variance  abs <= 1e-9 * max(1, |y|_inf)
 add_noise regime (sigma_n^2 = 1e-6, src/MFDataFusion.py:154-155; cond(Ky) ~ 1e9 .. 1e10):
-    NLML rel <= 1e-7, mean / variance abs <= 1e-7 * max(1, |y|_inf)  [SURVEY 8(c)]; gradient 1e-5 per component
+    NLML rel <= 1e-7, mean / variance abs <= 1e-7 * max(1, |y|_inf)  [SURVEY 8(c)]; gradient 1e-5 per component.
+    These are asserted on the HIP outputs against the QUAD-PRECISION values (oracle/quad_truth.c) wherever N <= 4096.  A comparison
+    of the HIP outputs with the fp64 oracle in this regime is a comparison of TWO rounded evaluations, each of which carries
+    O(eps * cond): its tolerance is derived from the case's cond(Ky) bound (`fp64_pair_nlml_rel`, `fp64_pair_pred_abs`,
+    `explicit_inverse_bound`), never a bare figure -- what such an assert protects is the ORACLE's rounding, not the product's.
 """
 import atexit
 import json
@@ -55,6 +59,26 @@ def cond_factor(cond):
     """factor on the normal-noise tolerances for a case whose cond(Ky) bound is `cond`: two backward-stable fp64 evaluations of
     the same quantity differ by O(eps * cond); 1e-9 is that figure at cond ~ 1e7"""
     return float(np.clip(cond / COND_KNEE, 1.0, COND_CAP))
+
+
+def fp64_pair_nlml_rel(cond):
+    """relative NLML tolerance between TWO fp64 evaluations (the HIP engine and the numpy/LAPACK oracle) of a case whose cond(Ky)
+    bound is `cond`: each of them is within (NLML_COND_C / 3) * eps * cond of the true value at worst (measured, see NLML_COND_C),
+    so the pair may differ by twice that; asserted at 3 x, like every measured line here: 2 * NLML_COND_C * eps * cond, never below
+    the stated 1e-10 and -- unlike `nlml_rel`, which bounds the distance to the TRUE value -- not capped at the regime's figure:
+    at N = 8192, sigma_n^2 = 1e-6 (cond bound ~ 7e9) the host LAPACK run alone is 0.9e-7 from the HIP value while an appended and
+    a fresh HIP factorisation agree to 1e-9 (round 3, cfg5 at size)"""
+    return float(max(NLML_REL, 2.0 * NLML_COND_C * np.finfo(np.float64).eps * float(cond)))
+
+
+PAIR_PRED_C = PRED_ABS / (np.finfo(np.float64).eps * COND_KNEE)     # = 0.45: the stated 1e-9 read as c * eps * cond at the knee cond = 1e7
+
+
+def fp64_pair_pred_abs(cond, y_scale=1.0):
+    """absolute mean / triangular-variance tolerance between TWO fp64 evaluations of a case whose cond(Ky) bound is `cond`: the line
+    through SURVEY 8(c)'s two regimes (1e-9 at cond 1e7, 1e-7 at 1e9) continued -- PAIR_PRED_C * eps * cond * max(1, |y|_inf), never
+    below the stated 1e-9 and with no cap (cf. `cond_factor`, the same line capped at 1e-6 for the distance to the true value)"""
+    return float(max(PRED_ABS, PAIR_PRED_C * np.finfo(np.float64).eps * float(cond)) * max(1.0, float(y_scale)))
 
 
 EXPLICIT_INVERSE_C = 12.3

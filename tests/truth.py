@@ -91,3 +91,47 @@ def check_against_truth(label, case, tr, nlml=None, grad=None, mean=None, var=No
         assert err <= bound, (err, bound)
     tol._record(label, "cond_factor", cf)
     return cf
+
+
+QUAD_MAX_ROWS = 4096      # quad-precision Cholesky: 2 s at 1024 rows, 25 s at 4096, 194 s at 8192 (16 threads)
+
+
+def check_add_noise_state(label, parts, theta, noise, X, Y, Xs, nlml, mean, var, jitter=1e-8, quad_rows=256):
+    """One fitted / appended state in the add_noise regime (sigma_n^2 = 1e-6, src/MFDataFusion.py:154-155) -- `nlml`, `mean`, `var`
+    (noise INCLUDED, as MultifidelityDataFusion.predict returns it) from the HIP path at (parts, theta, noise) on the rows (X, Y):
+
+      (1) against the QUAD-PRECISION values at the STATED add_noise tolerances (NLML rel 1e-7, mean / variance
+          1e-7 max(1, |y|_inf)) wherever N <= QUAD_MAX_ROWS (on the first `quad_rows` test rows: N^2 quad flops per row);
+      (2) against the fp64 oracle -- BOTH predictive forms: the triangular one and GPy's explicit inverse, which is what
+          src/MFDataFusion.py:156 returns -- at tolerances DERIVED from the case's cond(Ky) bound (tests/tolerances.py:
+          fp64_pair_nlml_rel, fp64_pair_pred_abs, explicit_inverse_bound): two rounded evaluations, each carrying O(eps cond).
+    Returns the oracle state."""
+    from oracle import gp_oracle as orc
+    Y = np.asarray(Y, dtype=np.float64).reshape(-1)
+    mean, var = np.asarray(mean).reshape(-1), np.asarray(var).reshape(-1)
+    ys = max(1.0, float(np.abs(Y).max()))
+    st = orc.inference(parts, theta, noise, X, Y, want_grad=False, const_jitter=jitter)
+    cond = tol.cond_bound(st["K"], noise, jitter)
+    kss = float(orc.cov_diag(parts, theta, 1)[0])
+    mu, v_inv = orc.predict(parts, theta, noise, X, st, Xs)
+    _, v_tri = orc.predict_stable(parts, theta, noise, X, st, Xs)
+    tol.check_nlml(nlml, st["nlml"], rel=tol.fp64_pair_nlml_rel(cond), label=label)
+    tol.check_pred(mean, mu, 1.0, tol.fp64_pair_pred_abs(cond, ys), label=label, what="mean_vs_fp64_oracle")
+    tol.check_pred(var, v_tri, 1.0, tol.fp64_pair_pred_abs(cond, ys), label=label, what="var_vs_fp64_triangular")
+    tol.check_pred(var, v_inv, 1.0, tol.explicit_inverse_bound(cond, kss, ys, base=tol.PRED_ABS_ADDNOISE), label=label,
+                   what="var_vs_fp64_explicit_inverse")
+    tol._record(label, "cond_bound", cond)
+    tol._record(label, "nlml_pair_err_over_eps_cond", abs(nlml - st["nlml"]) / abs(st["nlml"]) / (np.finfo(float).eps * cond))
+    tol._record(label, "mean_pair_err_over_eps_cond", np.abs(mean - mu).max() / ys / (np.finfo(float).eps * cond))
+    if X.shape[0] <= QUAD_MAX_ROWS:
+        from oracle import quad_truth
+        q = slice(0, min(quad_rows, len(mean)))
+        tr = quad_truth.evaluate(parts, theta, noise, X, Y, np.ascontiguousarray(Xs[q]), jitter=jitter, want_grad=False)
+        scale = max(abs(tr["nlml"]), 0.5 * (X.shape[0] * np.log(2 * np.pi) + abs(tr["logdet"])))
+        err = abs(nlml - tr["nlml"]) / scale
+        tol._record(label, "nlml_vs_quad_over_1e-7", err / tol.NLML_REL_ADDNOISE)
+        assert err <= tol.NLML_REL_ADDNOISE, (nlml, tr["nlml"], err)
+        tol.check_pred(mean[q], tr["mean"], ys, tol.PRED_ABS_ADDNOISE, label=label, what="mean_vs_quad")
+        tol.check_pred(np.maximum(var[q] - noise, 1e-15), np.maximum(tr["var"], 1e-15), ys, tol.PRED_ABS_ADDNOISE, label=label,
+                       what="var_vs_quad")
+    return st
