@@ -92,6 +92,14 @@ def one_step(args, comm, engines, data):
     # the sequential pieces of the job: the LF run, rank 0's first HF run -> restart 0, the predict
     chain_evals = sum(r.n_evals for r in model.hf_model.optimization_runs if not r.background)
     model.phase = {"lf_ms": (t1 - t0) * 1e3, "fit_ms": (t2 - t1) * 1e3, "predict_ms": (t3 - t2) * 1e3, "chain_evals": chain_evals}
+    # what the timed workload's own fit did: a jitter retry is a whole extra evaluation -- it would silently change
+    # the evaluation count the value is quoted on -- and the fitted noise variances say how ill-conditioned the timed factorisations are
+    lf_m = getattr(model, "lf_model", None)
+    model.phase["jitter_retries"] = int(model.hf_model.n_jitter_retries + (lf_m.n_jitter_retries if lf_m is not None else 0))
+    model.phase["failed_evaluations"] = int(model.hf_model.n_failed_evals + (lf_m.n_failed_evals if lf_m is not None else 0))
+    model.phase["fitted_noise_variance"] = {"hf": float(model.hf_model.likelihood.variance.value),
+                                            "lf": float(lf_m.likelihood.variance.value) if lf_m is not None else None}
+    model.phase["fit_driver"] = model.last_fit_info
     lanes = getattr(model, "last_lockstep_lanes", None)
     if lanes:
         model.phase["lockstep"] = [{"rounds": ls.rounds, "evaluations": ls.evals, "engine_ms": round(ls.engine_s * 1e3, 1),
@@ -367,6 +375,7 @@ def stop_power_watch(proc, wall0, wall1):
                     "a bare v_mfma_f64_4x4x4_4b loop holds 71 TFLOP/s at 2.40 GHz and ~1130 W (profiles/r03_sustained_mfma_probe.json)"}
 
 
+EXIT_JITTER_RETRIES = 5   # the timed steps repeated an evaluation with more jitter: the workload's evaluation count did not hold
 EXIT_PEER_LOST = 4    # a rank whose peer vanished mid-collective (the launcher reports the rank that vanished, not this one)
 
 
@@ -465,6 +474,8 @@ def main():
     ap.add_argument("--power", action="store_true", help="sample socket power / sclk beside the timed region (a child process; "
                                                          "off by default: it costs host CPU beside the optimiser threads; never under a profiler)")
     ap.add_argument("--no-power", action="store_true", help="(accepted for old command lines; power sampling is off unless --power)")
+    ap.add_argument("--allow-jitter-retries", action="store_true",
+                    help="print the line even if a timed step repeated an evaluation with more jitter (the default refuses: exit 5)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0; RCCL is made to accept that by giving every rank its own "
                          "NCCL_HOSTID (a real N-rank communicator over RCCL's socket transport on loopback)")
@@ -557,6 +568,13 @@ def main():
         phases.append(model.phase)
     barrier()
     dt = max(comm.allgather_object(time.perf_counter() - t0))     # max over ranks
+    retries = sum(comm.allgather_object(sum(p["jitter_retries"] for p in phases)))      # (collective: every rank takes the same exit)
+    if retries and not args.allow_jitter_retries:
+        sys.stderr.write("bench.py: rank %d: the timed steps saw %d jitter retries (Ky not positive definite at a point the optimiser "
+                         "visited): the evaluation count the value is quoted on would not be the workload's -- no line printed "
+                         "(--allow-jitter-retries to report anyway)\n" % (rank, retries))
+        sys.stderr.flush()
+        os._exit(EXIT_JITTER_RETRIES)
     wall1 = time.time()
     power = stop_power_watch(power_proc, wall0, wall1) if power_proc is not None else None
     ms_per_step = dt * 1e3 / args.steps
@@ -627,6 +645,9 @@ def main():
                                           else "concurrent restarts on %d auxiliary handles (round 3's mode; the default is lock step "
                                                "over batched evaluations)" % max(args.concurrency, 2),
                        "restart_concurrency": None if lockstep else max(args.concurrency, 2), "collectives": collectives,
+                       "fit_driver": phases[-1].get("fit_driver"), "jitter_retries_in_timed_steps": retries,
+                       "failed_evaluations_in_timed_steps": sum(p["failed_evaluations"] for p in phases),
+                       "fitted_noise_variance": phases[-1]["fitted_noise_variance"],
                        "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
                        "sharding": sharding_note(world, args.restarts, int(engines["lf"].comm_size))},

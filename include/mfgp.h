@@ -10,7 +10,8 @@
  *
  * Conventions
  *   - every function returns int32 status: 0 = OK; >0 = LAPACK-style info (1-based index of the first
- *     non-positive pivot met by the Cholesky); <0 = argument / HIP error (text via mfgp_last_error).
+ *     non-positive pivot met by the Cholesky); <0 = error (text via mfgp_last_error): -1 argument / state, -2 HIP,
+ *     -4 RCCL, MFGP_ERR_OOM (-6) a batch slab the device cannot hold (the handle stays usable: see mfgp_eval_batch).
  *   - all matrices are row-major (C order) fp64, caller-owned HOST buffers unless a name says "dev";
  *     the library copies what it needs and owns every device allocation behind the opaque handle.
  *   - hyper-parameters cross the boundary in natural units (variance, lengthscale, noise variance);
@@ -28,6 +29,8 @@ extern "C" {
 #endif
 
 typedef struct mfgp_handle mfgp_handle;
+
+#define MFGP_ERR_OOM (-6)
 
 /* kernel-part types: GPy.kern.RBF / Matern32 / Matern52 (src/abstractMFGP.py:60, :62 kern_class1..3) */
 enum { MFGP_KERN_RBF = 0, MFGP_KERN_MATERN32 = 1, MFGP_KERN_MATERN52 = 2 };
@@ -135,17 +138,29 @@ int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitt
  * undefined; the others are unaffected).  The return value covers the call as a whole (0, or < 0 for an argument / HIP error).
  * One pass of the factorisation plan carries the B matrix sets side by side (1 <= B <= 16; 4 Np^2 doubles of device memory
  * per set, kept by the handle), each evaluation's arithmetic is mfgp_eval's tile for tile: results are bitwise those of B
- * mfgp_eval calls.  The handle's own factorisation (what mfgp_predict / mfgp_nlml read) is left untouched. */
+ * mfgp_eval calls.  The handle's own factorisation (what mfgp_predict / mfgp_nlml read) is left untouched.
+ * Memory: a request whose sets do not fit -- hipMalloc says so, or they exceed the environment's MFGP_BATCH_MEM_CAP (bytes per
+ * handle) -- returns MFGP_ERR_OOM and changes nothing: the sets the handle already held stay, every other call works; the caller
+ * retries with fewer sets, or with mfgp_eval, which needs none (the host layer does: same results bit for bit, only slower).
+ * mfgp_mem_info: free / total bytes of the handle's device (hipMemGetInfo).  mfgp_batch_mem: the bytes `sets` sets would take on
+ * this handle at its current capacity, MFGP_BATCH_MEM_CAP (0: none) and the number of sets it holds -- what a caller sizes its
+ * batches from BEFORE asking. */
 int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const double* noises, const double* jitters,
                         int32_t want_grad, double* nlml, double* grads, int32_t* status);
+int32_t mfgp_mem_info(mfgp_handle* h, int64_t* free_bytes, int64_t* total_bytes);
+int32_t mfgp_batch_mem(mfgp_handle* h, int32_t sets, int64_t* bytes, int64_t* cap_bytes, int32_t* sets_held);
 
-/* Row-block form of the K build for the multi-GPU layout of SURVEY 8(e3) / north_star: each rank builds rows
- * [row_begin, row_end) (multiples of 64, within the padded size) of Ky = K + (noise+jitter) I -- all columns --
- * in place in the device matrix, the ranks all-gather their blocks (mfgp_allgather_rows: RCCL inside the library;
- * or any other transport through mfgp_rows_download / mfgp_rows_upload or the pointer mfgp_dev_matrix returns), then
- * mfgp_eval_prebuilt factorises what is there instead of building K itself.  Same arithmetic as mfgp_eval. */
+/* Row-block form of the K build for the multi-GPU layout of SURVEY 8(e3) / north_star: each rank builds its row blocks of
+ * Ky = K + (noise+jitter) I -- all columns -- in place in the device matrix, the ranks all-gather their blocks
+ * (mfgp_allgather_rows: RCCL inside the library; or any other transport through mfgp_rows_download / mfgp_rows_upload or the
+ * pointer mfgp_dev_matrix returns), then mfgp_eval_prebuilt factorises what is there instead of building K itself.  Same
+ * arithmetic as mfgp_eval.  mfgp_kbuild_rows: rows [row_begin, row_end) (multiples of 64, within the padded size);
+ * mfgp_kbuild_owned_rows: the rows of every 128-row block b with mfgp_row_block_owner(b, size) == rank -- the serpentine
+ * block-cyclic deal 0 1 .. G-1 G-1 .. 1 0 .. under which every rank's blocks hold the same share of the lower triangle. */
 int32_t mfgp_kbuild_rows(mfgp_handle* h, const double* theta, double noise, double jitter, int64_t row_begin,
                          int64_t row_end);
+int32_t mfgp_kbuild_owned_rows(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t rank, int32_t size);
+int32_t mfgp_row_block_owner(int32_t block, int32_t size);
 int32_t mfgp_dev_matrix(mfgp_handle* h, void** dev_ptr, int64_t* padded_n); /* Np x Np fp64, row-major, ld = Np */
 int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, double* grad);
 
@@ -154,8 +169,10 @@ int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, doub
  * mfgp_comm_unique_id: 128 opaque bytes (ncclUniqueId), produced on rank 0 and carried to the other ranks by the
  *   host side's own rendezvous; mfgp_comm_init: collective over all ranks, binds a communicator to the handle
  *   (its device, its stream); librccl is loaded lazily by these two calls only.
- * mfgp_allgather_rows: after every rank has run mfgp_kbuild_rows on its block [rank*Np/size, (rank+1)*Np/size),
- *   ONE in-place ncclAllGather on the device matrix completes Ky on every rank (8 Np^2/size bytes per rank).
+ * mfgp_allgather_rows: after every rank has run mfgp_kbuild_owned_rows(.., rank, size) with the communicator's rank and size,
+ *   the LOWER part of every block (128 x 128 (b + 1) doubles: all the factorisation reads) is packed by owner and ONE in-place
+ *   ncclAllGather of equal chunks completes the lower triangle of Ky on every rank -- 4 Np (Np + 128) / size bytes per rank,
+ *   half of what full rows would move; the part of a foreign block right of its diagonal block is left as it was.
  * mfgp_allgather_host: recv[rank*count .. ) = send of that rank, for the small results that shard by rows
  *   (predictive mean / variance of hf_model.predict(X*), src/MFDataFusion.py:156: 16 B per test row).
  * mfgp_rows_download / mfgp_rows_upload: the same row blocks of the device matrix through host memory, for
@@ -163,6 +180,11 @@ int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, doub
 int32_t mfgp_comm_unique_id(uint8_t* out128);
 int32_t mfgp_comm_init(mfgp_handle* h, const uint8_t* id128, int32_t rank, int32_t size);
 int32_t mfgp_comm_destroy(mfgp_handle* h);
+/* mfgp_comm_state: 0 = no communicator, n > 0 = a live one of n ranks, -1 = ABORTED: a rank whose sharded pass failed after the group
+ *   had been told to start it (or whose peers went silent for MFGP_SHARD_TIMEOUT_S, default 600 s) tears its communicator down
+ *   without them (ncclCommAbort) instead of issuing collectives nobody will match; every further collective call on the handle
+ *   returns -4 and the process is expected to END with an error, so that its launcher stops the peers. */
+int32_t mfgp_comm_state(mfgp_handle* h);
 int32_t mfgp_allgather_rows(mfgp_handle* h);
 int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, double* recv);
 /* mfgp_eval_sharded: mfgp_eval as ONE evaluation across the ranks of the handle's communicator (collective: every rank calls it
@@ -248,6 +270,8 @@ int32_t mfgp_dbg_gemm_nt(mfgp_handle* h, const double* A, const double* B, doubl
 int32_t mfgp_dbg_eval_as_rank(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, int32_t rank,
                               int32_t size, double* ms);
 /* Cholesky + inverse of one SPD 128x128 block through the leaf kernel: Lout, Xout are 128x128. */
+/* test hook: the n-th sharded pass from now (leader or follower form) fails on THIS rank after the control exchange (0: off) */
+int32_t mfgp_dbg_fail_sharded_after(mfgp_handle* h, int32_t n);
 int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xout, double* logdet_half);
 #ifdef __cplusplus
 }

@@ -25,14 +25,22 @@ def num_params(parts):
 # every symbol include/mfgp.h declares (tests check the .so exports each of them)
 EXPORTED_SYMBOLS = [
     "mfgp_create", "mfgp_destroy", "mfgp_last_error", "mfgp_device_info", "mfgp_build_id", "mfgp_set_data",
-    "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_eval_batch", "mfgp_eval_sharded", "mfgp_sharded_lead", "mfgp_sharded_serve", "mfgp_sharded_release", "mfgp_kbuild_rows", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
+    "mfgp_set_kernel", "mfgp_num_params", "mfgp_eval", "mfgp_eval_batch", "mfgp_mem_info", "mfgp_batch_mem", "mfgp_eval_sharded", "mfgp_sharded_lead", "mfgp_sharded_serve", "mfgp_sharded_release", "mfgp_kbuild_rows", "mfgp_kbuild_owned_rows", "mfgp_row_block_owner", "mfgp_dev_matrix", "mfgp_eval_prebuilt", "mfgp_factorize", "mfgp_nlml", "mfgp_nlml_grad", "mfgp_append_row", "mfgp_predict",
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters", "mfgp_device_synchronize",
-    "mfgp_comm_unique_id", "mfgp_comm_init", "mfgp_comm_destroy", "mfgp_allgather_rows", "mfgp_allgather_host",
+    "mfgp_comm_unique_id", "mfgp_comm_init", "mfgp_comm_destroy", "mfgp_comm_state", "mfgp_allgather_rows", "mfgp_allgather_host",
     "mfgp_rows_download", "mfgp_rows_upload",
-    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_eval_as_rank",
+    "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_eval_as_rank", "mfgp_dbg_fail_sharded_after",
 ]
+
+
+ERR_OOM = -6      # MFGP_ERR_OOM (include/mfgp.h)
+
+
+class EngineOutOfMemory(RuntimeError):
+    """mfgp_eval_batch: the batch's matrix sets do not fit the device (or MFGP_BATCH_MEM_CAP).  The handle is unchanged and usable:
+    retry with fewer sets, or with eval(), which needs none (engine.LockstepLane does)."""
 
 
 class EngineUnavailable(RuntimeError):
@@ -110,12 +118,16 @@ def load_library(path=None):
         "mfgp_num_params": (i32, [ctypes.POINTER(KernPart), i32]),
         "mfgp_eval": (i32, [H, dp, f64, f64, i32, dp, dp]),
         "mfgp_eval_batch": (i32, [H, i32, dp, dp, dp, i32, dp, dp, ctypes.POINTER(i32)]),
+        "mfgp_mem_info": (i32, [H, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
+        "mfgp_batch_mem": (i32, [H, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32)]),
         "mfgp_eval_sharded": (i32, [H, dp, f64, f64, i32, dp, dp]),
         "mfgp_dbg_eval_as_rank": (i32, [H, dp, f64, f64, i32, i32, i32, dp]),
         "mfgp_sharded_lead": (i32, [H, dp, f64, f64, i32, dp, dp]),
         "mfgp_sharded_serve": (i32, [H, ctypes.POINTER(i64)]),
         "mfgp_sharded_release": (i32, [H]),
         "mfgp_kbuild_rows": (i32, [H, dp, f64, f64, i64, i64]),
+        "mfgp_kbuild_owned_rows": (i32, [H, dp, f64, f64, i32, i32]),
+        "mfgp_row_block_owner": (i32, [i32, i32]),
         "mfgp_dev_matrix": (i32, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(i64)]),
         "mfgp_eval_prebuilt": (i32, [H, i32, dp, dp]),
         "mfgp_factorize": (i32, [H, dp, f64, f64]),
@@ -136,6 +148,8 @@ def load_library(path=None):
         "mfgp_comm_unique_id": (i32, [ctypes.POINTER(ctypes.c_uint8)]),
         "mfgp_comm_init": (i32, [H, ctypes.POINTER(ctypes.c_uint8), i32, i32]),
         "mfgp_comm_destroy": (i32, [H]),
+        "mfgp_comm_state": (i32, [H]),
+        "mfgp_dbg_fail_sharded_after": (i32, [H, i32]),
         "mfgp_allgather_rows": (i32, [H]),
         "mfgp_allgather_host": (i32, [H, dp, i64, dp]),
         "mfgp_rows_download": (i32, [H, i64, i64, dp]),
@@ -229,6 +243,8 @@ class Engine:
         msg = self._lib.mfgp_last_error(self._h).decode()
         if rc > 0:
             raise NotPositiveDefinite(rc, "%s: %s" % (who, msg))
+        if rc == ERR_OOM:
+            raise EngineOutOfMemory("%s: %s" % (who, msg))
         raise RuntimeError("%s failed (%d): %s" % (who, rc, msg))
 
     @property
@@ -321,6 +337,28 @@ class Engine:
         self._check(rc, "mfgp_eval_batch")
         return nlml, grads, status
 
+    def mem_info(self):
+        """(free, total) bytes of the handle's device"""
+        f, t = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.mfgp_mem_info(self._h, ctypes.byref(f), ctypes.byref(t)), "mfgp_mem_info")
+        return f.value, t.value
+
+    def batch_mem(self, sets):
+        """(bytes `sets` matrix sets of a batch take on this handle, MFGP_BATCH_MEM_CAP or 0, sets the handle holds already)"""
+        b, c, held = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        self._check(self._lib.mfgp_batch_mem(self._h, int(sets), ctypes.byref(b), ctypes.byref(c), ctypes.byref(held)), "mfgp_batch_mem")
+        return b.value, c.value, held.value
+
+    def batch_sets_that_fit(self, reserve_bytes=0):
+        """how many matrix sets a batch on this handle may hold: by the free device memory (less `reserve_bytes`, plus what the handle's
+        batch slab holds already) and by MFGP_BATCH_MEM_CAP; at most MAX_BATCH"""
+        per, cap, held = self.batch_mem(1)
+        free, _ = self.mem_info()
+        fit = max(0, free - int(reserve_bytes)) // per + held
+        if cap:
+            fit = min(fit, cap // per)
+        return int(min(fit, self.MAX_BATCH))
+
     # -- row-block K build + all-gather (multi-GPU layout of SURVEY 8(e3)) ---------------------------
     def _theta(self, theta):
         theta = _c64(theta).reshape(-1)
@@ -332,6 +370,17 @@ class Engine:
         theta = self._theta(theta)
         self._check(self._lib.mfgp_kbuild_rows(self._h, _dptr(theta), float(noise), float(jitter), int(row_begin),
                                                int(row_end)), "mfgp_kbuild_rows")
+
+    def kbuild_owned_rows(self, theta, noise, jitter, rank, size):
+        """the rows of every 128-row block rank `rank` of `size` owns (row_block_owner): what a rank builds before allgather_rows"""
+        theta = self._theta(theta)
+        self._check(self._lib.mfgp_kbuild_owned_rows(self._h, _dptr(theta), float(noise), float(jitter), int(rank), int(size)),
+                    "mfgp_kbuild_owned_rows")
+
+    @staticmethod
+    def row_block_owner(block, size):
+        """owner of 128-row block `block` among `size` ranks: serpentine block-cyclic (0 1 .. G-1 G-1 .. 1 0 ..)"""
+        return int(load_library().mfgp_row_block_owner(int(block), int(size)))
 
     def dev_matrix(self):
         """(device pointer, padded size Np) of the Np x Np fp64 matrix the factorisation consumes"""
@@ -361,8 +410,18 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.mfgp_comm_destroy(self._h), "mfgp_comm_destroy")
 
+    @property
+    def comm_aborted(self):
+        """the handle's communicator was torn down after a failed / unmatched collective: no further collective may be issued on it
+        and the process should end with an error (mfgp_comm_state == -1)"""
+        return self._h is not None and int(self._lib.mfgp_comm_state(self._h)) < 0
+
+    def dbg_fail_sharded_after(self, n):
+        self._check(self._lib.mfgp_dbg_fail_sharded_after(self._h, int(n)), "mfgp_dbg_fail_sharded_after")
+
     def allgather_rows(self):
-        """in-place RCCL all-gather of the ranks' row blocks of the device matrix (after kbuild_rows)"""
+        """RCCL all-gather of the ranks' 128-row blocks of the device matrix (after kbuild_owned_rows with the communicator's rank and
+        size): the lower part of every block, packed by owner -- half the bytes of full rows"""
         self._check(self._lib.mfgp_allgather_rows(self._h), "mfgp_allgather_rows")
 
     def allgather_host(self, send):

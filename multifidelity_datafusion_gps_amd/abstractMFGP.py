@@ -59,6 +59,8 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     shard_sequential = True     # multi-GPU: the fit's SEQUENTIAL evaluations -- the low-fidelity run (all ranks would idle through it)
                                 # and first run -> restart 0 (beside the ranks that were dealt no restart) -- are shared by a group
                                 # of ranks (mfgp_eval_sharded: same numbers bit for bit, the rows of L^-T / K^-1 split); needs RCCL
+    last_fit_info = None        # how the last fit's runs were driven: driver (lbfgsb-generators / thread-per-run / sequential), lanes, matrix
+                                # sets per batched pass per lane (sized from the device's free memory), out-of-memory fallbacks taken
     lockstep_threads = False    # True: the lock-stepped runs as one THREAD each on scipy's blocking fmin_l_bfgs_b (the form that does not
                                 # need scipy's private L-BFGS-B core; taken by itself when that core cannot be driven by reverse
                                 # communication -- lbfgsb.available()); False: one loop per lane over run generators (same runs, same steps)
@@ -244,6 +246,8 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         if batched and lock:
             self._ard_lockstep(model, num_restarts)
             return
+        self.last_fit_info = {"driver": "sequential (the reference's call order)" if int(self.restart_concurrency) <= 1
+                              else "concurrent restarts on auxiliary handles", "lanes": 1, "sets_per_pass": [0], "oom_fallbacks": []}
         if int(self.restart_concurrency) <= 1:
             model.optimize(max_iters=self.first_run_max_iters)
             self._free_noise(model)
@@ -291,6 +295,11 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         # one's idle phases: 1024: 49 / 44, 2048: 141 / 130, 4096: 586 / 544; at N = 8192 one lane measured 1 % ahead)
         want_lanes = int(self.lockstep_lanes) if self.lockstep_lanes else (2 if 768 <= len(model.X) < 6144 else 1)
         n_lanes = max(1, min(want_lanes, n_slots))
+        # memory policy (round 5): a further lane is a further handle with a slab of its own (one matrix set: 32 Np^2 bytes) -- only
+        # where the device has room for it beside the batches
+        per_set, free0 = self._device_memory(model._engine)
+        if per_set and n_lanes > 1 and free0 - self.memory_reserve(model._engine) < (n_lanes - 1 + n_slots) * per_set:
+            n_lanes = 1
         # (round-robin; giving lane 0 the sequential pair ALONE was measured twice and is within the run-to-run spread: its single
         # evaluations then share the GPU with the other lane's batch of five -- N = 2048: 126 / 121 ms per fit with a thread per run,
         # 124 / 130 with the run generators; 4096: 592 / 587, 527 / 544; 1024: 47 / 44.  Stream priorities do not rescue it: with the
@@ -304,9 +313,17 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
         for e in engines[1:]:
             e.set_data(model.X, model.Y[:, 0])
             e.set_kernel(model._parts)
+        # ... and a lane's passes carry as many sets as fit (the lanes share what is free; a lane that gets fewer sets than it has
+        # slots runs its rounds in chunks, one that gets none evaluates request by request on its handle's own slab -- the same
+        # steps, the same fit, bit for bit: LockstepLane)
+        budgets = self._lane_budgets(engines, [len(sl) for sl in per_lane])
+        self.last_fit_info = {"driver": "lbfgsb-generators", "lanes": n_lanes, "slots_per_lane": [len(sl) for sl in per_lane],
+                              "sets_per_pass": budgets, "oom_fallbacks": []}
         if gp._lbfgsb.available() and not self.lockstep_threads:
-            self._lockstep_by_programs(model, engines, per_lane, mine_bg, own, rank, size)
+            self._lockstep_by_programs(model, engines, per_lane, mine_bg, own, rank, size, budgets)
             return
+        self.last_fit_info["driver"] = "thread-per-run (scipy's L-BFGS-B core not drivable by reverse communication)" \
+            if not self.lockstep_threads else "thread-per-run (lockstep_threads)"
         lanes = [gp.LockstepEvaluator(e, len(sl)) for e, sl in zip(engines, per_lane)]
         lockstep = lanes[0] if lanes else None
         handle = None
@@ -338,7 +355,38 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             runs = [r for part in self.comm.allgather_object(runs) for r in part]
         self._install_winner(model, runs, rank, size)
 
-    def _lockstep_by_programs(self, model, engines, per_lane, mine_bg, own, rank, size):
+    # ---- memory policy of the batched evaluations --------------------------------------------------------
+    @staticmethod
+    def _device_memory(engine):
+        """(bytes of one matrix set of a batch on `engine`, free bytes of its device) -- (0, 0) for an engine that cannot say (test doubles)"""
+        if not (hasattr(engine, "batch_mem") and hasattr(engine, "mem_info")):
+            return 0, 0
+        return int(engine.batch_mem(1)[0]), int(engine.mem_info()[0])
+
+    @staticmethod
+    def memory_reserve(engine):
+        """device memory a fit leaves alone: 2 % of the device, at least 1 GiB (plan tables, predictive panels, the host application)"""
+        total = int(engine.mem_info()[1]) if hasattr(engine, "mem_info") else 0
+        return max(1 << 30, total // 50)
+
+    def _lane_budgets(self, engines, slots):
+        """matrix sets each lane's passes may carry: its slot count where everything fits; otherwise the free device memory (less the
+        reserve) dealt to the lanes in proportion to their slots, plus what a lane's handle holds already, and within
+        MFGP_BATCH_MEM_CAP; 0 = request by request.  None per lane for an engine that cannot say."""
+        if not engines or not hasattr(engines[0], "batch_mem"):
+            return [None] * len(engines)
+        info = [e.batch_mem(1) for e in engines]                     # (bytes per set, cap bytes, sets held)
+        free = int(engines[0].mem_info()[0]) - self.memory_reserve(engines[0])
+        need = sum(max(0, n - held) * per for n, (per, _, held) in zip(slots, info))
+        out = []
+        for n, (per, cap, held) in zip(slots, info):
+            fit = n if need <= free else held + int(max(0, free) * (n / max(1, sum(slots))) // per)
+            if cap:
+                fit = min(fit, cap // per)
+            out.append(int(max(0, min(n, fit))))
+        return out
+
+    def _lockstep_by_programs(self, model, engines, per_lane, mine_bg, own, rank, size, budgets=None):
         """The lock-stepped runs WITHOUT a thread per run: every run is a generator of engine evaluation requests
         (engine.GPRegression._run_gen: scipy's L-BFGS-B core by reverse communication), every lane one loop over its runs
         (engine.LockstepLane.drive) -- lane 0 in the calling thread, each further lane in one thread of its own, so that one lane's
@@ -364,7 +412,8 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
 
         if not own:
             self._free_noise(model)
-        lanes = [gp.LockstepLane(e) for e in engines]
+        budgets = budgets or [None] * len(engines)
+        lanes = [gp.LockstepLane(e, max_batch=(None if b is None else max(1, b))) for e, b in zip(engines, budgets)]
         programs = [[sequential_pair() if (own and k == 0) else model.restart_program(take_index, starts, free_all, self.restart_max_iters, out)
                      for k in slots] for slots in per_lane]
         errors = []
@@ -389,6 +438,8 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             raise errors[0]
         runs = [(first[0].f_opt, first[0].x_opt, 0)] if first else []
         runs += [out[i] for i in mine_bg]
+        self.last_fit_info["sets_per_pass_used"] = [ln.max_batch for ln in lanes]
+        self.last_fit_info["oom_fallbacks"] = [list(ln.oom_fallbacks) for ln in lanes]
         self.last_lockstep = lanes[0]
         self.last_lockstep_lanes = lanes
         if size > 1:

@@ -26,6 +26,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // (optional) tears a communicator down WITHOUT the peers' cooperation
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     // (optional: only mfgp_eval_sharded needs them)
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -59,6 +60,7 @@ RcclApi& rccl() {
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
         if (ok) {
+            api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.lib, "ncclCommAbort"));
             api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(api.lib, "ncclBroadcast"));
             api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
         }
@@ -80,9 +82,30 @@ void comm_release(mfgp_handle* h) {
         h->comm_rank = 0;
         h->comm_size = 1;
     }
+    if (h) h->comm_aborted = false;
+}
+
+// A collective of this rank can no longer be matched by its peers (a failure after the control block told them to start a pass;
+// a peer that went silent): the communicator is torn down without them -- ncclCommAbort also ends RCCL kernels of this rank that
+// still wait for a peer -- and the handle remembers it: every further collective call on it is refused (-4) instead of being
+// enqueued against peers that are somewhere else in the protocol (mismatched collectives never return).
+void comm_abort(mfgp_handle* h) {
+    if (!h || !h->comm) return;
+    RcclApi& api = rccl();
+    if (api.CommAbort) api.CommAbort(static_cast<ncclComm_t>(h->comm));
+    // (without ncclCommAbort the communicator is leaked rather than destroyed: ncclCommDestroy waits for the peers)
+    h->comm = nullptr;
+    h->comm_aborted = true;
+}
+
+static int comm_usable(mfgp_handle* h, const char* who) {
+    if (h->comm_aborted)
+        return fail(h, -4, std::string(who) + ": the handle's communicator was aborted after a failed collective; the process must end");
+    return 0;
 }
 
 int comm_allgather_chunks(mfgp_handle* h, double* base, size_t chunk, hipStream_t s) {
+    if (int rc = comm_usable(h, "ncclAllGather (rows of X^T)")) return rc;
     if (!h->comm || h->comm_size <= 1) return 0;
     ncclResult_t r = rccl().AllGather(base + (size_t)h->comm_rank * chunk, base, chunk, ncclDouble,
                                       static_cast<ncclComm_t>(h->comm), s);
@@ -91,6 +114,7 @@ int comm_allgather_chunks(mfgp_handle* h, double* base, size_t chunk, hipStream_
 }
 
 int comm_bcast_words(mfgp_handle* h, double* dev, size_t count, int root, hipStream_t s) {
+    if (int rc = comm_usable(h, "ncclBroadcast (control block)")) return rc;
     if (!h->comm || h->comm_size <= 1) return 0;
     RcclApi& api = rccl();
     if (!api.Broadcast) return fail(h, -4, "librccl lacks ncclBroadcast");
@@ -100,6 +124,7 @@ int comm_bcast_words(mfgp_handle* h, double* dev, size_t count, int root, hipStr
 }
 
 int comm_allreduce_sum(mfgp_handle* h, double* buf, size_t count, hipStream_t s) {
+    if (int rc = comm_usable(h, "ncclAllReduce (gradient tile partials)")) return rc;
     if (!h->comm || h->comm_size <= 1) return 0;
     RcclApi& api = rccl();
     if (!api.AllReduce) return fail(h, -4, "librccl lacks ncclAllReduce");
@@ -148,27 +173,79 @@ int32_t mfgp_comm_destroy(mfgp_handle* h) {
     return 0;
 }
 
+int32_t mfgp_comm_state(mfgp_handle* h) {
+    if (!h) return 0;
+    return h->comm_aborted ? -1 : (h->comm ? h->comm_size : 0);
+}
+
+int32_t mfgp_row_block_owner(int32_t block, int32_t size) { return block < 0 ? -1 : shard_owner(block, size); }
+
+// The row blocks of Ky: 128-row blocks dealt to the ranks in the serpentine block-cyclic order of a sharded
+// evaluation (plan.h shard_owner) -- with CONTIGUOUS blocks per rank the last rank's rows are full-width while the factorisation
+// reads only the lower triangle, so the largest message stays 8 Np^2 / size bytes whatever is cut; dealt this way every rank's
+// blocks hold the same share of the triangle and ONE in-place all-gather of equal packed chunks moves 4 Np (Np + 128) bytes in
+// all instead of 8 Np^2 (round 5: half the bytes of an exchange that costs 6 x the local build).
 int32_t mfgp_allgather_rows(mfgp_handle* h) {
     if (!h) return fail(h, -1, "mfgp_allgather_rows: NULL");
+    if (int rc = comm_usable(h, "mfgp_allgather_rows")) return rc;
     if (!h->comm) return fail(h, -1, "mfgp_allgather_rows: no communicator (mfgp_comm_init)");
     if (!h->have_data) return fail(h, -1, "mfgp_allgather_rows: mfgp_set_data not called");
-    const int64_t Np = h->Np;
-    if (Np % (64 * (int64_t)h->comm_size) != 0)
-        return fail(h, -1, "mfgp_allgather_rows: the padded size must split into equal 64-row multiples per rank");
-    HIPCHK(h, hipSetDevice(h->device));
-    const size_t count = (size_t)(Np / h->comm_size) * (size_t)Np;   // doubles per rank
-    double* A = h->buf[BUF_A];
-    // in place: rank r's block already sits at its final position (sendbuff == recvbuff + r * count)
-    ncclResult_t r = rccl().AllGather(A + (size_t)h->comm_rank * count, A, count, ncclDouble,
-                                      static_cast<ncclComm_t>(h->comm), h->stream);
-    if (r != ncclSuccess) return rccl_fail(h, "ncclAllGather (row blocks)", r);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->factorized = h->kinv_valid = h->grad_valid = false;
+    const int size = h->comm_size, rank = h->comm_rank, nblk = h->nblk;
+    if (size <= 1) return 0;                       // the group of one holds every block already
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (h->row_off_nblk != nblk || h->row_off_size != size) {
+        // block b's lower part (128 x 128 (b + 1) doubles) at offset off[b] of its owner's chunk; chunks padded to the largest
+        std::vector<long long> off((size_t)nblk), fill((size_t)size, 0);
+        for (int b = 0; b < nblk; ++b) {
+            const int own = shard_owner(b, size);
+            off[(size_t)b] = fill[(size_t)own];
+            fill[(size_t)own] += 128LL * 128LL * (b + 1);
+        }
+        h->row_chunk = *std::max_element(fill.begin(), fill.end());
+        if (nblk > h->row_off_cap) {
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (h->drow_off) HIPCHK(h, hipFree(h->drow_off));
+            h->drow_off = nullptr;
+            h->row_off_cap = nblk + 64;
+            HIPCHK(h, hipMalloc(&h->drow_off, (size_t)h->row_off_cap * sizeof(long long)));
+        }
+        HIPCHK(h, hipMemcpyAsync(h->drow_off, off.data(), (size_t)nblk * sizeof(long long), hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));        // (off is a local)
+        h->row_off_nblk = nblk;
+        h->row_off_size = size;
+    }
+    // staging: the workspace matrix W (idle until the factorisation starts) wherever size x chunk fits it, else a buffer of its own
+    const size_t need = (size_t)size * (size_t)h->row_chunk;
+    double* stage = h->buf[BUF_W];
+    if (need > (size_t)h->cap * (size_t)h->cap) {
+        if (need > h->stage_cap) {
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (h->dstage) HIPCHK(h, hipFree(h->dstage));
+            h->dstage = nullptr;
+            h->stage_cap = need;
+            HIPCHK(h, hipMalloc(&h->dstage, h->stage_cap * sizeof(double)));
+        }
+        stage = h->dstage;
+    }
+    double* A = h->buf[BUF_A];
+    launch_shard_rows_copy(s, A, (int)h->Np, nblk, stage, h->drow_off, h->row_chunk, rank, size, false, true);
+    ncclResult_t r = rccl().AllGather(stage + (size_t)rank * (size_t)h->row_chunk, stage, (size_t)h->row_chunk, ncclDouble,
+                                      static_cast<ncclComm_t>(h->comm), s);
+    if (r != ncclSuccess) {
+        (void)hipStreamSynchronize(s);
+        return rccl_fail(h, "ncclAllGather (row blocks of Ky, lower part)", r);
+    }
+    launch_shard_rows_copy(s, A, (int)h->Np, nblk, stage, h->drow_off, h->row_chunk, rank, size, true, true);
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
     return 0;
 }
 
 int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, double* recv) {
     if (!h || !send || !recv) return fail(h, -1, "mfgp_allgather_host: NULL argument");
+    if (int rc = comm_usable(h, "mfgp_allgather_host")) return rc;
     if (!h->comm) return fail(h, -1, "mfgp_allgather_host: no communicator (mfgp_comm_init)");
     if (count < 1) return fail(h, -1, "mfgp_allgather_host: count < 1");
     HIPCHK(h, hipSetDevice(h->device));

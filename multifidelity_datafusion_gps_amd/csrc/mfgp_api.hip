@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include "mfgp_internal.h"
 
 using namespace mfgp;
@@ -178,6 +180,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->dtasks_b) hipFree(h->dtasks_b);
     if (h->dtasks_s) hipFree(h->dtasks_s);
     if (h->dshard_off) hipFree(h->dshard_off);
+    if (h->drow_off) hipFree(h->drow_off);
     if (h->dctl) hipFree(h->dctl);
     if (h->hctl) hipHostFree(h->hctl);
     comm_release(h);
@@ -434,23 +437,68 @@ int32_t mfgp_eval(mfgp_handle* h, const double* theta, double noise, double jitt
 // ---- batched evaluation ------------------------------------------------------------------------------------------
 #define MFGP_MAX_BATCH_SETS 16
 
-static int ensure_batch(mfgp_handle* h, int B) {
-    if (B <= h->bsets && h->bsets_cap == h->cap) return 0;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int want = std::max(B, h->bsets_cap == h->cap ? h->bsets : 0);
-    free_batch(h);
+// device + pinned bytes `sets` matrix sets of a batch take on this handle (the slab dominates: 32 cap^2 bytes per set)
+static size_t batch_bytes(const mfgp_handle* h, int sets) {
     const size_t cap = (size_t)h->cap;
-    HIPCHK(h, hipMalloc(&h->bslab, (size_t)want * 4 * cap * cap * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->bz, (size_t)want * cap * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->balpha, (size_t)want * cap * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->blogdet, (size_t)want * (cap / NB) * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->bpart, (size_t)want * grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1) * sizeof(double)));
-    HIPCHK(h, hipHostMalloc(&h->bhres, (size_t)want * mfgp_handle::BRES * sizeof(double), hipHostMallocMapped));
-    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->bdres), h->bhres, 0));
+    const size_t per = 4 * cap * cap + 2 * cap + cap / NB + (size_t)grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1) + mfgp_handle::BRES;
+    return (size_t)sets * per * sizeof(double);
+}
+
+// MFGP_BATCH_MEM_CAP (bytes; unset / 0: none): the most ONE handle's batch slab may take -- for a host application that shares the
+// device, and for the tests of the fallback below
+static size_t batch_mem_cap() {
+    const char* v = getenv("MFGP_BATCH_MEM_CAP");
+    if (!v || !*v) return 0;
+    const double x = atof(v);
+    return x > 0 ? (size_t)x : 0;
+}
+
+// -> 0, MFGP_ERR_OOM (everything released again; nothing else of the handle touched), or -2 (another HIP error)
+static int alloc_batch(mfgp_handle* h, int want) {
+    const size_t cap = (size_t)h->cap;
+    hipError_t e = hipSuccess;
+    auto dev = [&](double** p, size_t n) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(double)); };
+    dev(&h->bslab, (size_t)want * 4 * cap * cap);
+    dev(&h->bz, (size_t)want * cap);
+    dev(&h->balpha, (size_t)want * cap);
+    dev(&h->blogdet, (size_t)want * (cap / NB));
+    dev(&h->bpart, (size_t)want * grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->bhres), (size_t)want * mfgp_handle::BRES * sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->bdres), h->bhres, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();               // (an allocation failure is not sticky, but it is the "last error" until read)
+        free_batch(h);
+        if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation)
+            return fail(h, MFGP_ERR_OOM, "mfgp_eval_batch: out of device memory for " + std::to_string(want) + " matrix sets (" +
+                                             std::to_string(batch_bytes(h, want) >> 20) + " MiB)");
+        return fail(h, -2, std::string("mfgp_eval_batch: allocating the batch slab: ") + hipGetErrorString(e));
+    }
     memset(h->bhres, 0, (size_t)want * mfgp_handle::BRES * sizeof(double));
     h->bsets = want;
     h->bsets_cap = h->cap;
     return 0;
+}
+
+// Memory policy of a batch (round 5): a request the device (or MFGP_BATCH_MEM_CAP) cannot hold is its own status, MFGP_ERR_OOM --
+// never a generic HIP error -- and leaves the handle usable: the sets it held before are still there (or re-allocated), every other
+// call works, and the caller retries with fewer sets (engine.LockstepLane does) or with single evaluations, which need no slab.
+static int ensure_batch(mfgp_handle* h, int B) {
+    if (B <= h->bsets && h->bsets_cap == h->cap) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int held = h->bsets_cap == h->cap ? h->bsets : 0;
+    const int want = std::max(B, held);
+    const size_t limit = batch_mem_cap();
+    if (limit && batch_bytes(h, want) > limit)
+        return fail(h, MFGP_ERR_OOM, "mfgp_eval_batch: " + std::to_string(want) + " matrix sets (" + std::to_string(batch_bytes(h, want) >> 20) +
+                                         " MiB) exceed MFGP_BATCH_MEM_CAP (" + std::to_string(limit >> 20) + " MiB)");
+    free_batch(h);
+    int rc = alloc_batch(h, want);
+    if (rc == MFGP_ERR_OOM && held > 0) {
+        const std::string why = h->err;
+        if (alloc_batch(h, held) != 0) free_batch(h);      // (what was just released fits again unless somebody else took it meanwhile)
+        h->err = why;
+    }
+    return rc;
 }
 
 // the batch's plan: the handle's plan with the 128-tile threshold divided by the number of sets a launch carries (classes
@@ -517,30 +565,46 @@ int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const d
         *reinterpret_cast<int*>(r + 30) = 0;
         for (int i = 0; i < np; ++i) r[128 + i] = specs[b].theta[i];        // the gradient's finishing kernel divides by them
     }
+    // from the first launch on, an error exit waits for what is already in flight on both streams: the next call rewrites the mapped
+    // result blocks and the per-set parameter words from the host
+    auto bail = [&](int code) {
+        (void)hipStreamSynchronize(h->stream);
+        if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+        return code;
+    };
+#define HIPCHK_BAIL(call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return bail(-2);                                                                    \
+        }                                                                                       \
+    } while (0)
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], s));
     launch_kbuild_tri_batch(s, specs.data(), B, h->dX, (int)h->N, Np, h->bslab, Np, (long long)set);
     h->launches += 1;
-    if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[1], s));
+    if (h->stage_timing) HIPCHK_BAIL(hipEventRecord(h->ev[1], s));
     const bool stream_kinv = grad && h->plb.kinv_streamed;
     for (const Step& st : h->plb.steps)
-        if (run_step(h, st, stream_kinv, B) != 0) return -1;
-    if (h->stage_timing) HIPCHK(h, hipEventRecord(h->ev[2], s));
+        if (run_step(h, st, stream_kinv, B) != 0) return bail(-1);
+    if (h->stage_timing) HIPCHK_BAIL(hipEventRecord(h->ev[2], s));
     double* const S0 = h->bslab + (size_t)BUF_S * cap * cap;
     launch_rowdot(s, S0, Np, h->dY, h->bz, Np, Np, 0, B, (long long)set, 0, (long long)cap);                   // z = X y
     launch_alpha_finish(s, S0, Np, h->bz, h->balpha, Np, h->blogdet, h->nblk, h->bdres, B, (long long)set, (long long)cap,
                         (int)(cap / NB), BRES);
     h->launches += 2;
     if (grad) {
-        if (!stream_kinv && run_step(h, h->plb.kinv_step, true, B) != 0) return -1;
+        if (!stream_kinv && run_step(h, h->plb.kinv_step, true, B) != 0) return bail(-1);
         const size_t npart = (size_t)grad_num_partials((int)cap) * (MFGP_MAX_THETA + 1);
         launch_grad_batch(s, specs.data(), B, h->dX, h->bslab, (long long)set, Np, h->balpha, (long long)cap, (int)h->N, Np,
                           h->bpart, (long long)npart, h->bdres + 64, BRES, h->bdres + 128, BRES);
         h->launches += 2;
     }
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[5], s));
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(s));
-    HIPCHK(h, hipGetLastError());
+    if (h->timing) HIPCHK_BAIL(hipEventRecord(h->ev[5], s));
+    HIPCHK_BAIL(hipGetLastError());
+    HIPCHK_BAIL(hipStreamSynchronize(s));
+    HIPCHK_BAIL(hipGetLastError());
+#undef HIPCHK_BAIL
     // accounting: B evaluations, timed as one pass
     const double npd = (double)h->Np;
     mfgp_timings& t = h->tm;
@@ -572,6 +636,28 @@ int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const d
         if (grad)
             for (int i = 0; i < np + 1; ++i) grads[(size_t)b * (np + 1) + i] = r[64 + i];
     }
+    return 0;
+}
+
+// what the host layer sizes a batch from (engine.LockstepLane / AbstractMFGP._ard_lockstep): free / total bytes of the handle's device,
+// the bytes `sets` matrix sets of a batch would take on this handle at its current capacity, and how many it holds already
+int32_t mfgp_mem_info(mfgp_handle* h, int64_t* free_bytes, int64_t* total_bytes) {
+    if (!h || !free_bytes || !total_bytes) return fail(h, -1, "mfgp_mem_info: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t f = 0, t = 0;
+    HIPCHK(h, hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return 0;
+}
+
+int32_t mfgp_batch_mem(mfgp_handle* h, int32_t sets, int64_t* bytes, int64_t* cap_bytes, int32_t* sets_held) {
+    int rc = check_ready(h, "mfgp_batch_mem");
+    if (rc) return rc;
+    if (sets < 0 || !bytes || !cap_bytes || !sets_held) return fail(h, -1, "mfgp_batch_mem: bad argument");
+    *bytes = (int64_t)batch_bytes(h, sets);
+    *cap_bytes = (int64_t)batch_mem_cap();
+    *sets_held = h->bsets_cap == h->cap ? h->bsets : 0;
     return 0;
 }
 
@@ -624,6 +710,43 @@ static int ensure_shard_plan(mfgp_handle* h, int rank, int size) {
     HIPCHK(h, hipMemcpyAsync(h->dshard_off, off.data(), (size_t)h->nblk * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// Waiting for a stream that carries a collective: hipStreamSynchronize never returns when a peer is gone (the RCCL kernel waits for
+// its data for ever).  With a communicator of more than one rank the wait is a poll with a deadline (MFGP_SHARD_TIMEOUT_S, default
+// 600 s -- a pass takes milliseconds, a leader's optimiser step between two passes less); past it the communicator is aborted
+// (which ends the waiting kernel) and the call fails with -4: the rank exits with an error instead of hanging the job.
+static double shard_timeout_s() {
+    const char* v = getenv("MFGP_SHARD_TIMEOUT_S");
+    const double x = v && *v ? atof(v) : 0.0;
+    return x > 0.0 ? x : 600.0;
+}
+static int shard_sync(mfgp_handle* h, hipStream_t s, const char* what) {
+    if (!h->comm || h->comm_size <= 1) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        return 0;
+    }
+    const double limit = shard_timeout_s();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) {
+            h->err = std::string(what) + ": " + hipGetErrorString(e);
+            comm_abort(h);
+            return -2;
+        }
+        if ((spins & 63) == 63) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > limit) {
+                comm_abort(h);
+                (void)hipStreamSynchronize(s);      // (the aborted collective's kernel ends; what was enqueued behind it drains)
+                return fail(h, -4, std::string(what) + ": no progress for " + std::to_string((int)limit) +
+                                       " s -- a peer of the group is gone or somewhere else in the protocol; the communicator was aborted");
+            }
+            if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.1 ? 500 : 20));
+        }
+    }
 }
 
 // the pass of rank `rank` of `size`; exchange = false: without the collectives (what one rank's GPU does, timed by
@@ -680,6 +803,7 @@ static int sharded_pass(mfgp_handle* h, const double* theta, double noise, doubl
 }
 
 static int sharded_finish(mfgp_handle* h, bool want_grad);
+static int shard_broken(mfgp_handle* h, int rc);
 
 int32_t mfgp_eval_sharded(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, double* nlml,
                           double* grad) {
@@ -687,9 +811,11 @@ int32_t mfgp_eval_sharded(mfgp_handle* h, const double* theta, double noise, dou
     if (rc) return rc;
     if (!theta) return fail(h, -1, "mfgp_eval_sharded: theta is NULL");
     HIPCHK(h, hipSetDevice(h->device));
+    const bool group = h->comm && h->comm_size > 1;      // (a failure inside a pass the peers run too: see shard_broken)
     rc = sharded_pass(h, theta, noise, jitter, want_grad != 0, h->comm_rank, h->comm_size, true);
-    if (rc) return rc;
+    if (rc) return group ? shard_broken(h, rc) : rc;
     rc = sharded_finish(h, want_grad != 0);
+    if (rc < 0 && group) return shard_broken(h, rc);
     if (rc) return rc;
     if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
     if (want_grad && grad)
@@ -719,13 +845,25 @@ static int ctl_exchange(mfgp_handle* h, double* ctl, bool leader) {
     if (rc) return rc;
     if (!leader) {
         HIPCHK(h, hipMemcpyAsync(h->hctl, h->dctl, CTL_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipStreamSynchronize(s));
+        if (int rs = shard_sync(h, s, "mfgp_sharded_serve: waiting for the leader's control block")) return rs;
         memcpy(ctl, h->hctl, CTL_WORDS * sizeof(double));
     }
     return 0;
 }
 
+// a failure on this rank AFTER the control block told the group to start a pass: its collectives can no longer be matched
+static int shard_broken(mfgp_handle* h, int rc) {
+    const std::string why = h->err;
+    (void)hipStreamSynchronize(h->stream2 ? h->stream2 : h->stream);
+    comm_abort(h);
+    (void)hipStreamSynchronize(h->stream);
+    h->err = why + " [inside a pass the group had already started: the communicator was aborted, no further collective is issued]";
+    h->factorized = h->kinv_valid = h->grad_valid = false;
+    return rc;
+}
+
 static int sharded_finish(mfgp_handle* h, bool want_grad) {
+    if (int rs = shard_sync(h, h->stream, "sharded evaluation: waiting for the pass (all-gather / all-reduce with the group)")) return rs;
     const bool streamed_flag = h->pl.kinv_streamed;       // finish_eval's flop accounting looks at the handle's own plan:
     h->pl.kinv_streamed = false;                          // a sharded pass never streams K^-1
     const int rc = finish_eval(h, want_grad);
@@ -744,13 +882,19 @@ int32_t mfgp_sharded_lead(mfgp_handle* h, const double* theta, double noise, dou
     for (int i = 0; i < h->spec.np; ++i)      // (checked BEFORE the followers are told: a refused call must not leave them mid-pass)
         if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "parameters must be positive and finite");
     if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "noise and jitter must be >= 0");
+    if (h->comm_aborted) return fail(h, -4, "mfgp_sharded_lead: the group's communicator was aborted after a failed pass");
+    rc = ensure_shard_plan(h, 0, h->comm_size);          // (allocations BEFORE the followers are told: a failure here leaves them waiting, not mid-pass)
+    if (rc) return rc;
     double ctl[CTL_WORDS] = {1.0, want_grad ? 1.0 : 0.0, noise, jitter, (double)h->spec.np};
     for (int i = 0; i < h->spec.np; ++i) ctl[5 + i] = theta[i];
     rc = ctl_exchange(h, ctl, true);
-    if (rc) return rc;
+    if (rc) return rc < 0 ? shard_broken(h, rc) : rc;
+    if (h->dbg_fail_sharded_in > 0 && --h->dbg_fail_sharded_in == 0)
+        return shard_broken(h, fail(h, -2, "mfgp_sharded_lead: injected failure (mfgp_dbg_fail_sharded_after)"));
     rc = sharded_pass(h, theta, noise, jitter, want_grad != 0, 0, h->comm_size, true);
-    if (rc) return rc;
+    if (rc) return shard_broken(h, rc);
     rc = sharded_finish(h, want_grad != 0);
+    if (rc < 0) return shard_broken(h, rc);
     if (rc) return rc;
     if (nlml) *nlml = 0.5 * ((double)h->N * 1.8378770664093453 + h->logdet + h->quad);
     if (want_grad && grad)
@@ -761,11 +905,17 @@ int32_t mfgp_sharded_lead(mfgp_handle* h, const double* theta, double noise, dou
 int32_t mfgp_sharded_release(mfgp_handle* h) {
     if (!h) return fail(h, -1, "mfgp_sharded_release: NULL");
     if (h->comm_rank != 0) return fail(h, -1, "mfgp_sharded_release: only rank 0 of the handle's communicator leads");
+    if (h->comm_aborted) return fail(h, -4, "mfgp_sharded_release: the group's communicator was aborted after a failed pass; nothing to release");
     HIPCHK(h, hipSetDevice(h->device));
     double ctl[CTL_WORDS] = {0.0};
     const int rc = ctl_exchange(h, ctl, true);
     if (rc) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return shard_sync(h, h->stream, "mfgp_sharded_release: waiting for the followers to take the release");
+}
+
+int32_t mfgp_dbg_fail_sharded_after(mfgp_handle* h, int32_t n) {
+    if (!h || n < 0) return fail(h, -1, "mfgp_dbg_fail_sharded_after: bad argument");
+    h->dbg_fail_sharded_in = n;
     return 0;
 }
 
@@ -782,10 +932,12 @@ int32_t mfgp_sharded_serve(mfgp_handle* h, int64_t* served) {
         if (ctl[0] == 0.0) break;
         if ((int)ctl[4] != h->spec.np) return fail(h, -1, "mfgp_sharded_serve: the leader's kernel has another parameter count");
         const bool g = ctl[1] != 0.0;
+        if (h->dbg_fail_sharded_in > 0 && --h->dbg_fail_sharded_in == 0)
+            return shard_broken(h, fail(h, -2, "mfgp_sharded_serve: injected failure (mfgp_dbg_fail_sharded_after)"));
         rc = sharded_pass(h, ctl + 5, ctl[2], ctl[3], g, h->comm_rank, h->comm_size, true);
-        if (rc) return rc;
+        if (rc) return shard_broken(h, rc);
         rc = sharded_finish(h, g);      // > 0: not positive definite -- the leader sees the same pivot and decides what comes next
-        if (rc < 0) return rc;
+        if (rc < 0) return shard_broken(h, rc);
         ++n;
     }
     if (served) *served = n;
@@ -823,6 +975,28 @@ int32_t mfgp_kbuild_rows(mfgp_handle* h, const double* theta, double noise, doub
     if (rc) return rc;
     launch_kbuild_rows(h->stream, h->spec, h->dX, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np,
                        (int)row_begin, (int)row_end);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->factorized = h->kinv_valid = h->grad_valid = false;
+    return 0;
+}
+
+// the rows of every 128-row block that rank `rank` of `size` owns (mfgp_row_block_owner): what a rank builds before mfgp_allgather_rows
+int32_t mfgp_kbuild_owned_rows(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t rank, int32_t size) {
+    int rc = check_ready(h, "mfgp_kbuild_owned_rows");
+    if (rc) return rc;
+    if (!theta) return fail(h, -1, "mfgp_kbuild_owned_rows: theta is NULL");
+    if (size < 1 || rank < 0 || rank >= size) return fail(h, -1, "mfgp_kbuild_owned_rows: need 0 <= rank < size");
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = set_params(h, theta, noise, jitter);
+    if (rc) return rc;
+    for (int b = 0; b < h->nblk; ++b) {
+        if (shard_owner(b, size) != rank) continue;
+        int e = b + 1;                             // (consecutive owned blocks -- the turning points of the serpentine -- in one launch)
+        while (e < h->nblk && shard_owner(e, size) == rank) ++e;
+        launch_kbuild_rows(h->stream, h->spec, h->dX, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np, b * NB, e * NB);
+        b = e - 1;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     h->factorized = h->kinv_valid = h->grad_valid = false;

@@ -100,8 +100,9 @@ void launch_grad_finish(hipStream_t s, const KernSpecDev& spec, const double* pa
 //   lower part of the mirrored inverse S <- transpose of its upper part (sharded evaluation, after the exchange of the rows of X^T)
 void launch_mirror_lower(hipStream_t s, double* S, int ld, int Np);
 //   pack this rank's blocks of the upper part of S into / unpack the other ranks' blocks out of the exchange's staging buffer
+//   (lower: the part of each 128-row block up to and including its diagonal block instead -- the row blocks of Ky, mfgp_allgather_rows)
 void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* stage, const long long* off, long long chunk,
-                            int rank, int size, bool unpack);
+                            int rank, int size, bool unpack, bool lower = false);
 //   nbatch sets: K^-1 of set b at Kinv + b * kstride, alpha + b * astride, partials + b * pstride, out + b * ostride; thetas =
 //   device-readable copy of the sets' parameter vectors, tstride apart (the finishing kernel divides by them)
 void launch_grad_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, const double* Kinv, long long kstride,
@@ -167,6 +168,8 @@ struct mfgp_handle {
     // multi-GPU (comm_rccl.hip): one RCCL communicator per handle, created by mfgp_comm_init; opaque here
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 1;
+    bool comm_aborted = false;           // the communicator was torn down after a failed / unmatched collective (comm_abort): no further one is issued
+    int dbg_fail_sharded_in = 0;         // test hook (mfgp_dbg_fail_sharded_after): the n-th sharded pass from now fails after the control exchange
     double* dstage = nullptr;            // device staging of mfgp_allgather_host
     size_t stage_cap = 0;
     // batched evaluation (mfgp_eval_batch): bsets matrix sets A | L | S | W of cap^2 each (the plan's task offsets apply to
@@ -179,6 +182,9 @@ struct mfgp_handle {
     double *bz = nullptr, *balpha = nullptr, *blogdet = nullptr, *bpart = nullptr;
     double *bhres = nullptr, *bdres = nullptr;   // BRES doubles per set: [0,1] scalars, [30] pivot status, [64..] gradient, [128..] theta
     static constexpr int BRES = 256;
+    long long* drow_off = nullptr;       // mfgp_allgather_rows: offset of every 128-row block's LOWER part inside its owner's chunk
+    long long row_chunk = 0;             //   doubles per rank in that all-gather
+    int row_off_cap = 0, row_off_nblk = 0, row_off_size = 0;   //   (capacity; the block count and communicator size the table was built for)
     long long* dshard_off = nullptr;     // offset of every 128-row block inside its owner's chunk of the exchange (device copy)
     long long shard_chunk = 0;           // doubles per rank in the exchange's all-gather
     int shard_off_cap = 0;
@@ -209,6 +215,8 @@ inline int fail(mfgp_handle* h, int code, const std::string& msg) {
 }
 // releases the communicator of a handle (no-op without one); defined in comm_rccl.hip
 void comm_release(mfgp_handle* h);
+// tears it down without the peers (ncclCommAbort) and poisons the handle's collective calls
+void comm_abort(mfgp_handle* h);
 // collectives of a sharded evaluation on the handle's communicator and stream (no-ops for a communicator of one / none):
 //   -> 0 or a negative status (h->err set)
 //   in-place all-gather of equal chunks: rank r's `chunk` doubles already sit at base + r * chunk

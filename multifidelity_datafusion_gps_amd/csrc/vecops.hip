@@ -218,24 +218,26 @@ __global__ __launch_bounds__(256) void mfgp_mirror_lower_f64(double* __restrict_
 // the diagonal on (the upper part of S), packed densely -- block b is 128 x (Np - 128 b) doubles at offset off[b] of its owner's
 // chunk -- so that ONE in-place ncclAllGather of equal chunks carries every rank's rows (the serpentine ownership makes the
 // chunks equal to within a block; they are padded to the largest).  pack: this rank's blocks S -> stage; unpack: the others'
-// blocks stage -> S.  One workgroup per (row of a block, block).
+// blocks stage -> S.  One workgroup per (row of a block, block).  lower != 0: the columns UP TO the diagonal block instead
+// (block b is 128 x 128 (b + 1) doubles) -- the row blocks of Ky that mfgp_allgather_rows exchanges: the factorisation reads
+// only the lower triangle.
 __global__ __launch_bounds__(256) void mfgp_shard_rows_copy_f64(double* __restrict__ S, int ld, double* __restrict__ stage,
                                                                 const long long* __restrict__ off, long long chunk, int rank,
-                                                                int size, int unpack) {
+                                                                int size, int unpack, int lower) {
     const int b = blockIdx.y, r = blockIdx.x;
     const int x = b % (2 * size), own = x < size ? x : 2 * size - 1 - x;        // plan.h shard_owner
     if ((own == rank) == (unpack != 0)) return;
-    const int w = ld - b * 128;                                                    // (ld = Np)
-    double* rowS = S + (long long)(b * 128 + r) * ld + b * 128;
+    const int w = lower ? (b + 1) * 128 : ld - b * 128;                            // (ld = Np)
+    double* rowS = S + (long long)(b * 128 + r) * ld + (lower ? 0 : b * 128);
     double* rowP = stage + (long long)own * chunk + off[b] + (long long)r * w;
     const d2_t* src = reinterpret_cast<const d2_t*>(unpack ? rowP : rowS);
     d2_t* dst = reinterpret_cast<d2_t*>(unpack ? rowS : rowP);
     for (int k = threadIdx.x; k < w / 2; k += 256) dst[k] = src[k];
 }
 void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* stage, const long long* off, long long chunk,
-                            int rank, int size, bool unpack) {
+                            int rank, int size, bool unpack, bool lower) {
     hipLaunchKernelGGL(mfgp_shard_rows_copy_f64, dim3(128, nblk), dim3(256), 0, s, S, ld, stage, off, chunk, rank, size,
-                       unpack ? 1 : 0);
+                       unpack ? 1 : 0, lower ? 1 : 0);
 }
 
 void launch_mirror_lower(hipStream_t s, double* S, int ld, int Np) {

@@ -401,6 +401,7 @@ class LockstepEvaluator:
         self.evals = 0
         self.round_sizes = []
         self.engine_s = 0.0       # wall seconds inside eval_batch (the rest of a fit's time is the hosts' L-BFGS-B steps and hand-offs)
+        self.oom_fallbacks = 0    # rounds whose batch did not fit the device and went request by request
 
     def evaluate(self, slot, theta, noise, jitter):
         """-> (nlml, grad) of THIS slot's point; raises NotPositiveDefinite for it alone"""
@@ -431,8 +432,18 @@ class LockstepEvaluator:
         try:
             for c0 in range(0, len(slots), cap):
                 part, sl = reqs[c0:c0 + cap], slots[c0:c0 + cap]
-                nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
-                                                           [r[2] for r in part], want_grad=True)
+                try:
+                    nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
+                                                               [r[2] for r in part], want_grad=True)
+                except _lib.EngineOutOfMemory:       # the sets do not fit: request by request on the handle's own slab (same results)
+                    self.oom_fallbacks += 1
+                    for r, k in zip(part, sl):
+                        try:
+                            f, g = self._eng.eval(r[0], r[1], r[2], want_grad=True)
+                            self._results[k] = (float(f), np.array(g))
+                        except NotPositiveDefinite as ex:
+                            self._results[k] = ex
+                    continue
                 for j, k in enumerate(sl):
                     self._results[k] = (NotPositiveDefinite(int(status[j])) if status[j] != 0
                                         else (float(nlml[j]), np.array(grads[j])))
@@ -454,12 +465,63 @@ class LockstepLane:
     driven by reverse communication): the host side of a round is the runs' own L-BFGS-B steps and nothing else.  Same statistics
     as LockstepEvaluator (rounds, evals, round_sizes, engine_s)."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, max_batch=None):
         self._eng = engine
         self.rounds = 0
         self.evals = 0
         self.round_sizes = []
         self.engine_s = 0.0
+        # memory policy (round 5): the most sets one pass may carry -- the engine's limit, or less where the caller sized it from the
+        # device's free memory (AbstractMFGP._ard_lockstep) -- halved whenever the engine answers EngineOutOfMemory; at 1 the lane
+        # evaluates request by request with eval(), which needs no batch slab.  A batched evaluation is bitwise the single one, so
+        # the runs take the same steps at every width.
+        cap = int(getattr(engine, "MAX_BATCH", 16))
+        self.max_batch = cap if not max_batch else max(1, min(cap, int(max_batch)))
+        self.oom_fallbacks = []       # (sets asked for, sets per pass from then on)
+
+    def _evaluate(self, part):
+        """-> the results of the requests `part` (at most max_batch of them): (nlml, grad) or the exception of that request"""
+        if len(part) > self.max_batch:                # (the lane narrowed since the caller cut its chunks)
+            out, c0 = [], 0
+            while c0 < len(part):
+                n = self.max_batch
+                out += self._evaluate(part[c0:c0 + n])
+                c0 += n
+            return out
+        while len(part) > 1 and self.max_batch > 1:
+            try:
+                nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
+                                                           [r[2] for r in part], want_grad=True)
+            except _lib.EngineOutOfMemory:
+                n_ = min(len(part), self.max_batch)
+                new = (n_ + 1) // 2 if n_ > 2 else 1          # 6 -> 3 -> 2 -> 1
+                self.oom_fallbacks.append((len(part), new))
+                self.max_batch = new
+                return self._evaluate(part)
+            except _EVAL_ERRORS as ex:               # the pass as a whole failed: a failed evaluation of every run in it
+                return [ex] * len(part)
+            return [NotPositiveDefinite(int(status[j])) if status[j] != 0 else (float(nlml[j]), np.array(grads[j]))
+                    for j in range(len(part))]
+        out = []
+        for theta, noise, jitter in part:            # one request, or a lane narrowed to one set: the handle's own evaluation
+            try:
+                if self.max_batch > 1 or not hasattr(self._eng, "eval"):
+                    nlml, grads, status = self._eng.eval_batch(np.array([theta]), [noise], [jitter], want_grad=True)
+                    out.append(NotPositiveDefinite(int(status[0])) if status[0] != 0 else (float(nlml[0]), np.array(grads[0])))
+                else:
+                    f, g = self._eng.eval(theta, noise, jitter, want_grad=True)
+                    out.append((float(f), np.array(g)))
+            except _lib.EngineOutOfMemory:           # (not even one set fits: single evaluations from here on)
+                self.oom_fallbacks.append((1, 1))
+                self.max_batch = 1
+                try:
+                    f, g = self._eng.eval(theta, noise, jitter, want_grad=True)
+                    out.append((float(f), np.array(g)))
+                except (NotPositiveDefinite,) + _EVAL_ERRORS as ex:
+                    out.append(ex)
+            except (NotPositiveDefinite,) + _EVAL_ERRORS as ex:
+                out.append(ex)
+        return out
 
     def drive(self, programs):
         """run the generators to their end; a program that raises ends every program of the lane (the exception propagates)"""
@@ -469,23 +531,16 @@ class LockstepLane:
                 live[k] = (prog, next(prog))
             except StopIteration:
                 pass
-        cap = getattr(self._eng, "MAX_BATCH", 16)
         while live:
             slots = sorted(live)
             results = {}
             t0 = time.perf_counter()
-            for c0 in range(0, len(slots), cap):
-                sl = slots[c0:c0 + cap]
-                part = [live[k][1] for k in sl]
-                try:
-                    nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
-                                                               [r[2] for r in part], want_grad=True)
-                except _EVAL_ERRORS as ex:           # the pass as a whole failed: a failed evaluation of every run in it
-                    for k in sl:
-                        results[k] = ex
-                    continue
-                for j, k in enumerate(sl):
-                    results[k] = NotPositiveDefinite(int(status[j])) if status[j] != 0 else (float(nlml[j]), np.array(grads[j]))
+            c0 = 0
+            while c0 < len(slots):
+                sl = slots[c0:c0 + self.max_batch]
+                for k, res in zip(sl, self._evaluate([live[k][1] for k in sl])):
+                    results[k] = res
+                c0 += len(sl)
             self.engine_s += time.perf_counter() - t0
             self.rounds += 1
             self.evals += len(slots)
@@ -537,6 +592,8 @@ class GPRegression:
         self.optimization_runs = []
         self._eval_hook = None     # (theta, noise, jitter) -> (nlml, grad): evaluations routed through a LockstepEvaluator
         self.n_evals = 0           # objective(+gradient) evaluations issued to the GPU
+        self.n_jitter_retries = 0  # ... of those, repeats of an evaluation whose Ky was not positive definite (jitchol's retries)
+        self.n_failed_evals = 0    # evaluations that ended as FAILED (DBL_MAX + the previous gradient: paramz' convention)
         import threading
         self._evals_lock = threading.Lock()   # n_evals is bumped by every thread that evaluates for this model (lanes, background restarts)
         self._main_evals = 0       # ... of those, the ones issued through this object's own state (not by background restarts)
@@ -634,6 +691,7 @@ class GPRegression:
                 break
             except NotPositiveDefinite:
                 self._count_eval()
+                self._count_retry()
                 self._main_evals += 1
                 tries += 1
                 diag_mean = self.kern.Kdiag_value() + noise + CONST_JITTER
@@ -651,6 +709,10 @@ class GPRegression:
     def _count_eval(self):
         with self._evals_lock:       # (+= on an attribute is a read and a write: two lanes' threads would lose counts now and then)
             self.n_evals += 1
+
+    def _count_retry(self):
+        with self._evals_lock:       # a jitter retry (GPy's jitchol: Ky not positive definite, the evaluation repeated with more jitter)
+            self.n_jitter_retries += 1
 
     def objective_function(self):
         self._ensure(False)
@@ -691,6 +753,8 @@ class GPRegression:
             if self._fail_count >= self._allowed_failures:
                 raise
             self._fail_count += 1
+            with self._evals_lock:
+                self.n_failed_evals += 1
             stale = getattr(self, "_last_good_grad", None)
             if stale is None or len(stale) != len(x):
                 stale = np.zeros_like(x)
@@ -740,14 +804,18 @@ class GPRegression:
         self.optimization_runs.append(run)
         return run
 
-    def _stateless_objective_gen(self, free, counter=None):
+    def _stateless_objective_gen(self, free, counter=None, carry=False):
         """-> f_gen(x): the NLML and its optimizer-space gradient at x as a GENERATOR that does not evaluate anything itself: it yields
         the engine evaluations it needs -- (theta, noise, jitter) -- and is sent their results (nlml, grad), or has the engine's
         NotPositiveDefinite thrown in (GPy's jitter retries: up to five more requests); its return value is (f, g).  Nothing of the
         model's Param objects is touched (free = the parameters x stands for; every other parameter keeps the value it has NOW).
         Whoever drives the generator decides how the requests are evaluated: one by one on an engine handle (`_stateless_objective`)
         or, for several runs in lock step, in one batched pass per round (`LockstepLane`).  `counter`: a one-element list that
-        counts the engine evaluations asked for."""
+        counts the engine evaluations asked for.  `carry`: the failed-evaluation state -- consecutive failures and the last good
+        gradient -- lives ON THE MODEL (`_fail_count`, `_last_good_grad`), as paramz keeps it, so that it persists across the
+        model's own SEQUENTIAL runs (optimize(), first run -> restart 0, the sequential order of the restarts); a randomized restart
+        that runs beside others (lock step, background handles) keeps the state per run -- its order among the others is not
+        defined, a shared count would not be either."""
         # index tables built once: the per-evaluation work is a handful of small-array operations (it runs under the GIL, beside
         # the other runs of a lock-stepped fit: every microsecond here is GPU idle time times the number of runs)
         params = self.parameters()
@@ -759,6 +827,9 @@ class GPRegression:
         noise_idx = pos[id(self.likelihood.variance)]
         shared = len(set(theta_idx.tolist())) != len(theta_idx)      # a Param object used by several factors: gradients add up
         state = {"fails": 0, "g": None}
+        if carry:
+            stale0 = getattr(self, "_last_good_grad", None)
+            state = {"fails": int(self._fail_count), "g": stale0 if stale0 is not None and len(stale0) == len(free) else None}
 
         def f_gen(x):
             vals = base.copy()
@@ -778,6 +849,7 @@ class GPRegression:
                         break
                     except NotPositiveDefinite:
                         self._count_eval()
+                        self._count_retry()
                         if counter is not None:
                             counter[0] += 1
                         tries += 1
@@ -786,10 +858,16 @@ class GPRegression:
                             raise np.linalg.LinAlgError("not positive definite, even with jitter.")
                         jitter_extra = diag_mean * 1e-6 * 10 ** (tries - 1)
                 state["fails"] = 0
+                if carry:
+                    self._fail_count = 0
             except (np.linalg.LinAlgError, ZeroDivisionError, ValueError):
                 if state["fails"] >= self._allowed_failures:
                     raise
                 state["fails"] += 1
+                if carry:
+                    self._fail_count = state["fails"]
+                with self._evals_lock:
+                    self.n_failed_evals += 1
                 stale = state["g"] if state["g"] is not None else np.zeros_like(pv)
                 return _F_FAILED, np.clip(stale, -_G_CLIP_FAILED, _G_CLIP_FAILED)
             acc = np.zeros(len(params))
@@ -800,6 +878,8 @@ class GPRegression:
             acc[noise_idx] = g[-1]
             gf = _logexp_gradfactor(pv, acc[free_idx])
             state["g"] = gf
+            if carry:
+                self._last_good_grad = gf
             return nlml, np.clip(gf, -1e100, 1e100)
 
         return f_gen
@@ -826,11 +906,11 @@ class GPRegression:
 
         return f_fp
 
-    def _run_gen(self, free, x0, max_iters, counter=None):
+    def _run_gen(self, free, x0, max_iters, counter=None, carry=False):
         """one L-BFGS-B run (scipy's core by reverse communication: lbfgsb.Lbfgsb; controls, `eval_cap` and result as
         fmin_l_bfgs_b(f_fp, x0, maxfun = maxiter = max_iters) behind `_capped`) as a generator of engine evaluation requests;
         returns (x_opt, f_opt, task)"""
-        f_gen = self._stateless_objective_gen(free, counter)
+        f_gen = self._stateless_objective_gen(free, counter, carry)
         run = _lbfgsb.Lbfgsb(x0, maxfun=int(max_iters), maxiter=int(max_iters))
         cap, n = self.eval_cap, 0
         best_f, best_x = np.inf, np.array(x0, dtype=np.float64)
@@ -951,7 +1031,7 @@ class GPRegression:
         if x0.size == 0:
             return
         counter = [0]
-        x_opt, f_opt, task = yield from self._run_gen(self._free_params(), x0, max_iters, counter)
+        x_opt, f_opt, task = yield from self._run_gen(self._free_params(), x0, max_iters, counter, carry=True)
         self.optimizer_array = x_opt
         self._main_evals += counter[0]
         run = _OptRun(x_opt, f_opt, counter[0], task)

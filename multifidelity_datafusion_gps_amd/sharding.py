@@ -182,7 +182,12 @@ class ShardGroup:
             return fn()
         finally:
             model._eval_hook = None
-            self.engine.sharded_release()
+            # a pass that failed after the group had been told to start it has aborted the communicator (mfgp_comm_state -1): the
+            # followers are somewhere inside that pass and a release would be one more collective nobody matches.  The exception
+            # propagates, the rank ends with an error and its launcher stops the peers (bench.launch_ranks / torchrun); a follower
+            # left alone gives up after MFGP_SHARD_TIMEOUT_S on its own.
+            if not getattr(self.engine, "comm_aborted", False):
+                self.engine.sharded_release()
 
 
 class RcclInitError(RuntimeError):
@@ -598,29 +603,29 @@ class TorchComm:
 
 def eval_rowblock_allgather(engine, comm, theta, noise, jitter=1e-8, want_grad=True):
     """One objective(+gradient) evaluation with the K(X,X) build sharded by row blocks:
-    rank r builds its block of full rows of Ky on its GPU, the blocks are all-gathered IN PLACE in every rank's device
-    matrix -- ncclAllGather over xGMI inside the library when the engine carries an RCCL communicator
-    (comm.attach_engine), through host memory and the communicator's object gather otherwise (multi-process tests on
-    a one-GPU box) -- then every rank factorises (the Cholesky itself does not shard at these sizes).
-    Needs the padded size to split into equal 64-row multiples per rank; falls back to the local build otherwise.
-    At N = 8192 on 8 GPUs each rank receives 470 MB to save < 0.15 ms of local K-build: this path is provided
+    every rank builds the full rows of ITS 128-row blocks of Ky on its GPU (serpentine block-cyclic deal, `Engine.row_block_owner`:
+    every rank's blocks hold the same share of the lower triangle), the blocks are all-gathered into every rank's device matrix
+    -- inside the library when the engine carries an RCCL communicator (comm.attach_engine): the lower part of each block packed
+    by owner, ONE ncclAllGather over xGMI, 4 Np^2 bytes in all; through host memory and the communicator's object gather
+    otherwise (multi-process tests on a one-GPU box) -- then every rank factorises (the Cholesky itself does not shard at these
+    sizes).  At N = 8192 on 8 GPUs each rank still receives 235 MB to save < 0.15 ms of local K-build: this path is provided
     because the layout is what a DISTRIBUTED factorisation would start from, not because it is faster here."""
     _, npad = engine.dev_matrix()
     size, rank = comm.size, comm.rank
     if size == 1:
         engine.kbuild_rows(theta, noise, jitter, 0, npad)
         return engine.eval_prebuilt(want_grad)
-    if npad % (64 * size) != 0:
-        return engine.eval(theta, noise, jitter, want_grad)
-    rows = npad // size
-    engine.kbuild_rows(theta, noise, jitter, rank * rows, (rank + 1) * rows)
+    engine.kbuild_owned_rows(theta, noise, jitter, rank, size)
     if getattr(comm, "_engine", None) is engine and engine.comm_size == size:
         engine.allgather_rows()
     else:
-        blocks = comm.allgather_object(engine.rows_download(rank * rows, (rank + 1) * rows))
-        for r, block in enumerate(blocks):
+        nblk = npad // 128
+        mine = [b for b in range(nblk) if engine.row_block_owner(b, size) == rank]
+        blocks = comm.allgather_object([(b, engine.rows_download(128 * b, 128 * (b + 1))) for b in mine])
+        for r, owned in enumerate(blocks):
             if r != rank:
-                engine.rows_upload(r * rows, block)
+                for b, block in owned:
+                    engine.rows_upload(128 * int(b), block)
     return engine.eval_prebuilt(want_grad)
 
 

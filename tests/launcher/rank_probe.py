@@ -24,7 +24,8 @@ try:
     comm.barrier()      # with a failed rank the others wait here until the launcher stops them, or lose their peer
 except ConnectionError:
     sys.exit(4)         # bench.EXIT_PEER_LOST, as bench.py's own ranks do
+evals = comm.allgather_object(int(res["evals"]))     # high-fidelity evaluations each rank issued (its restarts, the chain on rank 0)
 if rank == 0:
     print(json.dumps({"seen": seen, "mean_sum": float(res["mean"].sum()), "var_sum": float(res["var"].sum()),
-                      "theta": res["theta"].tolist()}), flush=True)
+                      "theta": res["theta"].tolist(), "hf_evals_per_rank": evals}), flush=True)
 comm.close()

@@ -37,6 +37,22 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Counters) == 19 * 8     # + timed_evals, timed_predict_var_flops
 
 
+def test_row_block_ownership_balances_the_lower_triangle():
+    """mfgp_row_block_owner (pure host function of the C-ABI, no device): serpentine block-cyclic 0 1 .. G-1 G-1 .. 1 0 ..; the packed
+    LOWER parts of every rank's blocks -- what mfgp_allgather_rows moves -- are equal to within a few blocks, so the padded
+    all-gather carries ~ half the bytes of full rows (at the bench size on 8 ranks: 0.508)"""
+    from multifidelity_datafusion_gps_amd._lib import Engine
+    own = Engine.row_block_owner
+    assert [own(b, 3) for b in range(8)] == [0, 1, 2, 2, 1, 0, 0, 1] and own(5, 1) == 0 and own(-1, 4) == -1
+    for nblk, size in ((64, 8), (64, 3), (32, 2), (128, 6)):
+        fill = [0] * size
+        for b in range(nblk):
+            fill[own(b, size)] += 128 * 128 * (b + 1)
+        moved = size * max(fill)                                  # doubles in the padded all-gather
+        full = (128 * nblk) ** 2                                  # doubles of full rows
+        assert 0.5 <= moved / full <= 0.5 + 1.5 * size / nblk, (nblk, size, moved / full)
+
+
 def test_no_cpu_fallback_engine_fails_loudly_without_gpu():
     if os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present")

@@ -32,6 +32,25 @@ def test_launcher_starts_one_rank_per_gpu_with_the_rendezvous_environment():
     assert abs(line["mean_sum"] - float(ref["mean"].sum())) < 1e-5 and abs(line["var_sum"] - float(ref["var"].sum())) < 1e-5
 
 
+def test_eight_rank_job_is_the_single_process_job():
+    """the size BASELINE.json's metric names (1/2/4/8 GPU), rehearsed on the CPU: 8 ranks over the launcher and the TCP rendezvous
+    (a one-GPU box admits at most 6 processes on its card, so the GPU rehearsal stops at 6 ranks: profiles/r05_bench_n6_*).  Restart
+    layout of AbstractMFGP.assign_restarts at 8 ranks: the chain (first run -> restart 0) on rank 0, no optimiser run on ranks 1-2,
+    one randomized restart each on ranks 3-7; every rank ends with the single process's winner and its share of the predictive rows."""
+    from multifidelity_datafusion_gps_amd.sharding import LocalComm
+    from tests.test_sharding_gloo import _run_model
+    r = _launch(8, [])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [s["rank"] for s in line["seen"]] == list(range(8)) and all(s["world"] == 8 for s in line["seen"])
+    ref = _run_model(LocalComm(), 2)
+    np.testing.assert_allclose(line["theta"], ref["theta"], rtol=1e-12)
+    assert abs(line["mean_sum"] - float(ref["mean"].sum())) < 1e-5 and abs(line["var_sum"] - float(ref["var"].sum())) < 1e-5
+    ev = line["hf_evals_per_rank"]
+    # ranks 1-2 adopt the winner (one factorisation at it, perhaps a lazy re-evaluation); ranks 3-7 ran one restart each; rank 0 the chain
+    assert max(ev[1:3]) <= 3 and min(ev[3:]) > 3 and ev[0] > max(ev[3:]) and sum(ev) <= ref["evals"] + 3 * 8, ev
+
+
 def test_launcher_reports_a_failed_rank_and_stops_the_others():
     r = _launch(2, ["1"])
     assert r.returncode == 7

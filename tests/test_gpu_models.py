@@ -225,6 +225,75 @@ def test_concurrent_and_lockstep_restarts_give_the_sequential_result(n_hf):
         assert np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4]), mode
 
 
+def test_batch_memory_policy_on_the_device(monkeypatch, engine_cls):
+    """VERDICT r4 #4 on the GPU.  (1) mfgp_eval_batch answers a request beyond MFGP_BATCH_MEM_CAP (read by ensure_batch) with its OWN
+    status -- EngineOutOfMemory, not a HIP error -- and leaves the handle usable: the sets it held, single evaluations, predictions.
+    (2) a fit sizes its passes from mfgp_mem_info / mfgp_batch_mem and narrows them further when the allocation fails anyway: the same
+    fitted parameters, runs and evaluation counts at 6, 2 and 0 sets per pass (0: request by request on the handle's own slab)."""
+    import multifidelity_datafusion_gps_amd as mf
+    from multifidelity_datafusion_gps_amd._lib import EngineOutOfMemory
+    rng = np.random.default_rng(8)
+    X_hf = rng.uniform(size=(600, 2))                                  # Np = 640: one matrix set of a batch = 4 * 640^2 * 8 B
+    e = engine_cls(0)
+    Xa = np.hstack([X_hf, lf2(X_hf)])
+    e.set_data(Xa, hf2(X_hf)[:, 0]); e.set_kernel(cases.composite(2, 1))
+    per, cap0, held0 = e.batch_mem(1)
+    free, total = e.mem_info()
+    assert 4 * 640 * 640 * 8 <= per <= 4.2 * 640 * 640 * 8 and cap0 == 0 and held0 == 0 and 0 < free <= total
+    th = np.tile([1.1, 0.9, 0.8, 0.3, 0.5, 0.7], (6, 1)) * np.linspace(0.9, 1.1, 6)[:, None]
+    f6, g6, st6 = e.eval_batch(th, np.full(6, 0.02))
+    assert e.batch_mem(1)[2] == 6 and not st6.any()
+    monkeypatch.setenv("MFGP_BATCH_MEM_CAP", str(int(2.5 * per)))
+    assert e.batch_mem(1)[1] == int(2.5 * per) and e.batch_sets_that_fit() == 2
+    f2, g2, st2 = e.eval_batch(th[:2], np.full(2, 0.02))               # within what the handle holds already: no allocation, no cap
+    assert np.array_equal(f2, f6[:2]) and np.array_equal(g2, g6[:2])
+    e2 = engine_cls(0)
+    e2.set_data(Xa, hf2(X_hf)[:, 0]); e2.set_kernel(cases.composite(2, 1))
+    with pytest.raises(EngineOutOfMemory):
+        e2.eval_batch(th, np.full(6, 0.02))
+    f1, g1 = e2.eval(th[3], 0.02)                                      # the handle is usable: single evaluation, a batch that fits, predict
+    assert f1 == f6[3] and np.array_equal(g1, g6[3])
+    fb, gb, _ = e2.eval_batch(th[:2], np.full(2, 0.02))
+    assert np.array_equal(fb, f6[:2]) and e2.batch_mem(1)[2] == 2
+    with pytest.raises(EngineOutOfMemory):
+        e2.eval_batch(th[:3], np.full(3, 0.02))
+    assert e2.batch_mem(1)[2] == 2                                     # a refused request leaves the sets the handle held
+    fb2, _, _ = e2.eval_batch(th[:2], np.full(2, 0.02))
+    assert np.array_equal(fb2, f6[:2])
+    m_, v_ = e2.predict(Xa[:5])
+    assert np.all(np.isfinite(m_)) and np.all(v_ > 0)
+    e.close(); e2.close()
+    monkeypatch.delenv("MFGP_BATCH_MEM_CAP")
+    out = {}
+    for mode, cap_sets, width in (("free", None, None), ("sized to 2", 2.5, None), ("sized to 0", 0.5, None),
+                                  ("asked for 6 against a cap of 2", 2.5, 6)):
+        if cap_sets is None:
+            monkeypatch.delenv("MFGP_BATCH_MEM_CAP", raising=False)
+        else:
+            monkeypatch.setenv("MFGP_BATCH_MEM_CAP", str(int(cap_sets * per)))
+        model = mf.NARGP(2, hf2, lf2, seed=5)
+        model.first_run_max_iters = model.restart_max_iters = 40
+        model.eval_cap = 12
+        model.lockstep_lanes = 1
+        if width:                                                      # the sizing bypassed: the lane meets the refusal itself
+            model._lane_budgets = lambda engines, slots: [width]
+        model.fit(X_hf)
+        info = model.last_fit_info
+        runs = sorted((r.f_opt, tuple(r.x_opt)) for r in model.hf_model.optimization_runs)
+        out[mode] = (np.array([p.value for p in model.hf_model.parameters()]), runs, model.hf_model.n_evals, info,
+                     max(model.last_lockstep_lanes[0].round_sizes))
+        model.close()
+    ref = out["free"]
+    assert ref[3]["sets_per_pass"] == [6] and ref[3]["oom_fallbacks"] == [[]] and ref[3]["driver"] == "lbfgsb-generators"
+    assert out["sized to 2"][3]["sets_per_pass"] == [2] and out["sized to 0"][3]["sets_per_pass"] == [0]
+    assert out["sized to 2"][3]["oom_fallbacks"] == [[]] and out["sized to 0"][3]["oom_fallbacks"] == [[]]
+    forced = out["asked for 6 against a cap of 2"][3]
+    assert forced["oom_fallbacks"][0][:2] == [(6, 3), (3, 2)] and forced["sets_per_pass_used"] == [2], forced
+    for mode, got in out.items():
+        assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2], mode
+        assert got[4] == 6, mode                                       # every round still holds all six live runs
+
+
 def test_batched_evaluation_is_bitwise_the_single_evaluation(engine):
     """mfgp_eval_batch (B matrix sets side by side in every launch of the sweep) against B mfgp_eval calls: bitwise, at sizes on
     both sides of the planner's regimes (one leaf, single macro panel, two streams, slim chain); a set whose Ky is not positive

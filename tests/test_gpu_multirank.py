@@ -142,7 +142,7 @@ def _rccl_worker(rank, world, port, q):
         # ncclBroadcast of the rows + ncclAllReduce of the gradient's tile sums): bitwise the single evaluation, at a size with
         # several macro panels and at the north-star size
         res["eval_sharded"] = {}
-        for n in (2100, 8192):
+        for n in ((2100, 8192) if world <= 3 else (2100,)):
             rng = np.random.default_rng(n)
             X = rng.uniform(size=(n, 4))
             Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
@@ -166,7 +166,7 @@ def _rccl_worker(rank, world, port, q):
         comm.barrier()
         f1, g1 = e.eval_sharded(thg, nz, 1e-8)
         m1, v1 = e.predict(Xa[:100])
-        res["eval_sharded"]["matern_ard_8192"] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), nograd=(0.0, 0.0))
+        res["eval_sharded"]["matern_ard_%d" % len(Y)] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), nograd=(0.0, 0.0))
         comm.barrier()
         e.comm_destroy()                                   # every rank still alive
         comm.barrier()
@@ -176,11 +176,12 @@ def _rccl_worker(rank, world, port, q):
         comm.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 6])
 def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
     """A REAL RCCL communicator with more than one rank ("an RCCL collective with >= 2 ranks has never executed
     anywhere"): mfgp_comm_unique_id on rank 0 -> TCP -> mfgp_comm_init on every rank, then mfgp_allgather_rows (ONE
-    in-place ncclAllGather on the device matrix) and mfgp_allgather_host between the processes."""
+    in-place ncclAllGather on the device matrix) and mfgp_allgather_host between the processes.  world = 6 is the most a one-GPU box
+    admits on its card (process guard); the 8-rank layout runs on the CPU (tests/test_bench_launcher.py) and in the driver's job."""
     from multifidelity_datafusion_gps_amd.sharding import LocalComm
     ref = _model_run(LocalComm(), 1)
     ref_r2 = _model_run(LocalComm(), 1, restarts=2)
@@ -277,3 +278,72 @@ def test_rccl_calls_with_a_communicator_of_one(engine):
     f2, g2 = eval_rowblock_allgather(engine, comm, theta, noise)
     assert f2 == f0 and np.array_equal(g2, g0)
     engine.comm_destroy()
+
+
+def _failing_leader_worker(rank, port, q):
+    import os
+    import sys
+    import time
+    from multifidelity_datafusion_gps_amd import sharding
+    os.environ.update(sharding.rehearsal_env(rank))
+    os.environ["MFGP_SHARD_TIMEOUT_S"] = "6"               # a follower whose leader is gone gives up after this long
+    from multifidelity_datafusion_gps_amd import engine as gp
+    from multifidelity_datafusion_gps_amd._lib import Engine
+    comm = sharding.SocketComm(rank, 2, "127.0.0.1", port, timeout=120)
+    e = Engine(0)
+    comm.attach_engine(e, required=True, init_timeout=90)
+    rng = np.random.default_rng(5)
+    X = rng.uniform(size=(700, 2))
+    m = gp.GPRegression(X, cases.hf_2d(X)[:, None], kernel=gp.RBF(2), engine=e)
+    group = comm.shard_group(e, [0, 1])
+    assert group is not None and group.size == 2
+    comm.barrier()
+    t0 = time.perf_counter()
+    res = {"rank": rank}
+    try:
+        if group.leads:
+            e.dbg_fail_sharded_after(3)                    # the third evaluation of the run fails AFTER the followers were told to start it
+        group.run(m, (lambda: m.optimize(max_iters=10)) if group.leads else None)
+        res["error"] = None
+    except RuntimeError as ex:
+        res["error"] = str(ex)
+    res["seconds"] = time.perf_counter() - t0
+    res["aborted"] = bool(e.comm_aborted)
+    res["evals"] = int(m.n_evals)
+    if group.leads:
+        try:                                               # a further collective on the poisoned handle is REFUSED, not enqueued
+            e.sharded_release()
+            res["release"] = "issued"
+        except RuntimeError as ex:
+            res["release"] = str(ex)
+    q.put((rank, res))
+    sys.stdout.flush()
+    os._exit(7 if res["error"] else 0)                     # (the rank ends with an error: its launcher would stop the peers)
+
+
+def test_a_leader_that_fails_inside_a_shared_pass_ends_the_group_instead_of_hanging_it():
+    """the leader of a shared evaluation fails after the control block told the follower to start the pass.  It must
+    not issue another collective (the release would never be matched): its communicator is aborted, ShardGroup.run skips the
+    release, the exception ends the rank -- and the follower, left inside the pass, gives up after MFGP_SHARD_TIMEOUT_S with an
+    error of its own instead of waiting for ever."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_leader_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        out = dict(q.get(timeout=240) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    lead, foll = out[0], out[1]
+    assert "injected failure" in lead["error"] and "communicator was aborted" in lead["error"], lead
+    assert lead["aborted"] and lead["evals"] <= 3 and lead["seconds"] < 30, lead
+    assert "aborted" in lead["release"] and lead["release"] != "issued", lead
+    assert foll["error"] is not None and foll["aborted"] and foll["seconds"] < 60, foll
+    assert [p.exitcode for p in procs] == [7, 7]

@@ -166,3 +166,105 @@ def test_reverse_communication_driver_on_random_functions_and_budgets():
         assert np.array_equal(xa, xb, equal_nan=True) and same_f, (case, n, budget, kind)
         assert (da["funcalls"], da["nit"], da["warnflag"], da["task"]) == (db["funcalls"], db["nit"], db["warnflag"], db["task"]), (case, kind)
         assert len(sa) == len(sb) and all(np.array_equal(p, q, equal_nan=True) for p, q in zip(sa, sb)), (case, kind)
+
+
+class _TightEngine(BatchOracleEngine):
+    """the CPU double with a device-memory budget: eval_batch raises EngineOutOfMemory for more sets than `sets_that_fit`; mem_info /
+    batch_mem answer what the HIP engine's would (1 byte per set)"""
+    sets_that_fit = 16
+    advertised_free = 1 << 40
+    MAX_BATCH = 16
+
+    def __init__(self):
+        super().__init__()
+        self.passes = []
+
+    def eval_batch(self, thetas, noises, jitters=1e-8, want_grad=True):
+        from multifidelity_datafusion_gps_amd._lib import EngineOutOfMemory
+        B = len(np.atleast_2d(thetas))
+        if B > self.sets_that_fit:
+            raise EngineOutOfMemory("mfgp_eval_batch: out of device memory for %d matrix sets" % B)
+        self.passes.append(B)
+        return super().eval_batch(thetas, noises, jitters, want_grad)
+
+    def eval(self, theta, noise, jitter=1e-8, want_grad=True):
+        self.passes.append(0)
+        return super().eval(theta, noise, jitter, want_grad)
+
+    def mem_info(self):
+        return self.advertised_free, 1 << 41
+
+    def batch_mem(self, sets):
+        return int(sets), 0, 0
+
+
+def _tight_fit(fit, free, width=None):
+    E = type("E", (_TightEngine,), dict(sets_that_fit=fit, advertised_free=free))
+    M = type("M", (mf.NARGP,), dict(first_run_max_iters=25, restart_max_iters=25, restart_lockstep=True, lockstep_lanes=1,
+                                    lockstep_width=width, memory_reserve=staticmethod(lambda e: 0)))
+    engines = {k: E() for k in ("hf", "lf")}
+    m = M(2, col(cases.hf_2d), col(cases.lf_2d), seed=3, engines=engines)
+    m.fit(np.random.default_rng(1).uniform(size=(40, 2)))
+    theta = np.array([p.value for p in m.hf_model.parameters()])
+    runs = sorted((round(r.f_opt, 12), tuple(np.round(r.x_opt, 12))) for r in m.hf_model.optimization_runs)
+    return theta, runs, m.hf_model.n_evals, m.last_fit_info, [p for p in engines["hf"].passes]
+
+
+def test_batch_memory_policy_narrows_the_passes_and_keeps_the_fit():
+    """the width of a batched pass follows the device's free memory -- sized BEFORE asking (mem_info / batch_mem),
+    halved WHEN the engine answers out-of-memory anyway, request by request at the end -- and the fit does not change by a bit."""
+    ref = _tight_fit(16, 1 << 40)
+    assert ref[3]["driver"] == "lbfgsb-generators" and ref[3]["sets_per_pass"] == [6] and ref[3]["oom_fallbacks"] == [[]]
+    assert max(ref[4]) == 6
+    # (1) sized from what the device reports free: 2 sets, then none (single evaluations on the handle's own slab)
+    for free, widest in ((2, 2), (0, 0)):
+        got = _tight_fit(16, free)
+        assert got[3]["sets_per_pass"] == [free] and got[3]["oom_fallbacks"] == [[]]
+        assert max(got[4][1:]) == widest, (free, sorted(set(got[4])))      # ([0]: the LF level's own evaluations come first)
+        assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]
+    # (2) the device reports room but the allocation fails (another process took it): 6 -> 3 -> 2 -> 1 sets on out-of-memory answers
+    for fit, used, steps in ((3, 3, [(6, 3)]), (2, 2, [(6, 3), (3, 2)]), (0, 1, [(6, 3), (3, 2), (2, 1)])):
+        got = _tight_fit(fit, 1 << 40)
+        assert got[3]["sets_per_pass"] == [6] and got[3]["sets_per_pass_used"] == [used], got[3]
+        assert got[3]["oom_fallbacks"][0][:len(steps)] == steps, got[3]
+        assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]
+
+
+def test_failed_evaluation_state_persists_across_a_models_sequential_runs():
+    """paramz keeps the count of consecutive failed evaluations and the last good gradient ON THE MODEL, across the
+    optimize() calls of a fit.  A second optimize() whose FIRST evaluation fails is answered with the first run's last good gradient
+    (not zeros), on the fast path (run generator) exactly as through the model's own objective."""
+    class FailsOnce(BatchOracleEngine):
+        fail_eval = None
+
+        def eval(self, theta, noise, jitter=1e-8, want_grad=True):
+            if self.n_evals + 1 == self.fail_eval:
+                self.n_evals += 1
+                raise ValueError("engine refused the evaluation")
+            return super().eval(theta, noise, jitter, want_grad)
+
+    rng = np.random.default_rng(2)
+    X = rng.uniform(size=(30, 2))
+    Y = np.sin(5.0 * X[:, :1]) * X[:, 1:2]
+    ends = {}
+    for fast in (True, False):
+        m = gp.GPRegression(X, Y, kernel=gp.RBF(2, ARD=True), engine=FailsOnce())
+        m.fast_optimize = fast
+        r1 = m.optimize(max_iters=15)
+        good = np.array(m._last_good_grad)
+        m._engine.fail_eval = m._engine.n_evals + 1          # the first evaluation of the next run
+        seen = []
+        orig = gp._lbfgsb.Lbfgsb.tell
+
+        def tell(self_, f, g, _seen=seen, _orig=orig):
+            _seen.append((float(f), np.array(g)))
+            return _orig(self_, f, g)
+        gp._lbfgsb.Lbfgsb.tell = tell
+        try:
+            r2 = m.optimize(max_iters=15)
+        finally:
+            gp._lbfgsb.Lbfgsb.tell = orig
+        assert seen[0][0] == gp._F_FAILED and np.array_equal(seen[0][1], good), fast      # the previous run's gradient, not zeros
+        assert m.n_failed_evals == 1 and m._fail_count == 0
+        ends[fast] = (r1.x_opt, r1.f_opt, r2.x_opt, r2.f_opt, r2.n_evals, m.n_evals)
+    assert all(np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b for a, b in zip(ends[True], ends[False]))

@@ -38,6 +38,15 @@ rehearsal)
     last_json $out/bench_n$n.json
   done
   ;;
+pick)
+  # selected tests, each group under its own timeout; PICK="file::test ..." (space separated pytest node ids / -k expressions are not split)
+  for t in ${PICK:?}; do
+    name=$(echo "$t" | tr '/:[]' '____')
+    timeout -k 10 ${PICK_TIMEOUT:-600} python -m pytest "$t" -m gpu -x -q -s > $out/$name.log 2>&1; rc=$?
+    tail -6 $out/$name.log
+    [ $rc -eq 0 ] || exit $rc
+  done
+  ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > $out/tests.log 2>&1; rc=$?; tail -15 $out/tests.log; exit $rc
   ;;
