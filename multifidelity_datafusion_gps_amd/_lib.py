@@ -409,6 +409,7 @@ class Engine:
 
     def comm_destroy(self):
         self._check(self._lib.mfgp_comm_destroy(self._h), "mfgp_comm_destroy")
+        self.comm_rank, self.comm_size = 0, 1
 
     @property
     def comm_aborted(self):

@@ -179,11 +179,22 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
             return None
         if getattr(self.comm, "transport", None) != "rccl":
             return None                    # (the collectives of a shared evaluation are RCCL's; a TCP-only job keeps rank 0's own runs)
-        key = (id(model._engine), tuple(members))
-        cache = self.__dict__.setdefault("_shard_groups", {})
-        if key not in cache:
-            cache[key] = self.comm.shard_group(model._engine, members)
-        return cache[key]
+        # keyed by the engine OBJECT (kept in the entry and compared with `is`: an id() may be reused once a handle is closed and
+        # replaced) -- the call is collective, so a group that could not be formed is remembered too (every rank asks again at the
+        # same point or none does), but it is said once, and close() forgets everything
+        cache = self.__dict__.setdefault("_shard_groups", [])
+        for eng, mem, group in cache:
+            if eng is model._engine and mem == tuple(members):
+                return group
+        group = self.comm.shard_group(model._engine, members)
+        cache.append((model._engine, tuple(members), group))
+        if group is None and not self.__dict__.get("_shard_group_warned"):
+            self.__dict__["_shard_group_warned"] = True
+            import warnings
+            warnings.warn("multi-GPU: the ranks %s could not form an RCCL group on this level's engine (%s): its sequential evaluations "
+                          "run on rank 0 alone" % (list(members), getattr(self.comm, "rccl_error", None) or "no reason recorded"),
+                          RuntimeWarning, stacklevel=2)
+        return group
 
     def _lf_posterior_mean(self, t):
         """f_low of a data-driven level: the CURRENT low-fidelity GP's posterior mean (mean only: the O(N^2 N*) variance
@@ -545,6 +556,15 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
     plot = plot_forecast = plot_uncertainties_2D = plot_compare_with_exact = _no_plot      # the reference's public plot methods
 
     def close(self):
+        # the communicators of the groups this object formed (collective: every member of a group closes); the world communicator
+        # attached by comm.attach_engine is the caller's, as the engines passed in from outside are
+        for eng, _, group in self.__dict__.pop("_shard_groups", []):
+            if group is not None and getattr(eng, "comm_size", 1) > 1 and eng is not getattr(self.comm, "_engine", None) \
+                    and not getattr(eng, "comm_aborted", False):
+                try:
+                    eng.comm_destroy()
+                except Exception:  # noqa: BLE001 - closing: a handle that is already gone
+                    pass
         for e in self._engines.values():
             e.close()
         self._engines = {}

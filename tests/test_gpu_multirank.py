@@ -45,7 +45,7 @@ def _model_run(comm, conc, restarts=6):
     mean, var = model.predict(rng.uniform(size=(333, 2)))
     theta = np.array([p.value for p in model.hf_model.parameters()])
     evals = model.hf_model.n_evals
-    groups = sorted((g.size, g.index) for g in getattr(model, "_shard_groups", {}).values() if g is not None)
+    groups = sorted((g.size, g.index) for _, _, g in getattr(model, "_shard_groups", []) if g is not None)
     # cfg5's panel form: one predictive-variance panel per acquisition, its rows sharded over the ranks and gathered; every
     # rank must acquire the same point
     model.adapt_maximizer = mf.adaptation_maximizers.PanelMaximizer(n_candidates=4096, seed=5)
@@ -317,7 +317,10 @@ def _failing_leader_worker(rank, port, q):
         except RuntimeError as ex:
             res["release"] = str(ex)
     q.put((rank, res))
-    sys.stdout.flush()
+    q.close()
+    q.join_thread()                                        # (the queue's feeder thread must have written the item before the hard exit)
+    sys.stderr.write("rank %d: %s\n" % (rank, res))
+    sys.stderr.flush()
     os._exit(7 if res["error"] else 0)                     # (the rank ends with an error: its launcher would stop the peers)
 
 
@@ -335,10 +338,10 @@ def test_a_leader_that_fails_inside_a_shared_pass_ends_the_group_instead_of_hang
     for p in procs:
         p.start()
     try:
-        out = dict(q.get(timeout=240) for _ in procs)
+        out = dict(q.get(timeout=150) for _ in procs)
     finally:
         for p in procs:
-            p.join(timeout=60)
+            p.join(timeout=30)
             if p.is_alive():
                 p.kill()
     lead, foll = out[0], out[1]

@@ -47,6 +47,62 @@ pick)
     [ $rc -eq 0 ] || exit $rc
   done
   ;;
+profile)
+  # the round's profiles (copied into profiles/ afterwards).  Every rocprofv3 line: the program directly after "--", PMC passes with
+  # --kernel-trace only, power sampling off (bench.py samples power only with --power, and never under a profiler).
+  R=$GRAFT_REPO_ROOT; out=$R/$out; export TMPDIR=/tmp; cd /tmp
+  echo "== bench kernel stats"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_stats -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/bench_profiled.json 2> $out/bench_profiled.err
+  f=$(find $out/bench_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/bench_kernel_stats.csv && head -14 $out/bench_kernel_stats.csv
+  rm -rf $out/bench_stats
+  echo "== one evaluation, kernel trace"
+  for n in ${TRACE_SIZES:-4096 8192}; do
+    timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace_$n -- python3 $R/tools/time_eval.py $n > $out/trace_$n.log 2>&1
+    (cd $R && python3 tools/chain_account.py $out/trace_$n > $out/chain_account_$n.txt 2>&1; python3 tools/trace_timeline.py $out/trace_$n 0 400 > $out/timeline_$n.txt 2>&1; python3 tools/plan_flops.py $((n/128)) $out/timeline_$n.txt > $out/plan_flops_$n.txt 2>&1)
+    cat $out/chain_account_$n.txt; tail -3 $out/plan_flops_$n.txt
+    rm -rf $out/trace_$n
+  done
+  echo "== one batched pass (N = 8192, B = 4; N = 4096, B = 4), kernel trace"
+  for nb in "8192 4" "4096 4"; do set -- $nb
+    timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace_b_$1 -- python3 $R/tools/batch_trace.py $1 $2 3 > $out/trace_b_$1.log 2>&1
+    python3 $R/tools/trace_last_pass.py $out/trace_b_$1 400 > $out/timeline_batch_$1_B$2.txt 2>&1; head -10 $out/timeline_batch_$1_B$2.txt
+    rm -rf $out/trace_b_$1
+  done
+  echo "== PMC passes: HBM traffic"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 $R/tools/time_eval.py 8192 > $out/pmc_$c.log 2>&1
+    f=$(find $out/pmc_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmc_${c}_time_eval_8192.csv
+    rm -rf $out/pmc_$c
+  done
+  (cd $R && python3 tools/pmc_summary.py 8192 $out/pmc.json FETCH_SIZE=$out/pmc_FETCH_SIZE_time_eval_8192.csv WRITE_SIZE=$out/pmc_WRITE_SIZE_time_eval_8192.csv > $out/pmc_summary.log 2>&1; tail -40 $out/pmc_summary.log)
+  echo "== PMC pass: matrix-pipe busy"
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmcA_eval_d -- python3 $R/tools/time_eval.py 8192 > $out/pmcA_eval.log 2>&1
+  f=$(find $out/pmcA_eval_d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmcA_eval.csv
+  f=$(find $out/pmcA_eval_d -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp $f $out/pmcA_eval_trace.csv
+  rm -rf $out/pmcA_eval_d
+  (cd $R && python3 tools/mfma_counters.py $out $out/mfma_counters.json > $out/mfma_counters.txt 2>&1; python3 -c "
+import json; d=json.load(open('$out/mfma_counters.json'))['pmcA_eval']
+for k,v in d.items(): print('%-28s launches %4d  %8.3f ms  clock %.2f GHz  mfma_busy %.3f (CU-busy basis) %.3f (launch basis)' % (k, v['launches'], v['duration_ms'], v.get('clock_ghz',0), v.get('mfma_busy',0), v.get('mfma_busy_g',0)))")
+  find $out -name "*.csv" -size +6M -delete
+  cd $R
+  ;;
+measure)
+  # the un-profiled records: batched passes, mid-size fits, per-rank share of a sharded evaluation, the BASELINE configurations, small N
+  python3 tools/batch_eval.py 512 1024 2048 4096 8192 > $out/batch_eval.txt 2>&1; cat $out/batch_eval.txt
+  python3 tools/midsize_fit.py 64 128 256 512 1024 2048 4096 > $out/midsize_fit.txt 2>&1; cut -c1-300 $out/midsize_fit.txt
+  python3 tools/midsize_fit.py --evals 20 2048 4096 >> $out/midsize_fit.txt 2>&1; tail -3 $out/midsize_fit.txt | cut -c1-300
+  python3 tools/shard_projection.py 4096 8192 > $out/shard_projection.txt 2>&1; cat $out/shard_projection.txt
+  timeout -k 10 500 python3 tools/run_configs.py > $out/configs.txt 2>&1; cat $out/configs.txt
+  python3 tools/small_n_latency.py > $out/small_n.txt 2>&1; tail -12 $out/small_n.txt
+  ;;
+accept)
+  # what the driver runs at round end: smoke, the whole -m gpu suite, the default bench line (CPU baseline included)
+  timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 || { tail -20 $out/smoke.log; exit 1; }
+  tail -2 $out/smoke.log
+  MFGP_PARITY_ERRORS=$out/parity_errors.json timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; rc=$?; tail -5 $out/tests.log; [ $rc -eq 0 ] || exit $rc
+  timeout -k 10 600 python bench.py > $out/bench.json 2> $out/bench.err || { tail -30 $out/bench.err; exit 1; }
+  last_json $out/bench.json
+  ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > $out/tests.log 2>&1; rc=$?; tail -15 $out/tests.log; exit $rc
   ;;
