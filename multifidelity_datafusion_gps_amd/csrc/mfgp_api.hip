@@ -64,6 +64,24 @@ static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nb
                                        std::to_string(s.role));
             h->launches++;
         }
+    } else if (s.kind == STEP_COMM_DIAG || s.kind == STEP_COMM_PANEL) {
+        // exchange steps of a distributed Cholesky (this rank's plan of a sharded evaluation: never batched); on the main stream,
+        // where the handle's collectives run.  Without a communicator (mfgp_dbg paths) the data simply stays where it is.
+        const int size = h->pls.shard.size, rank = h->pls.shard.rank, c = s.blk, Np = (int)h->Np;
+        if (s.kind == STEP_COMM_DIAG) {
+            const int root = shard_owner(c, size);
+            if (root == rank) launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c, h->ddist, h->dlogdet, h->dinfo, false);
+            if (int rc = comm_bcast_words(h, h->ddist, 2 * (size_t)NB * NB + 2, root, st)) return rc;
+            if (root != rank) launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c, h->ddist, h->dlogdet, h->dinfo, true);
+        } else {
+            std::vector<int> cnt((size_t)size, 0);
+            for (int i = c + 1; i < h->nblk; ++i) cnt[(size_t)shard_owner(i, size)]++;
+            const long long chunk = (long long)*std::max_element(cnt.begin(), cnt.end()) * NB * NB;
+            launch_dist_panel_copy(st, h->buf[BUF_L], Np, h->nblk, c, h->ddist, chunk, rank, size, false);
+            if (int rc = comm_allgather_chunks(h, h->ddist, (size_t)chunk, st)) return rc;
+            launch_dist_panel_copy(st, h->buf[BUF_L], Np, h->nblk, c, h->ddist, chunk, rank, size, true);
+        }
+        h->launches += 2;
     }   // kind 2: join -- the wait above is all there is
     if (s.rec_ev > 0) (void)hipEventRecord(h->evpool[s.rec_ev - 1], st);
     if (s.rec_ev_final > 0) (void)hipEventRecord(h->evpool[s.rec_ev_final - 1], st);
@@ -181,6 +199,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->dtasks_s) hipFree(h->dtasks_s);
     if (h->dshard_off) hipFree(h->dshard_off);
     if (h->drow_off) hipFree(h->drow_off);
+    if (h->ddist) hipFree(h->ddist);
     if (h->dctl) hipFree(h->dctl);
     if (h->hctl) hipHostFree(h->hctl);
     comm_release(h);
@@ -693,6 +712,16 @@ static int ensure_shard_plan(mfgp_handle* h, int rank, int size) {
         fill[(size_t)own] += 128LL * (h->Np - 128LL * b);
     }
     h->shard_chunk = *std::max_element(fill.begin(), fill.end());
+    if (h->pls.shard.dist) {   // one panel column, padded to the largest rank's share, + the diagonal message
+        const size_t need = std::max((size_t)(h->nblk / size + 2) * size * NB * NB, 2 * (size_t)NB * NB + 2);
+        if (need > h->dist_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->ddist) HIPCHK(h, hipFree(h->ddist));
+            h->ddist = nullptr;
+            h->dist_cap = need;
+            HIPCHK(h, hipMalloc(&h->ddist, need * sizeof(double)));
+        }
+    }
     // staging: the workspace matrix W wherever size x chunk fits it (always at sizes worth sharding: the chunks sum to ~Np^2 / 2);
     // a few blocks on many ranks pad beyond that -- then a buffer of its own
     if ((long long)size * h->shard_chunk > (long long)h->cap * h->cap && (size_t)size * (size_t)h->shard_chunk > h->stage_cap) {

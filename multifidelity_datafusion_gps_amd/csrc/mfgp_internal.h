@@ -103,6 +103,11 @@ void launch_mirror_lower(hipStream_t s, double* S, int ld, int Np);
 //   (lower: the part of each 128-row block up to and including its diagonal block instead -- the row blocks of Ky, mfgp_allgather_rows)
 void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* stage, const long long* off, long long chunk,
                             int rank, int size, bool unpack, bool lower = false);
+//   exchange steps of a distributed Cholesky (plan.h Shard::dist): the diagonal blocks + the leaf's words to / from one message; the
+//   blocks of block column c of L below the diagonal to / from the all-gather's buffer (chunk doubles per rank)
+void launch_dist_diag_copy(hipStream_t s, double* L, double* S, int ld, int c, double* stage, double* logdet, int* info, bool unpack);
+void launch_dist_panel_copy(hipStream_t s, double* L, int ld, int nblk, int c, double* stage, long long chunk, int rank, int size,
+                            bool unpack);
 //   nbatch sets: K^-1 of set b at Kinv + b * kstride, alpha + b * astride, partials + b * pstride, out + b * ostride; thetas =
 //   device-readable copy of the sets' parameter vectors, tstride apart (the finishing kernel divides by them)
 void launch_grad_batch(hipStream_t s, const KernSpecDev* specs, int nbatch, const double* X, const double* Kinv, long long kstride,
@@ -185,6 +190,8 @@ struct mfgp_handle {
     long long* drow_off = nullptr;       // mfgp_allgather_rows: offset of every 128-row block's LOWER part inside its owner's chunk
     long long row_chunk = 0;             //   doubles per rank in that all-gather
     int row_off_cap = 0, row_off_nblk = 0, row_off_size = 0;   //   (capacity; the block count and communicator size the table was built for)
+    double* ddist = nullptr;             // staging of a distributed Cholesky's exchange steps (one panel column, padded per rank)
+    size_t dist_cap = 0;
     long long* dshard_off = nullptr;     // offset of every 128-row block inside its owner's chunk of the exchange (device copy)
     long long shard_chunk = 0;           // doubles per rank in the exchange's all-gather
     int shard_off_cap = 0;

@@ -26,6 +26,7 @@ PlanOpts plan_opts_from_env() {
     o.kinv_stream = env_int("MFGP_KINV_STREAM", -1);
     o.chain_slim = env_int("MFGP_CHAIN_SLIM", -1);
     o.t128_min = std::max(0, env_int("MFGP_T128_MIN", 0));
+    o.dist_chol = env_int("MFGP_DIST_CHOL", -1);
     return o;
 }
 static int opt(int v, int dflt) { return v >= 0 ? v : dflt; }
@@ -528,6 +529,7 @@ static void plan_sweep(Plan& p) {
     const int chain_role_ct = CT == 32 ? 5 : chain_role;
     p.kinv_streamed = opt(p.opts.kinv_stream, 1) != 0 && p.shard.size <= 1;   // (sharded: K^-1 follows the exchange of the rows of X^T)
     const auto mine = [&](int64_t row) { return shard_owner((int)(row / NB), p.shard.size) == p.shard.rank; };
+    const bool dist = p.shard.size > 1 && p.shard.dist;   // the Cholesky's own rows by owner too (plan.h Shard)
     int kinv_lo = 0;    // first block column whose contribution to K^-1 is still outstanding
     const bool merge_xpanel = nb > 24;    // fewer, fuller launches on the bulk stream (N = 3072: 1.67 without / 1.80 with; 3584: 2.38 / 2.17)
     // One macro panel (nothing runs beside the chain): K^-1 is accumulated column by column in the chain's own K = 128 launches
@@ -554,6 +556,7 @@ static void plan_sweep(Plan& p) {
         const int sc = NB / T;
         in_blocks(jlo * sc, nb * sc, jlo * sc, jhi * sc, [&](int i, int j) {
             if (i < j) return;
+            if (dist && !mine((int64_t)i * T)) return;
             push(at(BUF_L, (int64_t)i * T, (int64_t)klo * NB), at(BUF_L, (int64_t)j * T, (int64_t)klo * NB),
                  at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1, (khi - klo) * NB, 0, -1.0, 1.0);
         });
@@ -564,6 +567,7 @@ static void plan_sweep(Plan& p) {
         const int64_t kc = (int64_t)c * NB;
         for (int i = (c + 1) * sc; i < nb * sc; ++i)
             for (int j = c * sc; j < (c + 1) * sc; ++j)
+                if (!dist || mine((int64_t)i * T))
                 push(at(BUF_A, (int64_t)i * T, kc), at(BUF_S, (int64_t)j * T, kc), at(BUF_L, (int64_t)i * T, (int64_t)j * T), -1,
                      (int)((int64_t)(j + 1) * T - kc), TF_B_LOWER, 1.0, 0.0);
     };
@@ -640,11 +644,20 @@ static void plan_sweep(Plan& p) {
         const int M2 = std::min(M1 + MB, nb);
         // ---- the chain of this macro panel (main stream) ----
         for (int c = M0; c < M1; ++c) {
-            Step s{};
-            s.kind = 0;
-            s.blk = c;
-            main_wait(s, ev_col[c]);
-            p.steps.push_back(s);
+            if (!dist || mine((int64_t)c * NB)) {
+                Step s{};
+                s.kind = STEP_LEAF;
+                s.blk = c;
+                main_wait(s, ev_col[c]);
+                p.steps.push_back(s);
+            }
+            if (dist) {   // L_cc, X_cc from the rank that factorised them (main_wait: a rank without the leaf meets column c here first)
+                Step s{};
+                s.kind = STEP_COMM_DIAG;
+                s.blk = c;
+                main_wait(s, ev_col[c]);
+                p.steps.push_back(s);
+            }
             {   // panel(c): the column of L below the diagonal and the in-macro part of the column of X^T above it
                 const int rows = (nb - 1 - c) + (c - M0);
                 if (rows > 0) {
@@ -654,6 +667,12 @@ static void plan_sweep(Plan& p) {
                     x_panel(T, c, c, M0, c);
                     launch(T, first, 0, T == 128 ? 0 : chain_role_ct);
                 }
+            }
+            if (dist && c + 1 < nb) {   // block column c of L: every rank's rows to everybody (the updates read L[j, c] of every row j)
+                Step s{};
+                s.kind = STEP_COMM_PANEL;
+                s.blk = c;
+                p.steps.push_back(s);
             }
             {   // inner(c): right-looking K = 128 updates inside the macro (A: also the next macro's first column if `shift`)
                 const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
@@ -817,6 +836,7 @@ void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& o
     p = Plan{};
     p.opts = opts;
     p.shard = shard;
+    p.shard.dist = shard.size > 1 && (shard.dist || opt(opts.dist_chol, nblk >= 256) != 0);
     if (shard.size > 1) p.opts.kind = 0;      // a sharded evaluation always runs the sweep
     p.t128_min = std::max(1, (opts.t128_min > 0 ? opts.t128_min : (nblk >= 56 ? 600 : 300)) / std::max(1, t128_div));
     p.batch_div = std::max(1, t128_div);

@@ -42,7 +42,8 @@ enum Buf { BUF_A = 0, BUF_L = 1, BUF_S = 2, BUF_W = 3 };
 
 // one launch of a plan
 struct Step {
-    int kind;  // 0 = leaf, 1 = gemm, 2 = join (no launch: the stream only waits for wait_ev)
+    int kind;  // StepKind: 0 = leaf, 1 = gemm, 2 = join (no launch: the stream only waits for wait_ev), 3 / 4 = the exchange steps
+               // of a distributed Cholesky (Shard::dist; blk = the block column)
     int role;  // gemm kernel symbol: 0 recursion, 1 K^-1, 2 predictive variance, 3 serial-chain step (slim workgroups)
     int strm;  // 0 = main stream (the serial chain), 1 = bulk-update stream (look-ahead)
     int wait_ev, rec_ev;  // 1-based event indices (0 = none): wait before / record after the launch
@@ -63,14 +64,25 @@ struct PlanOpts {
     int kinv_stream = -1;  // MFGP_KINV_STREAM
     int chain_slim = -1;   // MFGP_CHAIN_SLIM
     int t128_min = 0;      // MFGP_T128_MIN: tiles per launch from which 128-tiles are used
+    int dist_chol = -1;    // MFGP_DIST_CHOL: a sharded evaluation's Cholesky distributed over the group too (Shard::dist; default: from 256
+                           // block columns, N >= 32768 -- below, one GPU factorises faster than the group exchanges panels)
 };
 // Row ownership of a sharded evaluation (mfgp_eval_sharded): the work on the image of the identity / the rows of X^T and the rows
 // of K^-1 -- 2 N^3 / 3 of an evaluation's N^3 flops -- splits by 128-row block with no dependency between blocks; block b belongs
 // to rank shard_owner(b, size): block-cyclic in serpentine order (0 1 .. G-1 G-1 .. 1 0 ...), because the work of a block row
 // falls with its index (rows of X^T: ~ (nb - b)^2) or peaks in the middle (rows of K^-1: ~ b (nb - b)).
+// dist (round 5; SURVEY 8(e) "Cholesky": the 1-D block-cyclic multi-GPU factorisation for N >= 32768): the Cholesky's own work
+// splits by the same ownership too.  Rank r runs the leaf of the diagonal blocks it owns, the rows of every panel column and of
+// every trailing update of A that lie in its blocks -- N^3 / (3 G) instead of N^3 / 3 flops -- and the plan carries two exchange
+// steps per block column c on the chain: COMM_DIAG(c) (L_cc, X_cc and the leaf's log-det / pivot words from owner(c) to
+// everybody: 2 x 128 KB) before the panel, COMM_PANEL(c) (block column c of L below the diagonal, every 128-row block from its
+// owner to everybody: 8 (N - 128 c) 128 bytes in all) after it.  Every rank ends with the complete L; the tasks it runs are the
+// single evaluation's own tasks, so no result bit changes.
 struct Shard {
     int rank = 0, size = 1;
+    bool dist = false;     // (set by build_plan from PlanOpts::dist_chol and the size)
 };
+enum StepKind { STEP_LEAF = 0, STEP_GEMM = 1, STEP_JOIN = 2, STEP_COMM_DIAG = 3, STEP_COMM_PANEL = 4 };
 inline int shard_owner(int blk, int size) {
     if (size <= 1) return 0;
     const int x = blk % (2 * size);

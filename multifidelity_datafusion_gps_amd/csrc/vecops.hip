@@ -240,6 +240,59 @@ void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* 
                        unpack ? 1 : 0, lower ? 1 : 0);
 }
 
+// ---- exchange steps of a distributed Cholesky (plan.h Shard::dist) ------------------------------------------------------
+// COMM_DIAG(c): the diagonal blocks L_cc, X_cc (mirrored) and the leaf's two words (half log-det of the block, pivot status) in one
+// contiguous message of 2 * 128^2 + 2 doubles: packed by the owner, unpacked by everybody else.  One workgroup per block row.
+__global__ __launch_bounds__(128) void mfgp_dist_diag_copy_f64(double* __restrict__ L, double* __restrict__ S, int ld, int c,
+                                                               double* __restrict__ stage, double* __restrict__ logdet,
+                                                               int* __restrict__ info, int unpack) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    double* pl = L + (long long)(c * 128 + r) * ld + c * 128 + k;
+    double* ps = S + (long long)(c * 128 + r) * ld + c * 128 + k;
+    if (unpack) {
+        *pl = stage[r * 128 + k];
+        *ps = stage[128 * 128 + r * 128 + k];
+        if (r == 0 && k == 0) {
+            logdet[c] = stage[2 * 128 * 128];
+            const int st = (int)stage[2 * 128 * 128 + 1];
+            if (st != 0 && *info == 0) *info = st;
+        }
+    } else {
+        stage[r * 128 + k] = *pl;
+        stage[128 * 128 + r * 128 + k] = *ps;
+        if (r == 0 && k == 0) {
+            stage[2 * 128 * 128] = logdet[c];
+            stage[2 * 128 * 128 + 1] = (double)*info;
+        }
+    }
+}
+void launch_dist_diag_copy(hipStream_t s, double* L, double* S, int ld, int c, double* stage, double* logdet, int* info, bool unpack) {
+    hipLaunchKernelGGL(mfgp_dist_diag_copy_f64, dim3(128), dim3(128), 0, s, L, S, ld, c, stage, logdet, info, unpack ? 1 : 0);
+}
+// COMM_PANEL(c): block column c of L below the diagonal.  Block (i, c), i > c, belongs to shard_owner(i); it is the k-th block of its
+// owner in this column (k = the owner's blocks in (c, i)) and travels at [owner * chunk + k * 128^2) of the all-gather's buffer.
+// pack: this rank's blocks L -> stage; unpack: the others' blocks stage -> L.  One workgroup per (row of a block, block row).
+__global__ __launch_bounds__(128) void mfgp_dist_panel_copy_f64(double* __restrict__ L, int ld, int c, double* __restrict__ stage,
+                                                                long long chunk, int rank, int size, int unpack) {
+    const int i = c + 1 + blockIdx.y, r = blockIdx.x, t = threadIdx.x;
+    const int x = i % (2 * size), own = x < size ? x : 2 * size - 1 - x;        // plan.h shard_owner
+    if ((own == rank) == (unpack != 0)) return;
+    int k = 0;
+    for (int j = c + 1; j < i; ++j) {
+        const int xj = j % (2 * size);
+        k += ((xj < size ? xj : 2 * size - 1 - xj) == own);
+    }
+    double* pl = L + (long long)(i * 128 + r) * ld + c * 128 + t;
+    double* pp = stage + (long long)own * chunk + (long long)k * (128 * 128) + r * 128 + t;
+    if (unpack) *pl = *pp; else *pp = *pl;
+}
+void launch_dist_panel_copy(hipStream_t s, double* L, int ld, int nblk, int c, double* stage, long long chunk, int rank, int size,
+                            bool unpack) {
+    if (nblk - 1 - c <= 0) return;
+    hipLaunchKernelGGL(mfgp_dist_panel_copy_f64, dim3(128, nblk - 1 - c), dim3(128), 0, s, L, ld, c, stage, chunk, rank, size,
+                       unpack ? 1 : 0);
+}
+
 void launch_mirror_lower(hipStream_t s, double* S, int ld, int Np) {
     const int nt = Np / 64;
     hipLaunchKernelGGL(mfgp_mirror_lower_f64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, S, ld);

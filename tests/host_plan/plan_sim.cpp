@@ -225,65 +225,122 @@ void run_kinv(Sim& s) {
                      (int64_t)st.c * s.stride, 0);
 }
 
-// walk the steps in enqueue order: race check (+ execution when numeric); with_kinv: also the stand-alone K^-1 launch of a plan
-// that does not stream it.  -> 0, or < 0 with msg set
-int walk_steps(Sim& s, int numeric, int want_grad, bool with_kinv, char* msg, int msglen) {
+// The exchange steps of a distributed Cholesky (plan.h Shard::dist): which cells of L / S a rank reads (the blocks it owns and
+// sends) and writes (the blocks it receives).  blk = the block column c.
+void comm_accesses(Sim& s, const Step& st, int si) {
     const Plan& p = s.p;
-    // ---- walk the steps in enqueue order ----
-    Clock vc[NS] = {};
-    std::vector<Clock> evclock(p.n_events + 1, Clock{{-1, -1, -1}});
-    s.step_clock.resize(p.steps.size());
-    s.step_strm.resize(p.steps.size());
-    // the K build (one launch on the main stream, before every step) wrote the lower 64-tiles of A: model it as step -1
-    // by leaving the cells without a writer -- every plan step is ordered after it by stream order / the chain events
-    for (size_t si = 0; si < p.steps.size(); ++si) {
-        const Step& st = p.steps[si];
-        const int strm = (st.strm >= 0 && st.strm < NS) ? st.strm : 0;
-        if (st.wait_ev > 0) {
-            if (evclock[st.wait_ev].t[0] < 0) {
-                snprintf(msg, msglen, "step %zu waits for event %d before it is recorded", si, st.wait_ev);
-                return -1;
+    const int c = st.blk, size = p.shard.size, rank = p.shard.rank;
+    auto touch = [&](int buf, int bi, int bj, bool wr) {
+        const int64_t g0 = (int64_t)buf * s.stride + (int64_t)bi * NB * s.ld + (int64_t)bj * NB;
+        for (int rb = 0; rb < NB / CELL; ++rb)
+            for (int cb = 0; cb < NB / CELL; ++cb) {
+                const int64_t off = g0 + (int64_t)rb * CELL * s.ld + cb * CELL;
+                if (wr) s.write(off, si, 0); else s.read(off, si, 0);
             }
-            for (int k = 0; k < NS; ++k) vc[strm].t[k] = std::max(vc[strm].t[k], evclock[st.wait_ev].t[k]);
-        }
-        vc[strm].t[strm] += 1;
-        s.step_clock[si] = vc[strm];
-        s.step_strm[si] = strm;
-        if (st.kind == 0) {
-            const int64_t g0 = (int64_t)st.blk * NB * s.ld + (int64_t)st.blk * NB;
-            for (int rb = 0; rb < NB / CELL; ++rb)
-                for (int cb = 0; cb < NB / CELL; ++cb) {
-                    // the leaf reads the 16-blocks on and below the diagonal: every CELL that holds one
-                    if (cb <= rb) s.read((int64_t)BUF_A * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
-                    s.write((int64_t)BUF_L * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
-                    s.write((int64_t)BUF_S * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
-                }
-            if (numeric) {
-                const int info = leaf_compute(s, st.blk);
-                if (info) {
-                    snprintf(msg, msglen, "leaf %d: non-positive pivot %d (or NaN input)", st.blk, info);
-                    return -2;
-                }
-            }
-        } else if (st.kind == 1) {
-            const bool g = want_grad && st.gcount > 0;
-            const int n = g ? st.gcount : st.count, first = g ? st.gfirst : st.first;
-            const int64_t ba = (int64_t)st.a * s.stride, bb = (int64_t)st.b * s.stride, bc = (int64_t)st.c * s.stride;
-            const int64_t bc2 = st.c2 >= 0 ? (int64_t)st.c2 * s.stride : 0;
-            for (int k = 0; k < n; ++k) task_accesses(s, p.tasks[first + k], st.tile, ba, bb, bc, bc2, (int)si, k);
-            if (numeric)
-                for (int k = 0; k < n; ++k) task_compute(s, p.tasks[first + k], st.tile, ba, bb, bc, bc2);
-        }
-        if (st.rec_ev > 0) evclock[st.rec_ev] = vc[strm];
-        if (st.rec_ev_final > 0) evclock[st.rec_ev_final] = vc[strm];
+    };
+    if (st.kind == STEP_COMM_DIAG) {
+        const bool own = shard_owner(c, size) == rank;
+        touch(BUF_L, c, c, !own);
+        touch(BUF_S, c, c, !own);
+    } else {
+        for (int i = c + 1; i < p.nblk; ++i) touch(BUF_L, i, c, shard_owner(i, size) != rank);
     }
-    // everything must be visible to the main stream at the end (solve / gradient kernels follow there)
-    for (size_t si = 0; si < p.steps.size(); ++si)
-        if (s.step_strm[si] != 0 && vc[0].t[s.step_strm[si]] < s.step_clock[si].t[s.step_strm[si]]) {
-            snprintf(msg, msglen, "step %zu of stream %d is not joined into the main stream at the end of the plan", si, s.step_strm[si]);
-            return -3;
+}
+
+// walk the steps in enqueue order: race check (+ execution when numeric).  Resumable: run() stops in front of the next exchange step
+// of a distributed plan (its index is returned; the caller moves the data between the ranks' matrices and calls run() again) and
+// returns the number of steps at the end; < 0 with msg set on an error.
+struct Walker {
+    Clock vc[NS] = {};
+    std::vector<Clock> evclock;
+    size_t si = 0;
+    bool started = false;
+    int run(Sim& s, int numeric, int want_grad, char* msg, int msglen) {
+        const Plan& p = s.p;
+        if (!started) {
+            evclock.assign(p.n_events + 1, Clock{{-1, -1, -1}});
+            s.step_clock.resize(p.steps.size());
+            s.step_strm.resize(p.steps.size());
+            started = true;
         }
-    if (with_kinv && want_grad && !p.kinv_streamed && numeric) run_kinv(s);
+        // the K build (one launch on the main stream, before every step) wrote the lower 64-tiles of A: model it as step -1
+        // by leaving the cells without a writer -- every plan step is ordered after it by stream order / the chain events
+        for (; si < p.steps.size(); ++si) {
+            const Step& st = p.steps[si];
+            const int strm = (st.strm >= 0 && st.strm < NS) ? st.strm : 0;
+            const bool comm = st.kind == STEP_COMM_DIAG || st.kind == STEP_COMM_PANEL;
+            if (comm && !resumed_at(si)) {
+                pending = si;
+                return (int)si;
+            }
+            if (st.wait_ev > 0) {
+                if (evclock[st.wait_ev].t[0] < 0) {
+                    snprintf(msg, msglen, "step %zu waits for event %d before it is recorded", si, st.wait_ev);
+                    return -1;
+                }
+                for (int k = 0; k < NS; ++k) vc[strm].t[k] = std::max(vc[strm].t[k], evclock[st.wait_ev].t[k]);
+            }
+            vc[strm].t[strm] += 1;
+            s.step_clock[si] = vc[strm];
+            s.step_strm[si] = strm;
+            if (comm) {
+                if (strm != 0) {
+                    snprintf(msg, msglen, "exchange step %zu is not on the main stream", si);
+                    return -4;
+                }
+                comm_accesses(s, st, (int)si);
+            } else if (st.kind == STEP_LEAF) {
+                const int64_t g0 = (int64_t)st.blk * NB * s.ld + (int64_t)st.blk * NB;
+                for (int rb = 0; rb < NB / CELL; ++rb)
+                    for (int cb = 0; cb < NB / CELL; ++cb) {
+                        // the leaf reads the 16-blocks on and below the diagonal: every CELL that holds one
+                        if (cb <= rb) s.read((int64_t)BUF_A * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
+                        s.write((int64_t)BUF_L * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
+                        s.write((int64_t)BUF_S * s.stride + g0 + (int64_t)rb * CELL * s.ld + cb * CELL, (int)si, 0);
+                    }
+                if (numeric) {
+                    const int info = leaf_compute(s, st.blk);
+                    if (info) {
+                        snprintf(msg, msglen, "leaf %d: non-positive pivot %d (or NaN input)", st.blk, info);
+                        return -2;
+                    }
+                }
+            } else if (st.kind == STEP_GEMM) {
+                const bool g = want_grad && st.gcount > 0;
+                const int n = g ? st.gcount : st.count, first = g ? st.gfirst : st.first;
+                const int64_t ba = (int64_t)st.a * s.stride, bb = (int64_t)st.b * s.stride, bc = (int64_t)st.c * s.stride;
+                const int64_t bc2 = st.c2 >= 0 ? (int64_t)st.c2 * s.stride : 0;
+                for (int k = 0; k < n; ++k) task_accesses(s, p.tasks[first + k], st.tile, ba, bb, bc, bc2, (int)si, k);
+                if (numeric)
+                    for (int k = 0; k < n; ++k) task_compute(s, p.tasks[first + k], st.tile, ba, bb, bc, bc2);
+            }
+            if (st.rec_ev > 0) evclock[st.rec_ev] = vc[strm];
+            if (st.rec_ev_final > 0) evclock[st.rec_ev_final] = vc[strm];
+        }
+        // everything must be visible to the main stream at the end (solve / gradient kernels follow there)
+        for (size_t k = 0; k < p.steps.size(); ++k)
+            if (s.step_strm[k] != 0 && vc[0].t[s.step_strm[k]] < s.step_clock[k].t[s.step_strm[k]]) {
+                snprintf(msg, msglen, "step %zu of stream %d is not joined into the main stream at the end of the plan", k, s.step_strm[k]);
+                return -3;
+            }
+        return (int)p.steps.size();
+    }
+    long long pending = -1;     // the exchange step run() stopped in front of; resume() lets the next run() pass it
+    long long passed = -1;
+    bool resumed_at(size_t k) const { return passed == (long long)k; }
+    void resume() { passed = pending; }
+};
+
+// with_kinv: also the stand-alone K^-1 launch of a plan that does not stream it.  -> 0, or < 0 with msg set
+int walk_steps(Sim& s, int numeric, int want_grad, bool with_kinv, char* msg, int msglen) {
+    Walker w;
+    const int rc = w.run(s, numeric, want_grad, msg, msglen);
+    if (rc < 0) return rc;
+    if (rc != (int)s.p.steps.size()) {
+        snprintf(msg, msglen, "an exchange step (%d) in a plan that is executed alone", rc);
+        return -5;
+    }
+    if (with_kinv && want_grad && !s.p.kinv_streamed && numeric) run_kinv(s);
     return 0;
 }
 
@@ -379,7 +436,7 @@ int plan_sim(int nblk, int numeric, int want_grad, int slack, int mutate, double
 // report[0] = races (all ranks), [1] = max |X L - I| (rank 0), [2] = number of words of L / S that differ from the single run
 // (all ranks), [3] = words of K^-1 (own rows, lower 128-tiles) that differ, [4] = tasks of the largest rank plan / tasks of the
 // unsharded plan
-int plan_sim_sharded(int nblk, int size, double* report, char* msg, int msglen) {
+static int plan_sim_group(int nblk, int size, bool dist, double* report, char* msg, int msglen) {
     const PlanOpts opts = plan_opts_from_env();
     const int64_t ld = (int64_t)nblk * NB, stride = ld * ld;
     for (int i = 0; i < 8; ++i) report[i] = 0.0;
@@ -396,15 +453,66 @@ int plan_sim_sharded(int nblk, int size, double* report, char* msg, int msglen) 
     int rc = walk_steps(ref, 1, 1, true, msg, msglen);
     if (rc < 0) return rc;
     std::vector<Sim> rk((size_t)size);
+    std::vector<Walker> wk((size_t)size);
     size_t max_tasks = 0;
+    double comm_words = 0;
     for (int r = 0; r < size; ++r) {
         Sim& s = rk[(size_t)r];
         s.ld = ld; s.stride = stride;
-        build_plan(s.p, nblk, ld, stride, opts, 1, Shard{r, size});
+        Shard sh;
+        sh.rank = r; sh.size = size;
+        PlanOpts o = opts;
+        o.dist_chol = dist ? 1 : 0;            // (the size rule would turn it on from 256 block columns only)
+        build_plan(s.p, nblk, ld, stride, o, 1, sh);
         std::vector<double> dummy;
         prepare(s, true, dummy, nullptr);
-        rc = walk_steps(s, 1, 1, false, msg, msglen);
-        if (rc < 0) return rc;
+    }
+    // every rank runs up to its next exchange step; the exchange steps come in the same order on every rank (the planner emits them
+    // for all); the data moves between the ranks' matrices; on to the next
+    for (;;) {
+        std::vector<int> at((size_t)size);
+        for (int r = 0; r < size; ++r) {
+            at[(size_t)r] = wk[(size_t)r].run(rk[(size_t)r], 1, 1, msg, msglen);
+            if (at[(size_t)r] < 0) return at[(size_t)r];
+        }
+        const bool done0 = at[0] == (int)rk[0].p.steps.size();
+        for (int r = 0; r < size; ++r) {
+            const bool done = at[(size_t)r] == (int)rk[(size_t)r].p.steps.size();
+            if (done != done0) {
+                snprintf(msg, msglen, "rank %d and rank 0 disagree about the number of exchange steps", r);
+                return -6;
+            }
+            if (!done) {
+                const Step& a = rk[(size_t)r].p.steps[(size_t)at[(size_t)r]], &b = rk[0].p.steps[(size_t)at[0]];
+                if (a.kind != b.kind || a.blk != b.blk) {
+                    snprintf(msg, msglen, "rank %d meets exchange (%d, column %d) where rank 0 meets (%d, column %d)", r, a.kind, a.blk, b.kind, b.blk);
+                    return -6;
+                }
+            }
+        }
+        if (done0) break;
+        const Step& st = rk[0].p.steps[(size_t)at[0]];
+        const int c = st.blk;
+        auto copy_block = [&](int buf, int bi, int bj, int own) {
+            const int64_t g0 = (int64_t)buf * stride + (int64_t)bi * NB * ld + (int64_t)bj * NB;
+            for (int r = 0; r < size; ++r) {
+                if (r == own) continue;
+                for (int row = 0; row < NB; ++row)
+                    memcpy(rk[(size_t)r].mem.data() + g0 + (int64_t)row * ld, rk[(size_t)own].mem.data() + g0 + (int64_t)row * ld, NB * sizeof(double));
+            }
+            comm_words += (double)NB * NB;
+        };
+        if (st.kind == STEP_COMM_DIAG) {
+            copy_block(BUF_L, c, c, shard_owner(c, size));
+            copy_block(BUF_S, c, c, shard_owner(c, size));
+        } else {
+            for (int i = c + 1; i < nblk; ++i) copy_block(BUF_L, i, c, shard_owner(i, size));
+        }
+        for (int r = 0; r < size; ++r) wk[(size_t)r].resume();
+    }
+    report[5] = comm_words * 8.0;     // bytes every rank receives or sends through the Cholesky's exchange steps (per copy of a block)
+    for (int r = 0; r < size; ++r) {
+        Sim& s = rk[(size_t)r];
         report[0] += s.races;
         if (s.races && msg && !msg[0]) snprintf(msg, msglen, "rank %d: %d races; first: %s", r, s.races, s.first_race.c_str());
         size_t nt = 0;
@@ -464,6 +572,12 @@ int plan_sim_sharded(int nblk, int size, double* report, char* msg, int msglen) 
     }
     return report[0] > 0 ? 1 : 0;
 }
+
+int plan_sim_sharded(int nblk, int size, double* report, char* msg, int msglen) { return plan_sim_group(nblk, size, false, report, msg, msglen); }
+// the same with the DISTRIBUTED Cholesky (plan.h Shard::dist): every rank runs only its own rows of the panels and of the trailing
+// updates, the diagonal blocks and the panel columns travel through the plan's exchange steps (executed here in lock step over the
+// ranks' copies of the matrices).  report[5] = bytes moved by those steps.
+int plan_sim_dist(int nblk, int size, double* report, char* msg, int msglen) { return plan_sim_group(nblk, size, true, report, msg, msglen); }
 
 // out[0..7] = main-stream launches, bulk launches, waits on the main stream, records on the main stream, waits on bulk,
 // records on bulk, tasks (without the stand-alone K^-1 launch), gradient-only tasks

@@ -167,6 +167,43 @@ def _rccl_worker(rank, world, port, q):
         f1, g1 = e.eval_sharded(thg, nz, 1e-8)
         m1, v1 = e.predict(Xa[:100])
         res["eval_sharded"]["matern_ard_%d" % len(Y)] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), nograd=(0.0, 0.0))
+        # SURVEY 8(e) "Cholesky": the factorisation itself distributed over the group (1-D block-cyclic rows, plan.h Shard::dist; the size
+        # rule turns it on from N = 32768, MFGP_DIST_CHOL=1 here): every rank factorises only the diagonal blocks it owns and runs only
+        # its rows of the panels and trailing updates; the diagonal blocks and panel columns travel (ncclBroadcast / ncclAllGather per
+        # block column).  Bitwise the single evaluation -- NLML, gradient, the factor itself, predictions -- and a matrix that is not
+        # positive definite reports the same pivot on every rank.
+        if world <= 3:
+            os.environ["MFGP_DIST_CHOL"] = "1"             # (read when the handle plans: at the next set_data)
+            res["dist"] = {}
+            for n in (900, 4096):
+                rng = np.random.default_rng(n)
+                X = rng.uniform(size=(n, 4))
+                Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+                Y = cases.hf_4d(X)
+                e.set_data(Xa, Y)
+                e.set_kernel(cases.composite(4, 1))
+                th, nz = np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+                f0, g0 = e.eval(th, nz, 1e-8)
+                L0 = e.get_L()
+                m0, v0 = e.predict(Xa[:100])
+                comm.barrier()
+                f1, g1 = e.eval_sharded(th, nz, 1e-8)
+                L1 = e.get_L()
+                m1, v1 = e.predict(Xa[:100])
+                res["dist"][n] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), L_equal=bool(np.array_equal(L0, L1)))
+            Xd = np.vstack([Xa[:700], Xa[300:600]])        # duplicated rows, no noise, no jitter: not positive definite
+            e.set_data(Xd, np.concatenate([Y[:700], Y[300:600]]))
+            e.set_kernel(cases.composite(4, 1))
+            pivots = []
+            for fn in (e.eval, e.eval_sharded):
+                comm.barrier()
+                try:
+                    fn(th, 0.0, 0.0)
+                    pivots.append(0)
+                except Exception as ex:  # noqa: BLE001 - NotPositiveDefinite carries the pivot
+                    pivots.append(int(getattr(ex, "info", -1)))
+            res["dist"]["not_pd"] = pivots
+            del os.environ["MFGP_DIST_CHOL"]
         comm.barrier()
         e.comm_destroy()                                   # every rank still alive
         comm.barrier()
@@ -176,12 +213,14 @@ def _rccl_worker(rank, world, port, q):
         comm.close()
 
 
-@pytest.mark.parametrize("world", [2, 3, 6])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
     """A REAL RCCL communicator with more than one rank ("an RCCL collective with >= 2 ranks has never executed
     anywhere"): mfgp_comm_unique_id on rank 0 -> TCP -> mfgp_comm_init on every rank, then mfgp_allgather_rows (ONE
-    in-place ncclAllGather on the device matrix) and mfgp_allgather_host between the processes.  world = 6 is the most a one-GPU box
-    admits on its card (process guard); the 8-rank layout runs on the CPU (tests/test_bench_launcher.py) and in the driver's job."""
+    in-place ncclAllGather on the device matrix) and mfgp_allgather_host between the processes.  world = 5 is the most a one-GPU box
+    admits beside this test's own process, which computes the single-process reference on the same card (its process guard stops at 6;
+    `bench.py --gpus 6 --single-device`, whose launcher never touches the GPU, is the 6-rank rehearsal: profiles/r05_bench_n6_*);
+    the 8-rank layout runs on the CPU (tests/test_bench_launcher.py) and in the driver's job."""
     from multifidelity_datafusion_gps_amd.sharding import LocalComm
     ref = _model_run(LocalComm(), 1)
     ref_r2 = _model_run(LocalComm(), 1, restarts=2)
@@ -227,6 +266,14 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
             assert f1 == f0 and np.array_equal(g1, g0), (r, n)
             assert np.array_equal(m1, m0) and np.array_equal(v1, v0), (r, n)
             assert es["nograd"][0] == es["nograd"][1]
+        if world <= 3:
+            for n in (900, 4096):                          # the distributed Cholesky: bitwise the single evaluation, factor included
+                d = o["dist"][n]
+                (f0, g0, m0, v0), (f1, g1, m1, v1) = d["single"], d["sharded"]
+                assert f1 == f0 and np.array_equal(g1, g0) and d["L_equal"], (r, n)
+                assert np.array_equal(m1, m0) and np.array_equal(v1, v0), (r, n)
+            p_single, p_dist = o["dist"]["not_pd"]
+            assert p_single > 0 and p_dist == p_single, o["dist"]["not_pd"]
 
 
 @pytest.mark.parametrize("N", [300, 1500, 2100, 4200])

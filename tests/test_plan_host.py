@@ -110,13 +110,14 @@ def test_the_checker_catches_a_dropped_dependency(simlib):
 _SHARD_DRIVER = r"""
 import ctypes, json, sys
 lib = ctypes.CDLL(sys.argv[1])
-lib.plan_sim_sharded.restype = ctypes.c_int
-lib.plan_sim_sharded.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+fn = getattr(lib, sys.argv[3] if len(sys.argv) > 3 else "plan_sim_sharded")
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
 out = []
 for nb, size in json.loads(sys.argv[2]):
     rep = (ctypes.c_double * 8)()
     msg = ctypes.create_string_buffer(512)
-    rc = lib.plan_sim_sharded(nb, size, rep, msg, 512)
+    rc = fn(nb, size, rep, msg, 512)
     out.append([rc, list(rep), msg.value.decode()])
 print(json.dumps(out))
 """
@@ -143,6 +144,33 @@ def test_sharded_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
         assert rep[1] < 1e-12, (nb, size, rep)               # X L = I after the exchange
         assert rep[2] == 0 and rep[3] == 0, (nb, size, rep)    # no word of L / S / own K^-1 rows differs from the single run
         assert rep[4] <= 1.0
+
+
+@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}, {"MFGP_MACRO": "1"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_distributed_cholesky_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
+    """SURVEY 8(e) "Cholesky" (round 5): the 1-D block-cyclic factorisation over a rank group (plan.h Shard::dist).  Every rank's plan
+    holds only ITS rows of the panels and of the trailing updates of A (the leaf of the diagonal blocks it owns), plus two exchange
+    steps per block column -- the diagonal blocks from their owner, the panel column from the owners of its rows -- executed here
+    in lock step over the ranks' own copies of the matrices (pre-filled with NaN: a rank that read a row it never received would
+    poison its result).  Each rank's schedule is race-free, the exchange steps come in the same order on every rank, L, S and
+    the owned rows of K^-1 are BITWISE the single plan's, and the largest rank's task count falls towards 1/G of it."""
+    import json
+    specs = [(3, 2), (5, 2), (8, 3), (9, 4), (14, 3), (16, 4), (15, 2)] if not env else [(5, 2), (9, 4), (14, 2)]
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _SHARD_DRIVER, simlib, json.dumps(specs), "plan_sim_dist"], env=e, capture_output=True,
+                       text=True, check=True)
+    for (nb, size), (rc, rep, msg) in zip(specs, json.loads(r.stdout)):
+        assert rc == 0 and rep[0] == 0, (nb, size, rc, msg)
+        assert rep[1] < 1e-12, (nb, size, rep)               # X L = I on rank 0 (its L is part computed, part received)
+        assert rep[2] == 0 and rep[3] == 0, (nb, size, rep)    # no word of L / S / own K^-1 rows differs from the single run
+        assert rep[4] <= 1.0
+        # bytes through the Cholesky's exchange steps: 2 diagonal blocks + the blocks below, per block column
+        assert rep[5] == 8 * 128 * 128 * sum(2 + (nb - 1 - c) for c in range(nb)), (nb, size, rep[5])
+    if not env:
+        share = {(nb, size): rep[4] for (nb, size), (rc, rep, msg) in zip(specs, json.loads(r.stdout))}
+        assert share[(16, 4)] < 0.45 and share[(14, 3)] < 0.55, share   # (sharded without dist: 1/3 + 2/(3 G) = 0.5 / 0.56 at best)
 
 
 # ---- the same planner + checker under AddressSanitizer / UndefinedBehaviorSanitizer (CPU build; SURVEY section 5) -------------

@@ -38,6 +38,36 @@ rehearsal)
     last_json $out/bench_n$n.json
   done
   ;;
+ab_define)
+  # A/B of two compile-time variants of the library (AB_BASE / AB_DEFINE: -D switches through MFGP_BUILD_DEFINES; "" = the build the
+  # repository ships), alternating within this one call: kernel parity first (variant build), then AB_CMD (default: one evaluation alone at
+  # several sizes), batched passes and the bench under each build, twice
+  build() { MFGP_BUILD_DEFINES="$1" python -m multifidelity_datafusion_gps_amd.build --force > $out/build.log 2>&1 || { tail -20 $out/build.log; exit 1; }; }
+  build "${AB_DEFINE-}" &&
+  timeout -k 10 800 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_plans.py tests/test_gpu_parity.py -m gpu -x -q > $out/variant_tests.log 2>&1 || { tail -30 $out/variant_tests.log; build ""; exit 1; }
+  tail -2 $out/variant_tests.log
+  for rep in 1 2; do
+    for v in base variant; do
+      if [ $v = base ]; then build "${AB_BASE-}"; else build "${AB_DEFINE-}"; fi
+      timeout -k 10 300 ${AB_CMD:-python tools/time_eval.py 512 1024 2048 4096 8192} > $out/cmd_${v}_rep$rep.txt 2>&1 || { tail $out/cmd_${v}_rep$rep.txt; build ""; exit 1; }
+      echo "== $v rep $rep"; grep '^N=' $out/cmd_${v}_rep$rep.txt | cut -c1-200
+      BATCHES="${AB_BATCHES:-4}" timeout -k 10 300 python tools/batch_eval.py ${AB_SIZES:-4096 8192} > $out/batch_${v}_rep$rep.txt 2>&1 || { tail $out/batch_${v}_rep$rep.txt; build ""; exit 1; }
+      grep '^N=' $out/batch_${v}_rep$rep.txt
+      if [ "${AB_BENCH:-1}" = 1 ]; then
+        timeout -k 10 300 python bench.py --no-cpu-baseline --steps ${AB_STEPS:-6} --warmup 1 > $out/bench_${v}_rep$rep.json 2> $out/bench_${v}_rep$rep.err || { tail $out/bench_${v}_rep$rep.err; build ""; exit 1; }
+        last_json $out/bench_${v}_rep$rep.json
+      fi
+      if [ -n "${AB_FIT-}" ]; then python tools/midsize_fit.py --evals 20 $AB_FIT > $out/fit_${v}_rep$rep.txt 2>&1; tail -3 $out/fit_${v}_rep$rep.txt | cut -c1-250; fi
+    done
+  done
+  build ""
+  ;;
+leaf_stamps)
+  # lab build with cycle stamps in the leaf's panel loop (never shipped: the default build is restored at the end)
+  MFGP_BUILD_DEFINES="-DMFGP_LEAF_STAMPS ${AB_DEFINE-}" python -m multifidelity_datafusion_gps_amd.build --force > $out/build.log 2>&1 || { tail -20 $out/build.log; exit 1; }
+  timeout -k 10 120 python tools/leaf_stamps.py > $out/leaf_stamps.txt 2>&1; cat $out/leaf_stamps.txt
+  python -m multifidelity_datafusion_gps_amd.build --force > $out/build.log 2>&1
+  ;;
 pick)
   # selected tests, each group under its own timeout; PICK="file::test ..." (space separated pytest node ids / -k expressions are not split)
   for t in ${PICK:?}; do
