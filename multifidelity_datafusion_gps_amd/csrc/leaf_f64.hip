@@ -186,6 +186,53 @@ __device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb,
 }
 
 
+// One rank-16 block product of the panel loop's shadow phase in pointer form -- C (+)= -A B^T with A[row fr][k] at pa[k * sa / 4 ...]:
+//   update:      pa = sL + (ib*16 + fr)*LP + jb*16 + q (element s at pa[4 s]),  pb = sL + (kb*16 + fr)*LP + jb*16 + q,  C = (ib, kb), accumulate
+//   first touch: pa = Y + q*YP16 + fr (element s at pa[4 s YP16]),              pb = sL + (J*16 + fr)*LP + jb*16 + q,   C = (jb, J), from zero
+struct BlkProd {
+    const double* pa;
+    const double* pb;
+    double* pc;         // sL + (crow*16 + q)*LP + ccol*16 + fr ; element r at pc[4 r LP]
+    int sa;             // stride of A's k-slices
+    bool accumulate;
+};
+// TWO block products in flight in one wave (MFGP_LEAF_PAIR): their dependent chains of four ~100-cycle v_mfma_f64_16x16x4 interleave, and
+// the second block's 12 LDS reads travel under the first one's MFMAs -- the stamped panel loop shows the workers' block products as the
+// longer side of every panel (profiles/r05_leaf_stamps.txt)
+__device__ __forceinline__ void block_pair(const BlkProd& x, const BlkProd& y) {
+    d4_t c0, c1;
+    double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c0[r] = x.accumulate ? x.pc[4 * r * LP] : 0.0;
+        c1[r] = y.accumulate ? y.pc[4 * r * LP] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a0[s] = -x.pa[s * x.sa]; b0[s] = x.pb[4 * s];
+        a1[s] = -y.pa[s * y.sa]; b1[s] = y.pb[4 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        c0 = mfma(a0[s], b0[s], c0);
+        c1 = mfma(a1[s], b1[s], c1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x.pc[4 * r * LP] = c0[r];
+        y.pc[4 * r * LP] = c1[r];
+    }
+}
+__device__ __forceinline__ void block_one(const BlkProd& x) {
+    d4_t c0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c0[r] = x.accumulate ? x.pc[4 * r * LP] : 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c0 = mfma(-x.pa[s * x.sa], x.pb[4 * s], c0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x.pc[4 * r * LP] = c0[r];
+}
+
 // ---- leaf v3: the inverse rides on the factorisation --------------------------------------------------------------------
 // Same block-in-LDS, 16-column-panel factorisation as v2, but the inverse is no longer a second phase: it is produced by
 // the augmented system [A; I] INSIDE the panel loop, as idle-wave work in the shadow of wave 0's micro-Cholesky (which is
@@ -383,6 +430,54 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             const int nA = m * (m + 1) / 2;
             const int w = 7 - jb;                    // B: rows 0 .. jb, block columns jb+1 .. 7
             const int nB = (jb + 1) * w;
+#ifdef MFGP_LEAF_PAIR
+            // two block products in flight per wave; with MFGP_LEAF_W4OUT wave 4 -- which shares SIMD 0 with the pivot wave -- takes no
+            // block product and writes the panel out alone, the other six workers share the products
+#ifdef MFGP_LEAF_W4OUT
+            const int nwork = 6, widx = wave < 4 ? wave - 1 : wave - 2;
+            const bool producer = wave != 4;
+#else
+            const int nwork = 7, widx = wave - 1;
+            const bool producer = true;
+#endif
+            auto decode = [&](int idx) -> BlkProd {
+                BlkProd b;
+                int ci, cj;
+                b.sa = 4; b.accumulate = true;
+                if (idx < nP) {
+                    ci = jb + 2 + idx; cj = jb + 1;
+                    b.pa = sL + (ci * 16 + fr) * LP + jb * 16 + q;
+                    b.pb = sL + (cj * 16 + fr) * LP + jb * 16 + q;
+                } else if (idx < nP + nA) {
+                    int ii = 0, rem = idx - nP;
+                    while (rem > ii) { rem -= ii + 1; ++ii; }
+                    ci = jb + 2 + ii; cj = jb + 2 + rem;
+                    b.pa = sL + (ci * 16 + fr) * LP + jb * 16 + q;
+                    b.pb = sL + (cj * 16 + fr) * LP + jb * 16 + q;
+                } else {
+                    const int t = idx - nP - nA;
+                    ci = t / w; cj = jb + 1 + t % w;
+                    b.pb = sL + (cj * 16 + fr) * LP + jb * 16 + q;
+                    if (ci == jb) { b.pa = Yj + q * YP16 + fr; b.sa = 4 * YP16; b.accumulate = false; }
+                    else b.pa = sL + (ci * 16 + fr) * LP + jb * 16 + q;          // (I < jb: "L[I][jb]" read there is X^T[I,jb])
+                }
+                b.pc = sL + (ci * 16 + q) * LP + cj * 16 + fr;
+                return b;
+            };
+            if (producer) {
+                int idx = widx;
+                for (; idx + nwork < nP + nA + nB; idx += 2 * nwork) block_pair(decode(idx), decode(idx + nwork));
+                if (idx < nP + nA + nB) block_one(decode(idx));
+            }
+            LEAF_STAMP(wave, jb + 1, 3);
+#ifdef MFGP_LEAF_W4OUT
+            if (wave == 4) write_panel(jb, lane, 64);
+#else
+            write_panel(jb, tid - 64, 448);
+#endif
+            LEAF_STAMP(wave, jb + 1, 4);
+            if (false)
+#endif
             for (int idx = wave - 1; idx < nP + nA + nB; idx += 7) {
                 if (idx < nP) {
                     update_block(sL, jb + 2 + idx, jb + 1, jb, fr, q);
@@ -397,11 +492,13 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
                     else update_block(sL, I, J, jb, fr, q);     // (I < jb: "L[I][jb]" read there is X^T[I,jb])
                 }
             }
+#ifndef MFGP_LEAF_PAIR
             LEAF_STAMP(wave, jb + 1, 3);
             // Block column jb of L and row / column block jb of X are final since this panel's solves: write them out now,
             // in the shadow of the micro-Cholesky, panel by panel (16 + <= 32 KB each) instead of 256 KB after the last one.
             write_panel(jb, tid - 64, 448);
             LEAF_STAMP(wave, jb + 1, 4);
+#endif
         }
         __syncthreads();
         LEAF_STAMP(wave, jb + 1, 5);
