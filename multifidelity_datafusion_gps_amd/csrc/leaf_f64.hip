@@ -5,16 +5,17 @@
 // behind GPy's jitchol / pdinv.
 //
 // The block lives in LDS (pitch 130 doubles: fragment reads of v_mfma_f64_16x16x4 hit 32 distinct
-// 8-byte bank pairs).  8 waves.
-// Phase 1 factorises in place by 16-column panels with look-ahead:
-//   * the 16x16 diagonal micro-Cholesky runs in the REGISTERS of wave 0 (lane = row, 16 columns per
-//     lane, pivots and column entries broadcast with v_readlane: no LDS round trip, no barrier inside),
-//   * the inverse of the 16x16 diagonal factor comes out of the same pivot loop (one extra FMA per broadcast), and the
-//     rows below the diagonal block are solved as MFMA products with it,
-//   * the rank-16 trailing update runs on MFMA; the next panel's block column is updated first, then
-//     wave 0 factorises the next diagonal block WHILE waves 1-7 finish the rest of the update.
-// Phase 2 inverts in place: the eight 16x16 diagonal inverses are already there, the rest is assembled recursively
-// (X21 = -X22 (L21 X11) over 16 -> 32 -> 64 -> 128) on MFMA.
+// 8-byte bank pairs; 138 KB in all).  8 waves, 16-column panels with look-ahead:
+//   * the 16x16 diagonal micro-Cholesky runs in the REGISTERS of wave 0 (lane = row, 16 columns per lane; the entry the
+//     next pivot waits for broadcast with v_readlane, the others through an LDS broadcast issued ahead of their use),
+//   * the inverse of the 16x16 diagonal factor comes out of the same pivot loop (lanes 16-31, the same instructions), and
+//     the other rows of the panel are solved as MFMA block products with it,
+//   * the inverse of the WHOLE block rides on the panel loop as the augmented system [A; I] (the image of the identity in
+//     the upper triangle of the LDS block), exactly like the planner's sweep one level up,
+//   * per panel, wave 0 runs the critical path back to back -- the solve of block (jb+1, jb), panel jb's update of the next
+//     diagonal block, its micro-Cholesky -- while waves 1-7 solve the rest of the panel and, after ONE barrier, do every other
+//     rank-16 update and write the finished panel out in the micro-Cholesky's shadow (two workgroup barriers per panel).
+// Measured history and the variants that lost: LABBOOK.md, tools/gemm_lab/RETIRED.md, profiles/r05_leaf_*.txt.
 #include <stdlib.h>
 #include <mutex>
 #include "mfgp_internal.h"
@@ -25,16 +26,6 @@ constexpr int LP = 130;       // LDS pitch (doubles)
 constexpr int LEAF_THREADS = 512;
 constexpr int SC_RED = 0;      // scratch: 8 partial sums
 constexpr int SC_SIZE = 144;    // 8 partial sums (+ 8 spare), then the micro-Cholesky's 2 x 64 column broadcast slots
-
-#ifdef MFGP_LEAF_STAMPS
-// LAB BUILD ONLY (-DMFGP_LEAF_STAMPS through MFGP_BUILD_DEFINES; tools/leaf_stamps.py): s_memtime at the phase boundaries of the panel
-// loop, per wave and panel -- [wave][panel][slot]; slot 0 = start of phase A, 1 = end of this wave's phase-A work, 2 = barrier passed,
-// 3 = end of this wave's phase-B work (wave 0: the micro-Cholesky; workers: the updates), 4 = workers: panel written out, 5 = barrier passed
-__device__ unsigned long long mfgp_leaf_stamp_buf[8 * 9 * 8];
-#define LEAF_STAMP(w_, p_, s_) do { if ((threadIdx.x & 63) == 0) mfgp_leaf_stamp_buf[((w_) * 9 + (p_)) * 8 + (s_)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define LEAF_STAMP(w_, p_, s_) do { } while (0)
-#endif
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -186,53 +177,6 @@ __device__ __forceinline__ void update_block(double* sL, int ib, int kb, int jb,
 }
 
 
-// One rank-16 block product of the panel loop's shadow phase in pointer form -- C (+)= -A B^T with A[row fr][k] at pa[k * sa / 4 ...]:
-//   update:      pa = sL + (ib*16 + fr)*LP + jb*16 + q (element s at pa[4 s]),  pb = sL + (kb*16 + fr)*LP + jb*16 + q,  C = (ib, kb), accumulate
-//   first touch: pa = Y + q*YP16 + fr (element s at pa[4 s YP16]),              pb = sL + (J*16 + fr)*LP + jb*16 + q,   C = (jb, J), from zero
-struct BlkProd {
-    const double* pa;
-    const double* pb;
-    double* pc;         // sL + (crow*16 + q)*LP + ccol*16 + fr ; element r at pc[4 r LP]
-    int sa;             // stride of A's k-slices
-    bool accumulate;
-};
-// TWO block products in flight in one wave (MFGP_LEAF_PAIR): their dependent chains of four ~100-cycle v_mfma_f64_16x16x4 interleave, and
-// the second block's 12 LDS reads travel under the first one's MFMAs -- the stamped panel loop shows the workers' block products as the
-// longer side of every panel (profiles/r05_leaf_stamps.txt)
-__device__ __forceinline__ void block_pair(const BlkProd& x, const BlkProd& y) {
-    d4_t c0, c1;
-    double a0[4], b0[4], a1[4], b1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        c0[r] = x.accumulate ? x.pc[4 * r * LP] : 0.0;
-        c1[r] = y.accumulate ? y.pc[4 * r * LP] : 0.0;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        a0[s] = -x.pa[s * x.sa]; b0[s] = x.pb[4 * s];
-        a1[s] = -y.pa[s * y.sa]; b1[s] = y.pb[4 * s];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        c0 = mfma(a0[s], b0[s], c0);
-        c1 = mfma(a1[s], b1[s], c1);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        x.pc[4 * r * LP] = c0[r];
-        y.pc[4 * r * LP] = c1[r];
-    }
-}
-__device__ __forceinline__ void block_one(const BlkProd& x) {
-    d4_t c0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c0[r] = x.accumulate ? x.pc[4 * r * LP] : 0.0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) c0 = mfma(-x.pa[s * x.sa], x.pb[4 * s], c0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x.pc[4 * r * LP] = c0[r];
-}
-
 // ---- leaf v3: the inverse rides on the factorisation --------------------------------------------------------------------
 // Same block-in-LDS, 16-column-panel factorisation as v2, but the inverse is no longer a second phase: it is produced by
 // the augmented system [A; I] INSIDE the panel loop, as idle-wave work in the shadow of wave 0's micro-Cholesky (which is
@@ -273,7 +217,6 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
     const int fr = lane & 15;
     const int q = lane >> 4;
     const int64_t g0 = (int64_t)blk * NB * ld + (int64_t)blk * NB;  // offset of the diagonal block
-    LEAF_STAMP(wave, 0, 0);
     // load: only the 16-blocks on and below the diagonal (the upper part of the input is never used: that triangle of the
     // LDS block holds B).  Wave 0 takes the first diagonal tile alone and starts its micro-Cholesky at once, the other seven
     // waves bring in the remaining 35 tiles meanwhile.
@@ -314,9 +257,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         for (int u = 0; u < NLD; ++u)
             if (off[u] >= 0) *reinterpret_cast<d2_t*>(sL + off[u]) = v[u];
     }
-    LEAF_STAMP(wave, 0, 1);
     __syncthreads();
-    LEAF_STAMP(wave, 0, 2);
     // output of panel jb by `nthr` threads (t = 0 .. nthr-1): L[:, 16jb:16jb+16] with zeros above the diagonal, and the
     // mirrored inverse S[r][c] = X[max(r,c)][min(r,c)] for max(r,c) in block jb: X[hi][lo] = X^T[lo][hi] sits in the UPPER part
     // of sL, the diagonal 16-block in sY
@@ -346,46 +287,6 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             S[g0 + (int64_t)c * ld + r] = sL[c * LP + r];
         }
     };
-#ifdef MFGP_LEAF_3PHASE   // (A/B only: the loop of rounds 2-4)
-    for (int jb = 0; jb < 8; ++jb) {
-        const double* Yj = sY + (jb & 1) * 16 * YP16;
-        // panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb]
-        if (wave != jb) solve_block<YP16>(sL, Yj, wave, jb, fr, q);
-        __syncthreads();
-        if (jb == 7) break;
-        {   // priority: block column jb+1 of A gets panel jb's update first (one block per wave)
-            const int ib = jb + 1 + wave;
-            if (ib < 8) update_block(sL, ib, jb + 1, jb, fr, q);
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // the next diagonal block is factorised (and inverted) while waves 1-7 finish panel jb's updates
-            micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + ((jb + 1) & 1) * 16 * YP16, lane, info,
-                               blk * NB + jb * 16 + 16, sc + 16);
-        } else {
-            const int m = 6 - jb;                    // A: block columns jb+2 .. 7, lower blocks
-            const int nA = m * (m + 1) / 2;
-            const int w = 7 - jb;                    // B: rows 0 .. jb, block columns jb+1 .. 7
-            const int nB = (jb + 1) * w;
-            for (int idx = wave - 1; idx < nA + nB; idx += 7) {
-                if (idx < nA) {
-                    int ii = 0, rem = idx;
-                    while (rem > ii) { rem -= ii + 1; ++ii; }
-                    update_block(sL, jb + 2 + ii, jb + 2 + rem, jb, fr, q);
-                } else {
-                    const int t = idx - nA;
-                    const int I = t / w, J = jb + 1 + t % w;
-                    if (I == jb) bfirst_block(sL, Yj, jb, J, fr, q);
-                    else update_block(sL, I, J, jb, fr, q);     // (I < jb: "L[I][jb]" read there is X^T[I,jb])
-                }
-            }
-            // Block column jb of L and row / column block jb of X are final since this panel's solves: write them out now,
-            // in the shadow of the micro-Cholesky, panel by panel (16 + <= 32 KB each) instead of 256 KB after the last one.
-            write_panel(jb, tid - 64, 448);
-        }
-        __syncthreads();
-    }
-#else
     // Panel loop (round 5: two workgroup barriers per panel instead of three, and the pivot wave's work contiguous).  The leaf's
     // critical path runs through ONE block per panel: the sub-diagonal block (jb+1, jb) is solved, the next diagonal block (jb+1, jb+1)
     // takes panel jb's update, and its micro-Cholesky produces Y_{jb+1}, which the next panel's solves wait for.  Wave 0 does all three
@@ -400,7 +301,6 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
     };
     for (int jb = 0; jb < 8; ++jb) {
         const double* Yj = sY + (jb & 1) * 16 * YP16;
-        LEAF_STAMP(wave, jb + 1, 0);
         // phase A -- panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb].
         // Wave 0 takes the critical block row jb+1 (the wave that owns that row takes wave 0's row 0), then updates the next diagonal block.
         if (jb == 7) {
@@ -416,68 +316,17 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             const int ib = (wave == jb + 1) ? 0 : wave;
             if (ib != jb) solve_block<YP16>(sL, Yj, ib, jb, fr, q);
         }
-        LEAF_STAMP(wave, jb + 1, 1);
         __syncthreads();
-        LEAF_STAMP(wave, jb + 1, 2);
         if (wave == 0) {
             // the next diagonal block is factorised (and inverted) while waves 1-7 do the rest of panel jb
             micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + ((jb + 1) & 1) * 16 * YP16, lane, info,
                                blk * NB + jb * 16 + 16, sc + 16);
-            LEAF_STAMP(wave, jb + 1, 3);
         } else {
             const int nP = 6 - jb;                   // block column jb+1 of A below its diagonal block: the next panel's solves read it
             const int m = 6 - jb;                    // A: block columns jb+2 .. 7, lower blocks
             const int nA = m * (m + 1) / 2;
             const int w = 7 - jb;                    // B: rows 0 .. jb, block columns jb+1 .. 7
             const int nB = (jb + 1) * w;
-#ifdef MFGP_LEAF_PAIR
-            // two block products in flight per wave; with MFGP_LEAF_W4OUT wave 4 -- which shares SIMD 0 with the pivot wave -- takes no
-            // block product and writes the panel out alone, the other six workers share the products
-#ifdef MFGP_LEAF_W4OUT
-            const int nwork = 6, widx = wave < 4 ? wave - 1 : wave - 2;
-            const bool producer = wave != 4;
-#else
-            const int nwork = 7, widx = wave - 1;
-            const bool producer = true;
-#endif
-            auto decode = [&](int idx) -> BlkProd {
-                BlkProd b;
-                int ci, cj;
-                b.sa = 4; b.accumulate = true;
-                if (idx < nP) {
-                    ci = jb + 2 + idx; cj = jb + 1;
-                    b.pa = sL + (ci * 16 + fr) * LP + jb * 16 + q;
-                    b.pb = sL + (cj * 16 + fr) * LP + jb * 16 + q;
-                } else if (idx < nP + nA) {
-                    int ii = 0, rem = idx - nP;
-                    while (rem > ii) { rem -= ii + 1; ++ii; }
-                    ci = jb + 2 + ii; cj = jb + 2 + rem;
-                    b.pa = sL + (ci * 16 + fr) * LP + jb * 16 + q;
-                    b.pb = sL + (cj * 16 + fr) * LP + jb * 16 + q;
-                } else {
-                    const int t = idx - nP - nA;
-                    ci = t / w; cj = jb + 1 + t % w;
-                    b.pb = sL + (cj * 16 + fr) * LP + jb * 16 + q;
-                    if (ci == jb) { b.pa = Yj + q * YP16 + fr; b.sa = 4 * YP16; b.accumulate = false; }
-                    else b.pa = sL + (ci * 16 + fr) * LP + jb * 16 + q;          // (I < jb: "L[I][jb]" read there is X^T[I,jb])
-                }
-                b.pc = sL + (ci * 16 + q) * LP + cj * 16 + fr;
-                return b;
-            };
-            if (producer) {
-                int idx = widx;
-                for (; idx + nwork < nP + nA + nB; idx += 2 * nwork) block_pair(decode(idx), decode(idx + nwork));
-                if (idx < nP + nA + nB) block_one(decode(idx));
-            }
-            LEAF_STAMP(wave, jb + 1, 3);
-#ifdef MFGP_LEAF_W4OUT
-            if (wave == 4) write_panel(jb, lane, 64);
-#else
-            write_panel(jb, tid - 64, 448);
-#endif
-            LEAF_STAMP(wave, jb + 1, 4);
-            if (false)
-#endif
             for (int idx = wave - 1; idx < nP + nA + nB; idx += 7) {
                 if (idx < nP) {
                     update_block(sL, jb + 2 + idx, jb + 1, jb, fr, q);
@@ -492,21 +341,14 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
                     else update_block(sL, I, J, jb, fr, q);     // (I < jb: "L[I][jb]" read there is X^T[I,jb])
                 }
             }
-#ifndef MFGP_LEAF_PAIR
-            LEAF_STAMP(wave, jb + 1, 3);
             // Block column jb of L and row / column block jb of X are final since this panel's solves: write them out now,
             // in the shadow of the micro-Cholesky, panel by panel (16 + <= 32 KB each) instead of 256 KB after the last one.
             write_panel(jb, tid - 64, 448);
-            LEAF_STAMP(wave, jb + 1, 4);
-#endif
         }
         __syncthreads();
-        LEAF_STAMP(wave, jb + 1, 5);
     }
-#endif
     // ---- the last panel's share of the output and the half log-determinant ----
     write_panel(7, tid, LEAF_THREADS);
-    LEAF_STAMP(wave, 8, 6);
     {
         double v = (tid < NB) ? log(sL[tid * LP + tid]) : 0.0;
 #pragma unroll
@@ -531,12 +373,6 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const d
                  info + (int)blockIdx.x * istride);
 }
 
-
-#ifdef MFGP_LEAF_STAMPS
-extern "C" int mfgp_lab_leaf_stamps(unsigned long long* out) {      // lab builds only: not in include/mfgp.h
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mfgp_leaf_stamp_buf), sizeof(unsigned long long) * 8 * 9 * 8);
-}
-#endif
 
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
                  double* logdet_part, int* info, int nbatch, long long bstride, int ldstride, int istride) {

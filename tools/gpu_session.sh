@@ -62,12 +62,6 @@ ab_define)
   done
   build ""
   ;;
-leaf_stamps)
-  # lab build with cycle stamps in the leaf's panel loop (never shipped: the default build is restored at the end)
-  MFGP_BUILD_DEFINES="-DMFGP_LEAF_STAMPS ${AB_DEFINE-}" python -m multifidelity_datafusion_gps_amd.build --force > $out/build.log 2>&1 || { tail -20 $out/build.log; exit 1; }
-  timeout -k 10 120 python tools/leaf_stamps.py > $out/leaf_stamps.txt 2>&1; cat $out/leaf_stamps.txt
-  python -m multifidelity_datafusion_gps_amd.build --force > $out/build.log 2>&1
-  ;;
 pick)
   # selected tests, each group under its own timeout; PICK="file::test ..." (space separated pytest node ids / -k expressions are not split)
   for t in ${PICK:?}; do
