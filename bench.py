@@ -270,8 +270,8 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=170.0):
                          measured, n_lf_evals, n_hf_evals)}
 
 
-PMC_FILE = os.path.join("profiles", "r04_pmc.json")
-MFMA_FILE = os.path.join("profiles", "r04_mfma_counters.json")
+PMC_FILE = os.path.join("profiles", "r05_pmc.json")
+MFMA_FILE = os.path.join("profiles", "r05_mfma_counters.json")
 BARE_MFMA_TFLOPS = 71.0   # bare v_mfma_f64_4x4x4_4b loop on this part (profiles/r03_probes.txt): what the instruction itself can issue
 
 
