@@ -119,6 +119,12 @@ measure)
   timeout -k 10 500 python3 tools/run_configs.py > $out/configs.txt 2>&1; cat $out/configs.txt
   python3 tools/small_n_latency.py > $out/small_n.txt 2>&1; tail -12 $out/small_n.txt
   ;;
+soak)
+  # randomised parity soak against the oracle (240 s) and against the quad-precision values (300 s), and the N = 8192 truth check
+  timeout -k 10 400 python3 tools/fuzz_parity.py 240 ${SOAK_SEED:-51} 3000 > $out/fuzz_parity.txt 2>&1; tail -2 $out/fuzz_parity.txt
+  timeout -k 10 500 python3 tools/fuzz_parity.py 300 ${SOAK_SEED:-51} 700 truth > $out/fuzz_truth.txt 2>&1; tail -2 $out/fuzz_truth.txt
+  timeout -k 10 900 python3 tools/truth_check.py 8192 > $out/truth_check.txt 2>&1; tail -12 $out/truth_check.txt
+  ;;
 accept)
   # what the driver runs at round end: smoke, the whole -m gpu suite, the default bench line (CPU baseline included)
   timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 || { tail -20 $out/smoke.log; exit 1; }
