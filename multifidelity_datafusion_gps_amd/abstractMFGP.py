@@ -188,7 +188,7 @@ class AbstractMFGP(metaclass=abc.ABCMeta):
                 return group
         group = self.comm.shard_group(model._engine, members)
         cache.append((model._engine, tuple(members), group))
-        if group is None and not self.__dict__.get("_shard_group_warned"):
+        if group is None and self.comm.rank in members and not self.__dict__.get("_shard_group_warned"):   # (None is also what a rank OUTSIDE the group gets)
             self.__dict__["_shard_group_warned"] = True
             import warnings
             warnings.warn("multi-GPU: the ranks %s could not form an RCCL group on this level's engine (%s): its sequential evaluations "

@@ -191,6 +191,16 @@ def _rccl_worker(rank, world, port, q):
                 L1 = e.get_L()
                 m1, v1 = e.predict(Xa[:100])
                 res["dist"][n] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), L_equal=bool(np.array_equal(L0, L1)))
+                if n == 900:       # the leader / follower form runs the same distributed plan (one optimiser, the others serve)
+                    comm.barrier()
+                    if rank == 0:
+                        f2, g2 = e.sharded_lead(th * 1.03, nz, 1e-8)
+                        e.sharded_release()
+                    else:
+                        assert e.sharded_serve() == 1
+                        f2, g2 = None, None
+                    f3, g3 = e.eval(th * 1.03, nz, 1e-8)
+                    res["dist"]["lead"] = (f2, g2, f3, g3)
             Xd = np.vstack([Xa[:700], Xa[300:600]])        # duplicated rows, no noise, no jitter: not positive definite
             e.set_data(Xd, np.concatenate([Y[:700], Y[300:600]]))
             e.set_kernel(cases.composite(4, 1))
@@ -272,6 +282,9 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
                 (f0, g0, m0, v0), (f1, g1, m1, v1) = d["single"], d["sharded"]
                 assert f1 == f0 and np.array_equal(g1, g0) and d["L_equal"], (r, n)
                 assert np.array_equal(m1, m0) and np.array_equal(v1, v0), (r, n)
+            f2, g2, f3, g3 = o["dist"]["lead"]
+            if r == 0:
+                assert f2 == f3 and np.array_equal(g2, g3)
             p_single, p_dist = o["dist"]["not_pd"]
             assert p_single > 0 and p_dist == p_single, o["dist"]["not_pd"]
 
