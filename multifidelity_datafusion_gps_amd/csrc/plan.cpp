@@ -836,7 +836,7 @@ void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& o
     p = Plan{};
     p.opts = opts;
     p.shard = shard;
-    p.shard.dist = shard.size > 1 && (shard.dist || opt(opts.dist_chol, nblk >= 256) != 0);
+    p.shard.dist = shard.size > 1 && (shard.dist || opt(opts.dist_chol, nblk >= 128) != 0);
     if (shard.size > 1) p.opts.kind = 0;      // a sharded evaluation always runs the sweep
     p.t128_min = std::max(1, (opts.t128_min > 0 ? opts.t128_min : (nblk >= 56 ? 600 : 300)) / std::max(1, t128_div));
     p.batch_div = std::max(1, t128_div);

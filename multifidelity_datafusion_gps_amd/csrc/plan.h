@@ -64,14 +64,15 @@ struct PlanOpts {
     int kinv_stream = -1;  // MFGP_KINV_STREAM
     int chain_slim = -1;   // MFGP_CHAIN_SLIM
     int t128_min = 0;      // MFGP_T128_MIN: tiles per launch from which 128-tiles are used
-    int dist_chol = -1;    // MFGP_DIST_CHOL: a sharded evaluation's Cholesky distributed over the group too (Shard::dist; default: from 256
-                           // block columns, N >= 32768 -- below, one GPU factorises faster than the group exchanges panels)
+    int dist_chol = -1;    // MFGP_DIST_CHOL: a sharded evaluation's Cholesky distributed over the group too (Shard::dist; default: from 128
+                           // block columns, N >= 16384 -- below, one GPU factorises faster than the group exchanges panels:
+                           // profiles/r05_dist_projection.txt)
 };
 // Row ownership of a sharded evaluation (mfgp_eval_sharded): the work on the image of the identity / the rows of X^T and the rows
 // of K^-1 -- 2 N^3 / 3 of an evaluation's N^3 flops -- splits by 128-row block with no dependency between blocks; block b belongs
 // to rank shard_owner(b, size): block-cyclic in serpentine order (0 1 .. G-1 G-1 .. 1 0 ...), because the work of a block row
 // falls with its index (rows of X^T: ~ (nb - b)^2) or peaks in the middle (rows of K^-1: ~ b (nb - b)).
-// dist (round 5; SURVEY 8(e) "Cholesky": the 1-D block-cyclic multi-GPU factorisation for N >= 32768): the Cholesky's own work
+// dist (round 5; SURVEY 8(e) "Cholesky": the 1-D block-cyclic multi-GPU factorisation for large N): the Cholesky's own work
 // splits by the same ownership too.  Rank r runs the leaf of the diagonal blocks it owns, the rows of every panel column and of
 // every trailing update of A that lie in its blocks -- N^3 / (3 G) instead of N^3 / 3 flops -- and the plan carries two exchange
 // steps per block column c on the chain: COMM_DIAG(c) (L_cc, X_cc and the leaf's log-det / pivot words from owner(c) to

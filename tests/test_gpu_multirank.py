@@ -168,7 +168,7 @@ def _rccl_worker(rank, world, port, q):
         m1, v1 = e.predict(Xa[:100])
         res["eval_sharded"]["matern_ard_%d" % len(Y)] = dict(single=(f0, g0, m0, v0), sharded=(f1, g1, m1, v1), nograd=(0.0, 0.0))
         # SURVEY 8(e) "Cholesky": the factorisation itself distributed over the group (1-D block-cyclic rows, plan.h Shard::dist; the size
-        # rule turns it on from N = 32768, MFGP_DIST_CHOL=1 here): every rank factorises only the diagonal blocks it owns and runs only
+        # rule turns it on from N = 16384, MFGP_DIST_CHOL=1 here): every rank factorises only the diagonal blocks it owns and runs only
         # its rows of the panels and trailing updates; the diagonal blocks and panel columns travel (ncclBroadcast / ncclAllGather per
         # block column).  Bitwise the single evaluation -- NLML, gradient, the factor itself, predictions -- and a matrix that is not
         # positive definite reports the same pivot on every rank.
