@@ -655,6 +655,7 @@ def main():
                        "jitter_retries_per_step_rank0": per_step, "jitter_retries_same_in_every_step": retries_stable,
                        "failed_evaluations_in_timed_steps": sum(p["failed_evaluations"] for p in phases),
                        "fitted_noise_variance": phases[-1]["fitted_noise_variance"],
+                       "shard_groups_formed": int(getattr(comm, "groups_formed", 0)),   # (communicators created beside the world's: once per group, not per step)
                        "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
                        "sharding": sharding_note(world, args.restarts, int(engines["lf"].comm_size))},

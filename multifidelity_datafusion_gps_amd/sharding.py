@@ -438,6 +438,31 @@ class SocketComm:
             return ShardGroup(engine, self.rank, self.size)
         if engine is self._engine:
             return None              # one communicator per handle: the world's lives here
+        # A group formed before on the SAME engine handle is reused while its communicator is alive: creating one is a collective
+        # (ncclCommInitRank: a rendezvous over TCP + hundreds of milliseconds on real links) and a job that builds a fresh model
+        # object per fit on the same engines (bench.py does, per timed step) must not pay it inside every fit.  Every rank -- members
+        # and the others -- keeps the same record, so all of them reuse or none does.
+        mine = self.rank in members
+        cache = self.__dict__.setdefault("_shard_group_cache", [])
+        found = None
+        for k, (eng, mem, grp) in enumerate(cache):
+            if eng is engine and mem == tuple(members):
+                found = k
+                break
+        valid = found is not None and getattr(engine, "_h", None) is not None and not getattr(engine, "comm_aborted", False) and \
+            (not mine or (cache[found][2] is not None and getattr(engine, "comm_size", 1) == len(members)))
+        # (one small agreement over the host rendezvous: a rank whose record went stale -- its handle closed, its communicator destroyed or
+        # replaced -- makes EVERY rank form the group again; forming it is collective, a lone re-former would wait for ever)
+        if all(self.allgather_object(bool(valid))):
+            return cache[found][2]
+        if found is not None:
+            del cache[found]
+        group = self._form_group(engine, members, init_timeout)
+        self.groups_formed = getattr(self, "groups_formed", 0) + 1      # (communicators created: a job that re-uses its engines forms each group once)
+        cache.append((engine, tuple(members), group))
+        return group
+
+    def _form_group(self, engine, members, init_timeout):
         import threading
         uid, err = None, None
         if self.rank == members[0]:

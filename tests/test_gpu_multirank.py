@@ -138,6 +138,30 @@ def _rccl_worker(rank, world, port, q):
         res["model"] = _model_run(comm, 2)                 # e1 + e2 with the row gathers on RCCL
         # two restarts only: with three ranks one of them is dealt none and SHARES first run -> restart 0 with rank 0 (chain group)
         res["model_r2"] = _model_run(comm, 2, restarts=2)
+        if world == 3:
+            # a job that builds a fresh model per fit on the SAME engine handles (bench.py does, per timed step) forms its groups once:
+            # the second fit reuses the chain group's communicator instead of paying ncclCommInitRank inside the fit
+            import multifidelity_datafusion_gps_amd as mf
+            shared = {k: Engine(0) for k in ("lf", "hf")}
+            formed0 = getattr(comm, "groups_formed", 0)
+            fits = []
+            for _ in range(2):
+                class B2(mf.NARGP):
+                    lf_max_iters = first_run_max_iters = restart_max_iters = 8
+                    eval_cap = 8
+                    num_restarts = 2
+                rng2 = np.random.default_rng(17)
+                X_lf2 = rng2.uniform(size=(300, 2))
+                mdl = B2(2, hf, None, lf_X=X_lf2, lf_Y=lf(X_lf2), seed=3, comm=comm, engines=shared)
+                mdl.fit(rng2.uniform(size=(200, 2)))
+                fits.append(np.array([p.value for p in mdl.hf_model.parameters()]))
+            res["group_reuse"] = dict(formed=getattr(comm, "groups_formed", 0) - formed0, same_fit=bool(np.array_equal(fits[0], fits[1])))
+            for e_ in shared.values():
+                if e_.comm_size > 1:
+                    e_.comm_destroy()
+            comm.barrier()
+            for e_ in shared.values():
+                e_.close()
         # ONE evaluation sharded over the ranks (mfgp_eval_sharded: rows of L^-T and of K^-1 by 128-row block, grouped
         # ncclBroadcast of the rows + ncclAllReduce of the gradient's tile sums): bitwise the single evaluation, at a size with
         # several macro panels and at the north-star size
@@ -276,6 +300,9 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world):
             assert f1 == f0 and np.array_equal(g1, g0), (r, n)
             assert np.array_equal(m1, m0) and np.array_equal(v1, v0), (r, n)
             assert es["nograd"][0] == es["nograd"][1]
+        if world == 3:
+            # two groups per fit (the low-fidelity run's, the chain group's), formed ONCE for the two fits on the shared engines
+            assert o["group_reuse"] == dict(formed=2, same_fit=True), o["group_reuse"]
         if world <= 3:
             for n in (900, 4096):                          # the distributed Cholesky: bitwise the single evaluation, factor included
                 d = o["dist"][n]
