@@ -195,7 +195,13 @@ int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, d
  *   sums (one ncclAllReduce of P + 1 sums per tile) -- are split by 128-row block.  Every rank returns the same nlml / grad,
  *   BITWISE those of mfgp_eval, and is left with the complete factorisation (mfgp_predict works; mfgp_get_Kinv does not: a rank
  *   holds only its own rows).  What a fit's SEQUENTIAL evaluations -- the low-fidelity run, first run -> restart 0 of
- *   src/abstractMFGP.py:131-137 -- gain from more GPUs. */
+ *   src/abstractMFGP.py:131-137 -- gain from more GPUs.
+ *   From 128 block columns (N >= 16384; MFGP_DIST_CHOL=1 / 0 forces it on / off when the handle plans) the Cholesky itself is
+ *   distributed over the group too: 1-D block-cyclic rows with the same ownership, a rank factorises the diagonal blocks it owns
+ *   and runs its rows of every panel and trailing update; per block column one ncclBroadcast (the diagonal blocks) and one
+ *   ncclAllGather (the panel column) sit on the chain.  The same tasks, so the same bits.
+ *   Failure: a rank whose pass fails after the group has started it, or whose peers make no progress for MFGP_SHARD_TIMEOUT_S
+ *   (600), aborts its communicator (mfgp_comm_state = -1; further collective calls return -4) and must end -- nothing hangs. */
 int32_t mfgp_eval_sharded(mfgp_handle* h, const double* theta, double noise, double jitter, int32_t want_grad, double* nlml,
                           double* grad);
 /* The same with ONE optimiser: rank 0 of the communicator LEADS (mfgp_sharded_lead = mfgp_eval_sharded whose arguments reach the
