@@ -75,3 +75,27 @@ def build_and_run(name, models, recorder, adapt_steps=0, model_kw=None):
 
 def _param_values(gp_model):
     return [p.value for p in gp_model.parameters()]
+
+
+def run_gpc_rounds(name, models, recorder, driver_cls, gpc_cls, num_adapts=2, model_kw=None):
+    """The reference's experiment scripts in miniature (tests/utils.py:75-86 of the reference): fit, wrap the model's posterior mean in a
+    polynomial-chaos object, and let the round-based driver (`driver_cls`: the REFERENCE's src/gpc/mfgp_gpc.py::MFGP_GPC in the fixture
+    generator, this package's gpc.MFGP_GPC in the replay test) alternate adaptation and moment refresh.  The polynomial-chaos object is
+    this package's LegendreGPC in both runs (the reference's is a chaospy wrapper; chaospy is not available) -- what the fixture pins
+    is the DRIVER: the order of adapt / update_function / get_mean / get_var / get_mse calls and the cost bookkeeping.  -> histories."""
+    p = PROBLEMS[name]
+    X_lf, X_hf, X_test = make_inputs(name)
+    kw = dict(p["kw"])
+    kw.update(model_kw or {})
+    np.random.seed(p["seed"] + 2000)
+    model = getattr(models, p["cls"])(*p["args"](), **kw)
+    model.fit(X_hf)
+    hf = {2: hf_2d_T, 4: hf_4d_T}[p["dim"]]
+    pce = gpc_cls(lambda x: model.predict(x)[0], np.zeros(p["dim"]), np.ones(p["dim"]), polynomial_order=4, quadrature_order=4)
+    recorder.quiet = True
+    drv = driver_cls(model, pce, num_adapts, float(len(X_hf)), X_test=X_test, Y_test=hf(X_test))
+    drv.adapt()
+    recorder.quiet = False
+    return dict(mean_history=np.array(drv.mean_history, dtype=np.float64), var_history=np.array(drv.var_history, dtype=np.float64),
+                cost_history=np.array(drv.cost_history, dtype=np.float64), mse_history=np.array(drv.mse_history, dtype=np.float64),
+                hf_X=np.asarray(model.hf_X), n_predict=recorder.n_predict, predict_sha=recorder.predict_hash.hexdigest())

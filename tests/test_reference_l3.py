@@ -120,3 +120,30 @@ def test_compat_modules_answer_for_the_reference_imports():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_pce_driver_rounds_match_the_reference_driver():
+    """SURVEY 8(f4), the caller: tests/golden/ref_l3_gpc_nargp_2d.npz was made by the REFERENCE's own round-based driver
+    (/root/reference/src/gpc/mfgp_gpc.py::MFGP_GPC, a GPy-free file, run where it lies) over the reference's NARGP and this package's
+    Legendre PCE.  This package's driver (gpc/mfgp_gpc.py) over this package's NARGP must produce the same rounds: the same 2 x 5
+    acquisitions (same points, same number and hash of acquisition callbacks), the same polynomial-chaos moments, costs and test
+    errors after every round -- bit for bit."""
+    from multifidelity_datafusion_gps_amd.gpc import LegendreGPC, MFGP_GPC
+    z = np.load(os.path.join(GOLDEN, "ref_l3_gpc_nargp_2d.npz"))
+    rec = Recorder()
+    Eng = rec.engine_factory()
+
+    class _Engines(dict):
+        def __missing__(self, key):
+            self[key] = Eng()
+            return self[key]
+
+    kw = dict(engines=_Engines(), adapt_maximizer=ScipyDirectMaximizer(faithful=True))
+    kw["engines"]["lf"], kw["engines"]["hf"]
+    res = l3_problems.run_gpc_rounds("nargp_2d", models, rec, MFGP_GPC, LegendreGPC, num_adapts=2, model_kw=kw)
+    np.testing.assert_array_equal(res["cost_history"], z["res_cost_history"])
+    np.testing.assert_array_equal(res["hf_X"], z["res_hf_X"])
+    np.testing.assert_array_equal(res["mean_history"], z["res_mean_history"])
+    np.testing.assert_array_equal(res["var_history"], z["res_var_history"])
+    np.testing.assert_array_equal(res["mse_history"], z["res_mse_history"])
+    assert res["n_predict"] == int(z["res_n_predict"]) and res["predict_sha"] == str(z["res_predict_sha"])
