@@ -134,7 +134,8 @@ def test_sharded_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
     import json
     # (nblk, ranks); 14 blocks = N 1792: the first size with more than one macro panel.  The full list under the default switches,
     # three of them under the others (the checker executes every rank's plan on the CPU: seconds per rank at 14 blocks)
-    specs = [(3, 2), (5, 2), (8, 3), (9, 4), (14, 3), (16, 4)] if not env else [(5, 2), (9, 4), (14, 2)]
+    # (16 blocks on 4 ranks and 9 on 4 run in the distributed-Cholesky test below, which shares every B / X^T / K^-1 task with this plan)
+    specs = [(3, 2), (5, 2), (8, 3), (14, 3)] if not env else [(5, 2), (9, 4), (14, 2)]
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", _SHARD_DRIVER, simlib, json.dumps(specs)], env=e, capture_output=True, text=True,
@@ -187,7 +188,7 @@ def asan_bin():
     return ASAN_BIN
 
 
-@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_SHIFT": "0"}, {"MFGP_PLAN": "levels"},
+@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_PLAN": "levels"},
                                  {"MFGP_PLAN": "recursive"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0", "MFGP_KINV_STREAM": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_planner_and_checker_are_clean_under_asan_and_ubsan(asan_bin, env):
