@@ -92,7 +92,7 @@ def explicit_inverse_bound(cond, kss, y_scale=1.0, base=PRED_ABS):
     for variances that are ~ 1e-9: GPU run of round 4, cfg3's fitted level) -- the triangular form the HIP path computes does
     not.  The bound is the stated tolerance, widened to EXPLICIT_INVERSE_C * eps * cond * k** where that is larger (measured
     worst over the round-4 soaks -- profiles/r04_fuzz_parity*.txt, 1 900 random cases -- and the configuration runs: 4.10 eps cond_bound (632 low-noise cases up to N = 5000)
-    k**; asserted at ~ 3 x that)."""
+    k**; asserted at ~ 3 x that; round 5's soak of 520 cases up to N = 5000 reached 4.33: profiles/r05_fuzz_parity_n5000_seed61.txt)."""
     return max(base * max(1.0, float(y_scale)), EXPLICIT_INVERSE_C * np.finfo(np.float64).eps * float(cond) * float(kss))
 
 
