@@ -1,9 +1,12 @@
 // comm_rccl.hip -- the exchange steps of the multi-GPU path: one process per GPU, one RCCL
 // communicator per engine handle, collectives enqueued on the handle's own stream.
 //
-//   mfgp_allgather_rows  : the K(X,X) row-block layout of north_star / SURVEY 8(e3): every rank has built its block of
-//                          full rows of Ky in place (mfgp_kbuild_rows); ONE in-place ncclAllGather over xGMI completes the
-//                          matrix on every rank (per-rank message 8 Np^2 / size bytes).
+//   mfgp_allgather_rows  : the K(X,X) row-block layout of north_star / SURVEY 8(e3): every rank has built the rows of the
+//                          128-row blocks it owns (mfgp_kbuild_owned_rows: serpentine block-cyclic deal); the LOWER part of every
+//                          block is packed by owner and ONE ncclAllGather of equal chunks completes the lower triangle of Ky on
+//                          every rank (4 Np (Np + 128) bytes in all: half of what full rows would move).
+//   mfgp_comm_state      : 0 / size / -1 = no communicator / alive / ABORTED (comm_abort: a rank whose shared pass failed, or whose
+//                          peers went silent, tears the communicator down without them and refuses every further collective).
 //   mfgp_allgather_host  : the small gathers -- predictive (mean, variance) row blocks (SURVEY 8(e1), 16 B per test row)
 //                          and restart results (8(e2)) -- host buffer -> device staging -> ncclAllGather -> host.
 //   mfgp_rows_download / mfgp_rows_upload : the same row blocks through host memory, for transports other than RCCL

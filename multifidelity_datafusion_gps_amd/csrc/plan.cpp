@@ -11,7 +11,8 @@ namespace mfgp {
 
 // The planner's switches (environment, read when a handle plans; DESIGN.md "Planner switches").  Only those a GPU test runs
 // (tests/test_gpu_plans.py VARIANTS) and the CPU plan checker covers: MFGP_PLAN, MFGP_MACRO, MFGP_SHIFT, MFGP_KINV_STREAM,
-// MFGP_CHAIN_SLIM, MFGP_T128_MIN.  Everything else the earlier rounds measured is a constant here (the measured best); the
+// MFGP_CHAIN_SLIM, MFGP_T128_MIN, and -- a sharded evaluation's plan only -- MFGP_DIST_CHOL (the Cholesky itself distributed over the rank
+// group: tests/test_gpu_multirank.py, tests/test_plan_host.py).  Everything else the earlier rounds measured is a constant here (the measured best); the
 // variants that lost their A/B live on in tools/gemm_lab/RETIRED.md.
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
