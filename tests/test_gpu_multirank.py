@@ -227,6 +227,21 @@ def _rccl_worker(rank, world, port, q, dist_everywhere=False):
                         f2, g2 = None, None
                     f3, g3 = e.eval(th * 1.03, nz, 1e-8)
                     res["dist"]["lead"] = (f2, g2, f3, g3)
+            if world == 2 and not dist_everywhere:
+                # ... and at the size where the planner turns it on BY ITSELF (128 block columns): no switch in the environment
+                del os.environ["MFGP_DIST_CHOL"]
+                rng = np.random.default_rng(16384)
+                Xb = rng.uniform(size=(16384, 4))
+                Xba = np.hstack([Xb, cases.lf_4d(Xb)[:, None]])
+                Yb = cases.hf_4d(Xb)
+                e.set_data(Xba, Yb)
+                e.set_kernel(cases.composite(4, 1))
+                nzb = 0.01 * Yb.var()
+                f0, g0 = e.eval(th, nzb, 1e-8)
+                comm.barrier()
+                f1, g1 = e.eval_sharded(th, nzb, 1e-8)
+                res["dist"]["default_16384"] = (f0, g0, f1, g1)
+                os.environ["MFGP_DIST_CHOL"] = "1"
             Xd = np.vstack([Xa[:700], Xa[300:600]])        # duplicated rows, no noise, no jitter: not positive definite
             e.set_data(Xd, np.concatenate([Y[:700], Y[300:600]]))
             e.set_kernel(cases.composite(4, 1))
@@ -317,6 +332,9 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world, dist_everywhere):
             f2, g2, f3, g3 = o["dist"]["lead"]
             if r == 0:
                 assert f2 == f3 and np.array_equal(g2, g3)
+            if world == 2 and not dist_everywhere:
+                f0, g0, f1, g1 = o["dist"]["default_16384"]
+                assert f1 == f0 and np.array_equal(g1, g0)
             p_single, p_dist = o["dist"]["not_pd"]
             assert p_single > 0 and p_dist == p_single, o["dist"]["not_pd"]
 
