@@ -268,3 +268,27 @@ def test_failed_evaluation_state_persists_across_a_models_sequential_runs():
         assert m.n_failed_evals == 1 and m._fail_count == 0
         ends[fast] = (r1.x_opt, r1.f_opt, r2.x_opt, r2.f_opt, r2.n_evals, m.n_evals)
     assert all(np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b for a, b in zip(ends[True], ends[False]))
+
+
+def test_thread_per_run_lockstep_survives_out_of_memory_batches():
+    """the thread-per-run form (engine.LockstepEvaluator: the fallback for a scipy whose L-BFGS-B core cannot be driven by reverse
+    communication) meets an engine whose batches never fit: every round goes request by request on the handle's own slab, the fit is
+    the sequential order's bit for bit, and the lanes say how many rounds fell back"""
+    ref = _fit("sequential")
+    E = type("E", (_TightEngine,), dict(sets_that_fit=0, advertised_free=1 << 40))
+    M = type("M", (mf.NARGP,), dict(first_run_max_iters=25, restart_max_iters=25, restart_lockstep=True, lockstep_lanes=2,
+                                    lockstep_threads=True))
+    engines = {k: E() for k in ("hf", "lf", "hf#1")}
+    m = M(2, col(cases.hf_2d), col(cases.lf_2d), seed=3, engines=engines)
+    rng = np.random.default_rng(1)
+    m.fit(rng.uniform(size=(40, 2)))
+    theta = np.array([p.value for p in m.hf_model.parameters()])
+    runs = sorted((round(r.f_opt, 12), tuple(np.round(r.x_opt, 12))) for r in m.hf_model.optimization_runs)
+    mean, var = m.predict(rng.uniform(size=(16, 2)))           # (the factorisation at the winner: the model's count includes it)
+    assert np.array_equal(theta, ref[0]) and runs == ref[1] and m.hf_model.n_evals == ref[2]
+    assert np.array_equal(mean, ref[3]) and np.array_equal(var, ref[4])
+    lanes = m.last_lockstep_lanes
+    assert all(isinstance(ln, gp.LockstepEvaluator) for ln in lanes)
+    assert sum(ln.oom_fallbacks for ln in lanes) == sum(1 for ln in lanes for n in ln.round_sizes if n >= 1) > 0
+    assert m.last_fit_info["driver"].startswith("thread-per-run")
+    assert all(p == 0 for p in engines["hf"].passes)            # no batch ever ran: single evaluations only
