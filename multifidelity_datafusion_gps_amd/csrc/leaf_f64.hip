@@ -14,7 +14,9 @@
 //     the upper triangle of the LDS block), exactly like the planner's sweep one level up,
 //   * per panel, wave 0 runs the critical path back to back -- the solve of block (jb+1, jb), panel jb's update of the next
 //     diagonal block, its micro-Cholesky -- while waves 1-7 solve the rest of the panel and, after ONE barrier, do every other
-//     rank-16 update and write the finished panel out in the micro-Cholesky's shadow (two workgroup barriers per panel).
+//     rank-16 update and write the finished panel out in the micro-Cholesky's shadow (two workgroup barriers per panel);
+//     every solved 16x16 block leaves for global memory straight from the solving wave's accumulators (solve_block), the
+//     shadow pass keeps the diagonal block and the lower strip of the mirrored inverse.
 // Measured history and the variants that lost: LABBOOK.md, tools/gemm_lab/RETIRED.md, profiles/r05_leaf_*.txt.
 #include <stdlib.h>
 #include <mutex>
@@ -148,8 +150,13 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
 // tools/gemm_lab/RETIRED.md.)
 
 // rows of block ib below the diagonal block jb:  X = A Y_jj^T  (x L_jj^T = a), one 16x16 block per wave on MFMA
+// gL / gS != nullptr (the panel loop's solves; round 5): the block is FINAL -- it also leaves for global memory straight from the
+// accumulators, 16 lanes a contiguous 128-byte row segment: a block below the diagonal into the factor, a block above it (X^T[ib,jb])
+// into the upper part of the mirrored inverse, with zeros in its place in the factor -- instead of a pass of the seven worker waves
+// over the LDS block in the micro-Cholesky's shadow, where THEY are the longer side (-2 % per evaluation at N <= 2048, level above)
 template <int YP = LP>
-__device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q) {
+__device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib, int jb, int fr, int q, double* gL = nullptr,
+                                            double* gS = nullptr, int ld = 0) {
     d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -159,6 +166,18 @@ __device__ __forceinline__ void solve_block(double* sL, const double* Y, int ib,
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) sL[(ib * 16 + q + 4 * r) * LP + jb * 16 + fr] = acc[r];
+    if (gL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long o = (long long)(ib * 16 + q + 4 * r) * ld + jb * 16 + fr;
+            if (ib > jb) {
+                gL[o] = acc[r];
+            } else {
+                gL[o] = 0.0;
+                gS[o] = acc[r];
+            }
+        }
+    }
 }
 
 // C[ib][kb] -= L[ib][jb] L[kb][jb]^T on 16x16 blocks of the LDS matrix
@@ -258,12 +277,14 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             if (off[u] >= 0) *reinterpret_cast<d2_t*>(sL + off[u]) = v[u];
     }
     __syncthreads();
-    // output of panel jb by `nthr` threads (t = 0 .. nthr-1): L[:, 16jb:16jb+16] with zeros above the diagonal, and the
+    // output of panel jb by `nthr` threads (t = 0 .. nthr-1): what the solves did not write -- the diagonal 16-block of L, and the
     // mirrored inverse S[r][c] = X[max(r,c)][min(r,c)] for max(r,c) in block jb: X[hi][lo] = X^T[lo][hi] sits in the UPPER part
     // of sL, the diagonal 16-block in sY
+    double* const gL = Lout + g0;        // the solving waves write their finished blocks themselves (solve_block)
+    double* const gS = S + g0;
     auto write_panel = [&](int jb, int t, int nthr) {
-        for (int e = t; e < NB * 8; e += nthr) {
-            const int row = e >> 3, c2 = 8 * jb + (e & 7);
+        for (int e = t; e < 16 * 8; e += nthr) {          // the diagonal 16-block of L (zeros above its diagonal); the rest left with the solves
+            const int row = 16 * jb + (e >> 3), c2 = 8 * jb + (e & 7);
             d2_t v = *reinterpret_cast<const d2_t*>(sL + row * LP + 2 * c2);
             if (2 * c2 > row) v.x = 0.0;
             if (2 * c2 + 1 > row) v.y = 0.0;
@@ -282,10 +303,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             }
             S[g0 + (int64_t)r * ld + c] = v;
         }
-        for (int e = t; e < 16 * 16 * jb; e += nthr) {    // its mirror image: rows above the block, 16 consecutive columns each
-            const int c = e >> 4, r = 16 * jb + (e & 15);
-            S[g0 + (int64_t)c * ld + r] = sL[c * LP + r];
-        }
+        // (its mirror image -- rows above the block -- left with the solves too)
     };
     // Panel loop (round 5: two workgroup barriers per panel instead of three, and the pivot wave's work contiguous).  The leaf's
     // critical path runs through ONE block per panel: the sub-diagonal block (jb+1, jb) is solved, the next diagonal block (jb+1, jb+1)
@@ -304,17 +322,17 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         // phase A -- panel "solves", one 16x16 block per wave: rows below the diagonal give L[ib,jb], rows above give X^T[ib,jb].
         // Wave 0 takes the critical block row jb+1 (the wave that owns that row takes wave 0's row 0), then updates the next diagonal block.
         if (jb == 7) {
-            if (wave != 7) solve_block<YP16>(sL, Yj, wave, 7, fr, q);
+            if (wave != 7) solve_block<YP16>(sL, Yj, wave, 7, fr, q, gL, gS, ld);
             __syncthreads();
             break;
         }
         if (wave == 0) {
-            solve_block<YP16>(sL, Yj, jb + 1, jb, fr, q);
+            solve_block<YP16>(sL, Yj, jb + 1, jb, fr, q, gL, gS, ld);
             wave_handover();
             update_block(sL, jb + 1, jb + 1, jb, fr, q);
         } else {
             const int ib = (wave == jb + 1) ? 0 : wave;
-            if (ib != jb) solve_block<YP16>(sL, Yj, ib, jb, fr, q);
+            if (ib != jb) solve_block<YP16>(sL, Yj, ib, jb, fr, q, gL, gS, ld);
         }
         __syncthreads();
         if (wave == 0) {
