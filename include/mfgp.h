@@ -183,7 +183,8 @@ int32_t mfgp_comm_destroy(mfgp_handle* h);
 /* mfgp_comm_state: 0 = no communicator, n > 0 = a live one of n ranks, -1 = ABORTED: a rank whose sharded pass failed after the group
  *   had been told to start it (or whose peers went silent for MFGP_SHARD_TIMEOUT_S, default 600 s) tears its communicator down
  *   without them (ncclCommAbort) instead of issuing collectives nobody will match; every further collective call on the handle
- *   returns -4 and the process is expected to END with an error, so that its launcher stops the peers. */
+ *   returns -4 and the process is expected to END with an error, so that its launcher stops the peers.  The same deadline guards
+ *   mfgp_allgather_rows and mfgp_allgather_host: a gather the peers never join returns -4 after it instead of blocking for ever. */
 int32_t mfgp_comm_state(mfgp_handle* h);
 int32_t mfgp_allgather_rows(mfgp_handle* h);
 int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, double* recv);

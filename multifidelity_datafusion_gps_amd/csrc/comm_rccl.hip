@@ -17,7 +17,9 @@
 // over whatever the host side uses for rendezvous (sharding.SocketComm: TCP on 127.0.0.1).
 #include <dlfcn.h>
 #include <string.h>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <rccl/rccl.h>
 #include "mfgp_internal.h"
 
@@ -105,6 +107,43 @@ static int comm_usable(mfgp_handle* h, const char* who) {
     if (h->comm_aborted)
         return fail(h, -4, std::string(who) + ": the handle's communicator was aborted after a failed collective; the process must end");
     return 0;
+}
+
+// Waiting for a stream that carries a collective: hipStreamSynchronize never returns when a peer is gone (the RCCL kernel waits for
+// its data for ever).  With a communicator of more than one rank the wait is a poll with a deadline (MFGP_SHARD_TIMEOUT_S, default
+// 600 s -- a pass takes milliseconds, a leader's optimiser step between two passes less); past it the communicator is aborted
+// (which ends the waiting kernel) and the call fails with -4: the rank exits with an error instead of hanging the job.
+static double shard_timeout_s() {
+    const char* v = getenv("MFGP_SHARD_TIMEOUT_S");
+    const double x = v && *v ? atof(v) : 0.0;
+    return x > 0.0 ? x : 600.0;
+}
+int comm_stream_wait(mfgp_handle* h, hipStream_t s, const char* what) {
+    if (!h->comm || h->comm_size <= 1) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        return 0;
+    }
+    const double limit = shard_timeout_s();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) {
+            h->err = std::string(what) + ": " + hipGetErrorString(e);
+            comm_abort(h);
+            return -2;
+        }
+        if ((spins & 63) == 63) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > limit) {
+                comm_abort(h);
+                (void)hipStreamSynchronize(s);      // (the aborted collective's kernel ends; what was enqueued behind it drains)
+                return fail(h, -4, std::string(what) + ": no progress for " + std::to_string((int)limit) +
+                                       " s -- a peer of the group is gone or somewhere else in the protocol; the communicator was aborted");
+            }
+            if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.1 ? 500 : 20));
+        }
+    }
 }
 
 int comm_allgather_chunks(mfgp_handle* h, double* base, size_t chunk, hipStream_t s) {
@@ -241,7 +280,7 @@ int32_t mfgp_allgather_rows(mfgp_handle* h) {
         return rccl_fail(h, "ncclAllGather (row blocks of Ky, lower part)", r);
     }
     launch_shard_rows_copy(s, A, (int)h->Np, nblk, stage, h->drow_off, h->row_chunk, rank, size, true, true);
-    HIPCHK(h, hipStreamSynchronize(s));
+    if (int rc = comm_stream_wait(h, s, "mfgp_allgather_rows: waiting for the all-gather of the row blocks")) return rc;
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -265,8 +304,9 @@ int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, d
     ncclResult_t r = rccl().AllGather(mine, h->dstage, (size_t)count, ncclDouble, static_cast<ncclComm_t>(h->comm),
                                       h->stream);
     if (r != ncclSuccess) return rccl_fail(h, "ncclAllGather (host vectors)", r);
-    HIPCHK(h, hipMemcpyAsync(recv, h->dstage, total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // the deadline wait BEFORE the copy back: a copy into pageable memory blocks the host until the stream reaches it
+    if (int rc = comm_stream_wait(h, h->stream, "mfgp_allgather_host: waiting for the all-gather")) return rc;
+    HIPCHK(h, hipMemcpy(recv, h->dstage, total * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -17,8 +17,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
-#include <chrono>
-#include <thread>
 #include "mfgp_internal.h"
 
 using namespace mfgp;
@@ -741,43 +739,6 @@ static int ensure_shard_plan(mfgp_handle* h, int rank, int size) {
     return 0;
 }
 
-// Waiting for a stream that carries a collective: hipStreamSynchronize never returns when a peer is gone (the RCCL kernel waits for
-// its data for ever).  With a communicator of more than one rank the wait is a poll with a deadline (MFGP_SHARD_TIMEOUT_S, default
-// 600 s -- a pass takes milliseconds, a leader's optimiser step between two passes less); past it the communicator is aborted
-// (which ends the waiting kernel) and the call fails with -4: the rank exits with an error instead of hanging the job.
-static double shard_timeout_s() {
-    const char* v = getenv("MFGP_SHARD_TIMEOUT_S");
-    const double x = v && *v ? atof(v) : 0.0;
-    return x > 0.0 ? x : 600.0;
-}
-static int shard_sync(mfgp_handle* h, hipStream_t s, const char* what) {
-    if (!h->comm || h->comm_size <= 1) {
-        HIPCHK(h, hipStreamSynchronize(s));
-        return 0;
-    }
-    const double limit = shard_timeout_s();
-    const auto t0 = std::chrono::steady_clock::now();
-    for (long spins = 0;; ++spins) {
-        const hipError_t e = hipStreamQuery(s);
-        if (e == hipSuccess) return 0;
-        if (e != hipErrorNotReady) {
-            h->err = std::string(what) + ": " + hipGetErrorString(e);
-            comm_abort(h);
-            return -2;
-        }
-        if ((spins & 63) == 63) {
-            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (el > limit) {
-                comm_abort(h);
-                (void)hipStreamSynchronize(s);      // (the aborted collective's kernel ends; what was enqueued behind it drains)
-                return fail(h, -4, std::string(what) + ": no progress for " + std::to_string((int)limit) +
-                                       " s -- a peer of the group is gone or somewhere else in the protocol; the communicator was aborted");
-            }
-            if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.1 ? 500 : 20));
-        }
-    }
-}
-
 // the pass of rank `rank` of `size`; exchange = false: without the collectives (what one rank's GPU does, timed by
 // mfgp_dbg_eval_as_rank for the projections of DESIGN.md section 7 -- its results are NOT an evaluation's)
 static int sharded_pass(mfgp_handle* h, const double* theta, double noise, double jitter, bool want_grad, int rank, int size,
@@ -874,7 +835,7 @@ static int ctl_exchange(mfgp_handle* h, double* ctl, bool leader) {
     if (rc) return rc;
     if (!leader) {
         HIPCHK(h, hipMemcpyAsync(h->hctl, h->dctl, CTL_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (int rs = shard_sync(h, s, "mfgp_sharded_serve: waiting for the leader's control block")) return rs;
+        if (int rs = comm_stream_wait(h, s, "mfgp_sharded_serve: waiting for the leader's control block")) return rs;
         memcpy(ctl, h->hctl, CTL_WORDS * sizeof(double));
     }
     return 0;
@@ -883,8 +844,8 @@ static int ctl_exchange(mfgp_handle* h, double* ctl, bool leader) {
 // a failure on this rank AFTER the control block told the group to start a pass: its collectives can no longer be matched
 static int shard_broken(mfgp_handle* h, int rc) {
     const std::string why = h->err;
-    (void)hipStreamSynchronize(h->stream2 ? h->stream2 : h->stream);
-    comm_abort(h);
+    comm_abort(h);                        // first: it also ends a collective of this rank that waits for a peer, so that the streams drain
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     (void)hipStreamSynchronize(h->stream);
     h->err = why + " [inside a pass the group had already started: the communicator was aborted, no further collective is issued]";
     h->factorized = h->kinv_valid = h->grad_valid = false;
@@ -892,7 +853,7 @@ static int shard_broken(mfgp_handle* h, int rc) {
 }
 
 static int sharded_finish(mfgp_handle* h, bool want_grad) {
-    if (int rs = shard_sync(h, h->stream, "sharded evaluation: waiting for the pass (all-gather / all-reduce with the group)")) return rs;
+    if (int rs = comm_stream_wait(h, h->stream, "sharded evaluation: waiting for the pass (all-gather / all-reduce with the group)")) return rs;
     const bool streamed_flag = h->pl.kinv_streamed;       // finish_eval's flop accounting looks at the handle's own plan:
     h->pl.kinv_streamed = false;                          // a sharded pass never streams K^-1
     const int rc = finish_eval(h, want_grad);
@@ -939,7 +900,7 @@ int32_t mfgp_sharded_release(mfgp_handle* h) {
     double ctl[CTL_WORDS] = {0.0};
     const int rc = ctl_exchange(h, ctl, true);
     if (rc) return rc;
-    return shard_sync(h, h->stream, "mfgp_sharded_release: waiting for the followers to take the release");
+    return comm_stream_wait(h, h->stream, "mfgp_sharded_release: waiting for the followers to take the release");
 }
 
 int32_t mfgp_dbg_fail_sharded_after(mfgp_handle* h, int32_t n) {
@@ -959,7 +920,8 @@ int32_t mfgp_sharded_serve(mfgp_handle* h, int64_t* served) {
         rc = ctl_exchange(h, ctl, false);
         if (rc) return rc;
         if (ctl[0] == 0.0) break;
-        if ((int)ctl[4] != h->spec.np) return fail(h, -1, "mfgp_sharded_serve: the leader's kernel has another parameter count");
+        if ((int)ctl[4] != h->spec.np)       // (the leader is inside the pass already: its collectives must not wait for this rank)
+            return shard_broken(h, fail(h, -1, "mfgp_sharded_serve: the leader's kernel has another parameter count"));
         const bool g = ctl[1] != 0.0;
         if (h->dbg_fail_sharded_in > 0 && --h->dbg_fail_sharded_in == 0)
             return shard_broken(h, fail(h, -2, "mfgp_sharded_serve: injected failure (mfgp_dbg_fail_sharded_after)"));

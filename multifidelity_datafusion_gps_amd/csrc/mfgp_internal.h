@@ -224,6 +224,9 @@ inline int fail(mfgp_handle* h, int code, const std::string& msg) {
 void comm_release(mfgp_handle* h);
 // tears it down without the peers (ncclCommAbort) and poisons the handle's collective calls
 void comm_abort(mfgp_handle* h);
+// wait for a stream that carries a collective: a poll with a deadline (MFGP_SHARD_TIMEOUT_S), never hipStreamSynchronize; past the
+// deadline the communicator is aborted and the call fails with -4
+int comm_stream_wait(mfgp_handle* h, hipStream_t s, const char* what);
 // collectives of a sharded evaluation on the handle's communicator and stream (no-ops for a communicator of one / none):
 //   -> 0 or a negative status (h->err set)
 //   in-place all-gather of equal chunks: rank r's `chunk` doubles already sit at base + r * chunk

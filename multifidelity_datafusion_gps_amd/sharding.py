@@ -244,6 +244,8 @@ class SocketComm:
         self._engine = None
         self._peers = []       # hub: sockets of ranks 1..size-1, in rank order
         self._hub = None       # spoke: socket to rank 0
+        self._shard_group_cache = []     # (engine, members, ShardGroup | None): the groups formed so far (shard_group)
+        self.groups_formed = 0           # communicators created for groups: a job that re-uses its engines forms each group once
         if self.size == 1:
             return
         loopback = addr in ("127.0.0.1", "localhost", "::1")
@@ -443,7 +445,7 @@ class SocketComm:
         # object per fit on the same engines (bench.py does, per timed step) must not pay it inside every fit.  Every rank -- members
         # and the others -- keeps the same record, so all of them reuse or none does.
         mine = self.rank in members
-        cache = self.__dict__.setdefault("_shard_group_cache", [])
+        cache = self._shard_group_cache
         found = None
         for k, (eng, mem, grp) in enumerate(cache):
             if eng is engine and mem == tuple(members):
@@ -458,7 +460,7 @@ class SocketComm:
         if found is not None:
             del cache[found]
         group = self._form_group(engine, members, init_timeout)
-        self.groups_formed = getattr(self, "groups_formed", 0) + 1      # (communicators created: a job that re-uses its engines forms each group once)
+        self.groups_formed += 1
         cache.append((engine, tuple(members), group))
         return group
 

@@ -460,3 +460,65 @@ def test_a_leader_that_fails_inside_a_shared_pass_ends_the_group_instead_of_hang
     assert "aborted" in lead["release"] and lead["release"] != "issued", lead
     assert foll["error"] is not None and foll["aborted"] and foll["seconds"] < 60, foll
     assert [p.exitcode for p in procs] == [7, 7]
+
+
+def _unmatched_gather_worker(rank, port, q):
+    import os
+    import sys
+    import time
+    from multifidelity_datafusion_gps_amd import sharding
+    os.environ.update(sharding.rehearsal_env(rank))
+    os.environ["MFGP_SHARD_TIMEOUT_S"] = "5"
+    from multifidelity_datafusion_gps_amd._lib import Engine
+    comm = sharding.SocketComm(rank, 2, "127.0.0.1", port, timeout=120)
+    e = Engine(0)
+    comm.attach_engine(e, required=True, init_timeout=90)
+    np.testing.assert_array_equal(e.allgather_host(np.full(3, float(rank))).reshape(-1), np.repeat([0.0, 1.0], 3))    # a matched gather first
+    comm.barrier()
+    res = {"rank": rank, "error": None}
+    t0 = time.perf_counter()
+    if rank == 0:
+        try:
+            e.allgather_host(np.arange(5.0))               # rank 1 never issues its half
+        except RuntimeError as ex:
+            res["error"] = str(ex)
+        res["seconds"] = time.perf_counter() - t0
+        res["aborted"] = bool(e.comm_aborted)
+        try:
+            e.allgather_host(np.arange(5.0))
+            res["again"] = "issued"
+        except RuntimeError as ex:
+            res["again"] = str(ex)
+    else:
+        time.sleep(12.0)                                   # alive, its communicator intact, but somewhere else in the protocol
+    q.put((rank, res))
+    q.close()
+    q.join_thread()
+    sys.stderr.write("rank %d: %s\n" % (rank, res))
+    sys.stderr.flush()
+    os._exit(0)
+
+
+def test_a_gather_the_peer_never_joins_gives_up_after_the_deadline():
+    """Every wait for a stream that carries a collective is the poll with a deadline (comm_stream_wait), the small host gathers and
+    the row-block gather included: a peer that never issues its half costs MFGP_SHARD_TIMEOUT_S, then the communicator is aborted,
+    the call fails with a message that says so, and further collectives on the handle are refused."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_unmatched_gather_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        out = dict(q.get(timeout=150) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    lone = out[0]
+    assert lone["error"] is not None and "no progress for 5 s" in lone["error"], lone
+    assert lone["aborted"] and 4.0 < lone["seconds"] < 30.0, lone
+    assert lone["again"] != "issued" and "aborted" in lone["again"], lone
