@@ -42,14 +42,33 @@ def simlib():
     return LIB
 
 
+_WORKERS = max(1, min(4, (os.cpu_count() or 2) // 2))      # checker processes side by side (each is single-threaded)
+
+
+def _spread(specs, call):
+    """`call(list of specs) -> list of results`, the specs dealt round-robin over _WORKERS concurrent calls; results in spec order"""
+    from concurrent.futures import ThreadPoolExecutor
+    specs = list(specs)
+    parts = [specs[k::_WORKERS] for k in range(_WORKERS) if specs[k::_WORKERS]]
+    with ThreadPoolExecutor(len(parts) or 1) as pool:
+        outs = list(pool.map(call, parts))
+    res = [None] * len(specs)
+    for k, out in enumerate(outs):
+        res[k::_WORKERS] = out
+    return res
+
+
 def _run(lib, specs, env=None):
-    """the planner reads its switches from the environment when it plans: one subprocess per environment"""
+    """the planner reads its switches from the environment when it plans: subprocesses per environment"""
     import json
     e = dict(os.environ)
     e.update(env or {})
-    r = subprocess.run([sys.executable, "-c", _DRIVER, lib, json.dumps(specs)], env=e, capture_output=True, text=True,
-                       check=True)
-    return json.loads(r.stdout)
+
+    def call(part):
+        r = subprocess.run([sys.executable, "-c", _DRIVER, lib, json.dumps(part)], env=e, capture_output=True, text=True,
+                           check=True)
+        return json.loads(r.stdout)
+    return _spread(specs, call)
 
 
 ENVS = [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}, {"MFGP_SHIFT": "0"}, {"MFGP_KINV_STREAM": "0"},
@@ -123,6 +142,18 @@ print(json.dumps(out))
 """
 
 
+def _run_sharded(lib, specs, env, entry="plan_sim_sharded"):
+    import json
+    e = dict(os.environ)
+    e.update(env)
+
+    def call(part):
+        r = subprocess.run([sys.executable, "-c", _SHARD_DRIVER, lib, json.dumps(part), entry], env=e, capture_output=True, text=True,
+                           check=True)
+        return json.loads(r.stdout)
+    return _spread(specs, call)
+
+
 @pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_sharded_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
@@ -131,16 +162,12 @@ def test_sharded_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
     rebuilt from the upper one, every rank's K^-1 rows accumulated -- each rank's plan race-free, and L, S and the owned rows of
     K^-1 BITWISE what one rank computes alone (same tasks, same arithmetic); the largest rank plan shrinks towards
     1/3 + 2/(3 G) of the single plan's tasks as the matrix grows."""
-    import json
     # (nblk, ranks); 14 blocks = N 1792: the first size with more than one macro panel.  The full list under the default switches,
     # three of them under the others (the checker executes every rank's plan on the CPU: seconds per rank at 14 blocks)
     # (16 blocks on 4 ranks and 9 on 4 run in the distributed-Cholesky test below, which shares every B / X^T / K^-1 task with this plan)
     specs = [(3, 2), (5, 2), (8, 3), (14, 3)] if not env else [(5, 2), (9, 4), (14, 2)]
-    e = dict(os.environ)
-    e.update(env)
-    r = subprocess.run([sys.executable, "-c", _SHARD_DRIVER, simlib, json.dumps(specs)], env=e, capture_output=True, text=True,
-                       check=True)
-    for (nb, size), (rc, rep, msg) in zip(specs, json.loads(r.stdout)):
+    results = _run_sharded(simlib, specs, env)
+    for (nb, size), (rc, rep, msg) in zip(specs, results):
         assert rc == 0 and rep[0] == 0, (nb, size, msg)
         assert rep[1] < 1e-12, (nb, size, rep)               # X L = I after the exchange
         assert rep[2] == 0 and rep[3] == 0, (nb, size, rep)    # no word of L / S / own K^-1 rows differs from the single run
@@ -156,13 +183,9 @@ def test_distributed_cholesky_plans_reproduce_the_single_plan_bit_for_bit(simlib
     in lock step over the ranks' own copies of the matrices (pre-filled with NaN: a rank that read a row it never received would
     poison its result).  Each rank's schedule is race-free, the exchange steps come in the same order on every rank, L, S and
     the owned rows of K^-1 are BITWISE the single plan's, and the largest rank's task count falls towards 1/G of it."""
-    import json
     specs = [(3, 2), (8, 3), (14, 3), (16, 4)] if not env else [(5, 2), (9, 4), (14, 2)]
-    e = dict(os.environ)
-    e.update(env)
-    r = subprocess.run([sys.executable, "-c", _SHARD_DRIVER, simlib, json.dumps(specs), "plan_sim_dist"], env=e, capture_output=True,
-                       text=True, check=True)
-    for (nb, size), (rc, rep, msg) in zip(specs, json.loads(r.stdout)):
+    results = _run_sharded(simlib, specs, env, "plan_sim_dist")
+    for (nb, size), (rc, rep, msg) in zip(specs, results):
         assert rc == 0 and rep[0] == 0, (nb, size, rc, msg)
         assert rep[1] < 1e-12, (nb, size, rep)               # X L = I on rank 0 (its L is part computed, part received)
         assert rep[2] == 0 and rep[3] == 0, (nb, size, rep)    # no word of L / S / own K^-1 rows differs from the single run
@@ -170,7 +193,7 @@ def test_distributed_cholesky_plans_reproduce_the_single_plan_bit_for_bit(simlib
         # bytes through the Cholesky's exchange steps: 2 diagonal blocks + the blocks below, per block column
         assert rep[5] == 8 * 128 * 128 * sum(2 + (nb - 1 - c) for c in range(nb)), (nb, size, rep[5])
     if not env:
-        share = {(nb, size): rep[4] for (nb, size), (rc, rep, msg) in zip(specs, json.loads(r.stdout))}
+        share = {(nb, size): rep[4] for (nb, size), (rc, rep, msg) in zip(specs, results)}
         assert share[(16, 4)] < 0.45 and share[(14, 3)] < 0.55, share   # (sharded without dist: 1/3 + 2/(3 G) = 0.5 / 0.56 at best)
 
 
@@ -200,10 +223,14 @@ def test_planner_and_checker_are_clean_under_asan_and_ubsan(asan_bin, env):
     e.update(env)
     e["ASAN_OPTIONS"] = "detect_leaks=1:abort_on_error=0:exitcode=97"
     e["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
-    r = subprocess.run([asan_bin] + [str(v) for spec in specs for v in spec], env=e, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
-    lines = r.stdout.strip().splitlines()
+    def call(part):
+        r = subprocess.run([asan_bin] + [str(v) for spec in part for v in spec], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+        out = r.stdout.strip().splitlines()
+        assert len(out) == len(part)
+        return out
+    lines = _spread(specs, call)
     assert len(lines) == len(specs)
     for spec, line in zip(specs, lines):
         assert line.split()[0] == "0", (spec, line)
