@@ -34,7 +34,9 @@ rehearsal)
   # the N-rank bench at FULL size on the one-GPU box (every rank on GPU 0, RCCL over its socket transport: sharding.rehearsal_env).
   # 6 ranks is the most the box allows on its card (process guard); the 8-rank layout is rehearsed on the CPU (tests/test_bench_launcher.py)
   for n in ${RANKS:-6}; do
-    timeout -k 10 900 python bench.py --gpus $n --single-device --no-cpu-baseline --steps 1 --warmup 1 > $out/bench_n$n.json 2> $out/bench_n$n.err || { tail -30 $out/bench_n$n.err; exit 1; }
+    # REHEARSAL_ARGS="--restarts 4" with 6 ranks: the 8-rank layout's STRUCTURE (restarts on the last ranks, ranks 1-2 idle -> a chain group
+    # of 3 shares first run -> restart 0) within the 6 processes the box admits; RANKS=1 with the same arguments gives its reference line
+    timeout -k 10 900 python bench.py --gpus $n $([ $n -gt 1 ] && echo --single-device) --no-cpu-baseline --steps 1 --warmup 1 ${REHEARSAL_ARGS:-} > $out/bench_n$n.json 2> $out/bench_n$n.err || { tail -30 $out/bench_n$n.err; exit 1; }
     last_json $out/bench_n$n.json
   done
   ;;
