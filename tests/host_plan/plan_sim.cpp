@@ -573,6 +573,62 @@ static int plan_sim_group(int nblk, int size, bool dist, double* report, char* m
     return report[0] > 0 ? 1 : 0;
 }
 
+// SCHEDULE ONLY (no arithmetic: any size) of a group's plans -- at the sizes the plans are made for, N = 8192 ... 32768 on 8 ranks: every
+// rank's plan race-free, every wait behind its record, the exchange steps met in the same order by every rank.
+// report[0] = races (all ranks), [4] = largest rank's tasks / tasks of the unsharded plan, [5] = bytes through the Cholesky's exchange
+// steps, [6] = exchange steps per rank
+int plan_sim_group_schedule(int nblk, int size, int dist, double* report, char* msg, int msglen) {
+    const PlanOpts opts = plan_opts_from_env();
+    const int64_t ld = (int64_t)nblk * NB, stride = ld * ld;
+    for (int i = 0; i < 8; ++i) report[i] = 0.0;
+    if (msg && msglen) msg[0] = 0;
+    size_t ref_tasks = 0;
+    {
+        Plan ref;
+        PlanOpts o = opts;
+        o.kinv_stream = 0;
+        build_plan(ref, nblk, ld, stride, o);
+        for (const Step& st : ref.steps) if (st.kind == 1) ref_tasks += (size_t)st.count;
+        ref_tasks += (size_t)ref.kinv_step.count;
+    }
+    std::vector<std::vector<std::pair<int, int>>> order((size_t)size);
+    size_t max_tasks = 0;
+    for (int r = 0; r < size; ++r) {
+        Sim s;                                   // one rank at a time: the race cells of 256 block columns are 1 M per matrix
+        s.ld = ld; s.stride = stride;
+        Shard sh;
+        sh.rank = r; sh.size = size;
+        PlanOpts o = opts;
+        o.dist_chol = dist ? 1 : 0;
+        build_plan(s.p, nblk, ld, stride, o, 1, sh);
+        std::vector<double> dummy;
+        prepare(s, false, dummy, nullptr);
+        Walker w;
+        for (;;) {
+            const int at = w.run(s, 0, 1, msg, msglen);
+            if (at < 0) return at;
+            if (at == (int)s.p.steps.size()) break;
+            const Step& st = s.p.steps[(size_t)at];
+            order[(size_t)r].push_back({st.kind, st.blk});
+            if (r == 0) report[5] += 8.0 * NB * NB * (st.kind == STEP_COMM_DIAG ? 2 : nblk - 1 - st.blk);
+            w.resume();
+        }
+        report[0] += s.races;
+        if (s.races && msg && !msg[0]) snprintf(msg, msglen, "rank %d: %d races; first: %s", r, s.races, s.first_race.c_str());
+        size_t nt = 0;
+        for (const Step& st : s.p.steps) if (st.kind == 1) nt += (size_t)st.count;
+        max_tasks = std::max(max_tasks, nt + (size_t)s.p.kinv_step.count);
+        if (order[(size_t)r] != order[0]) {
+            snprintf(msg, msglen, "rank %d meets its exchange steps in another order than rank 0 (%zu against %zu steps)", r,
+                     order[(size_t)r].size(), order[0].size());
+            return -6;
+        }
+    }
+    report[4] = (double)max_tasks / (double)ref_tasks;
+    report[6] = (double)order[0].size();
+    return report[0] > 0 ? 1 : 0;
+}
+
 int plan_sim_sharded(int nblk, int size, double* report, char* msg, int msglen) { return plan_sim_group(nblk, size, false, report, msg, msglen); }
 // the same with the DISTRIBUTED Cholesky (plan.h Shard::dist): every rank runs only its own rows of the panels and of the trailing
 // updates, the diagonal blocks and the panel columns travel through the plan's exchange steps (executed here in lock step over the

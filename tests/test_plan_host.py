@@ -197,6 +197,44 @@ def test_distributed_cholesky_plans_reproduce_the_single_plan_bit_for_bit(simlib
         assert share[(16, 4)] < 0.45 and share[(14, 3)] < 0.55, share   # (sharded without dist: 1/3 + 2/(3 G) = 0.5 / 0.56 at best)
 
 
+_SCHED_DRIVER = r"""
+import ctypes, json, sys
+lib = ctypes.CDLL(sys.argv[1])
+fn = lib.plan_sim_group_schedule
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+out = []
+for nb, size, dist in json.loads(sys.argv[2]):
+    rep = (ctypes.c_double * 8)()
+    msg = ctypes.create_string_buffer(512)
+    rc = fn(nb, size, dist, rep, msg, 512)
+    out.append([rc, list(rep), msg.value.decode()])
+print(json.dumps(out))
+"""
+
+
+def test_group_schedules_at_the_sizes_of_the_eight_rank_job(simlib):
+    """What no one-GPU rig can run: the plans of an 8-rank group at the sizes they are made for -- the bench's LF group (64 block
+    columns on 8 ranks) and chain group (on 3), and the distributed Cholesky at N = 8192 / 16384 (its default threshold) / 32768 on 8
+    ranks.  Schedule only (no arithmetic): every rank's plan free of races with every wait behind its record, the exchange steps met
+    in the same order by all ranks (2 nb - 1 of them, 8 * 128 * 128 * (2 + blocks below) bytes per column), and the largest rank's task list
+    near 1/8 of the single plan's under the distributed Cholesky."""
+    import json
+    specs = [(64, 8, 0), (64, 3, 0), (64, 8, 1), (128, 8, 1), (128, 8, 0), (256, 8, 1), (128, 5, 1)]
+
+    def call(part):
+        r = subprocess.run([sys.executable, "-c", _SCHED_DRIVER, simlib, json.dumps(part)], capture_output=True, text=True, check=True)
+        return json.loads(r.stdout)
+    for (nb, size, dist), (rc, rep, msg) in zip(specs, _spread(specs, call)):
+        assert rc == 0 and rep[0] == 0, (nb, size, dist, rc, msg)
+        if dist:
+            assert rep[6] == 2 * nb - 1, (nb, size, rep)
+            assert rep[5] == 8 * 128 * 128 * sum(2 + (nb - 1 - c) for c in range(nb)), (nb, size, rep)
+            assert rep[4] < 1.0 / size + 0.1, (nb, size, rep)
+        else:
+            assert rep[6] == 0 and rep[4] < 1.0, (nb, size, rep)
+
+
 # ---- the same planner + checker under AddressSanitizer / UndefinedBehaviorSanitizer (CPU build; SURVEY section 5) -------------
 ASAN_BIN = os.path.join(ROOT, "tests", "host_plan", "plan_sim_asan")
 ASAN_SRC = SRC + [os.path.join(ROOT, "tests", "host_plan", "plan_sim_main.cpp")]
