@@ -241,6 +241,18 @@ def _rccl_worker(rank, world, port, q, dist_everywhere=False):
                 comm.barrier()
                 f1, g1 = e.eval_sharded(th, nzb, 1e-8)
                 res["dist"]["default_16384"] = (f0, g0, f1, g1)
+                # ... and at N = 32768, the size SURVEY 8(e) names for it (256 block columns, a 34 GB slab per rank, 4.3 GB of panels
+                # through 511 exchange steps)
+                rng = np.random.default_rng(32768)
+                Xc = rng.uniform(size=(32768, 4))
+                Yc = cases.hf_4d(Xc)
+                e.set_data(np.hstack([Xc, cases.lf_4d(Xc)[:, None]]), Yc)
+                e.set_kernel(cases.composite(4, 1))
+                nzc = 0.01 * Yc.var()
+                f0, g0 = e.eval(th, nzc, 1e-8)
+                comm.barrier()
+                f1, g1 = e.eval_sharded(th, nzc, 1e-8)
+                res["dist"]["default_32768"] = (f0, g0, f1, g1)
                 os.environ["MFGP_DIST_CHOL"] = "1"
             Xd = np.vstack([Xa[:700], Xa[300:600]])        # duplicated rows, no noise, no jitter: not positive definite
             e.set_data(Xd, np.concatenate([Y[:700], Y[300:600]]))
@@ -333,8 +345,9 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world, dist_everywhere):
             if r == 0:
                 assert f2 == f3 and np.array_equal(g2, g3)
             if world == 2 and not dist_everywhere:
-                f0, g0, f1, g1 = o["dist"]["default_16384"]
-                assert f1 == f0 and np.array_equal(g1, g0)
+                for key in ("default_16384", "default_32768"):
+                    f0, g0, f1, g1 = o["dist"][key]
+                    assert f1 == f0 and np.array_equal(g1, g0), key
             p_single, p_dist = o["dist"]["not_pd"]
             assert p_single > 0 and p_dist == p_single, o["dist"]["not_pd"]
 
