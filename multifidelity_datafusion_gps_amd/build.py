@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmfgp_hip.so")
-SOURCES = ["gemm_f64.hip", "leaf_f64.hip", "covariance.hip", "vecops.hip", "comm_rccl.hip", "plan.cpp", "mfgp_api.hip"]
+SOURCES = ["gemm_f64.hip", "leaf_f64.hip", "covariance.hip", "vecops.hip", "trimv_f64.hip", "comm_rccl.hip", "plan.cpp", "mfgp_api.hip"]
 HEADERS = ["mfgp_internal.h", "plan.h", os.path.join("..", "..", "include", "mfgp.h")]
 
 

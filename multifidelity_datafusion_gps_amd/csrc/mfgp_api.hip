@@ -1017,10 +1017,14 @@ int32_t mfgp_eval_prebuilt(mfgp_handle* h, int32_t want_grad, double* nlml, doub
     return 0;
 }
 
+static double prior_variance(const mfgp_handle* h);
+static int ensure_xs(mfgp_handle* h, int rows_p);
+
 // rank-1 append at fixed hyper-parameters (the adaptation loop of src/abstractMFGP.py:320,354 grows the
 // training set by one row per step).  O(N^2): one covariance row, two triangular mat-vecs with the stored inverse
-// factor, one finishing kernel, one mat-vec for alpha.  Returns 0 = appended; 1 = no padding slot left (N is a multiple
-// of 128: the caller re-uploads and refactorises); >1 = not positive definite with the new row.
+// factor (l = X k, w = X^T l: 8 Np^2 bytes in all), one finishing kernel that also brings alpha up to date in O(N).
+// Returns 0 = appended; 1 = no padding slot left (N is a multiple of 128: the caller re-uploads and refactorises);
+// >1 = not positive definite with the new row.
 int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     int rc = check_ready(h, "mfgp_append_row");
     if (rc) return rc;
@@ -1031,33 +1035,22 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     hipStream_t s = h->stream;
     const int n = (int)h->N, D = h->D;
     const int64_t Np = h->Np;
-    // stage the new row as a 128-row zero-padded panel operand; X[n] / Y[n] are written by the finishing kernel, and only
+    // stage the new row as a 64-row zero-padded panel operand; X[n] / Y[n] are written by the finishing kernel, and only
     // if the extension is positive definite (a rejected append leaves the handle's data untouched)
-    if (128 > h->xs_cap_rows || D != h->xs_cap_D) {
-        HIPCHK(h, hipStreamSynchronize(s));
-        if (h->dXs) HIPCHK(h, hipFree(h->dXs));
-        h->xs_cap_rows = std::max(128, h->xs_cap_rows);
-        h->xs_cap_D = D;
-        HIPCHK(h, hipMalloc(&h->dXs, (size_t)h->xs_cap_rows * D * sizeof(double)));
-    }
-    memset(h->hio, 0, (size_t)128 * D * sizeof(double));      // (pinned staging: one asynchronous copy, see mfgp_predict)
+    rc = ensure_xs(h, 128);
+    if (rc) return rc;
+    memset(h->hio, 0, (size_t)64 * D * sizeof(double));      // (pinned staging: one asynchronous copy, see mfgp_predict)
     memcpy(h->hio, x_new, (size_t)D * sizeof(double));
-    HIPCHK(h, hipMemcpyAsync(h->dXs, h->hio, (size_t)128 * D * sizeof(double), hipMemcpyHostToDevice, s));
-    // k = K(x_new, X[0:n]) -> row 0 of W ; l = X k ; w = X^T l
-    launch_kbuild_panel(s, h->spec, h->dXs, 128, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np);
-    HIPCHK(h, hipMemsetAsync(h->dvec, 0, (size_t)Np * sizeof(double), s));
-    launch_rowdot(s, h->buf[BUF_S], (int)Np, h->buf[BUF_W], h->dvec, n, (int)Np, 0);
+    HIPCHK(h, hipMemcpyAsync(h->dXs, h->hio, (size_t)64 * D * sizeof(double), hipMemcpyHostToDevice, s));
+    // k = K(x_new, X[0:n]) -> row 0 of W (0 in the padded columns) ; l = X k ; w = X^T l.  The first pass runs to the end of
+    // row n's 128-block: rows n .. of S are still identity rows, so l[n ..] = k[n ..] = 0 -- the second pass reads l in whole
+    // 128-column chunks (masked by its column range, but the operand has to be finite)
+    launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np);
+    launch_rowdot(s, h->buf[BUF_S], (int)Np, h->buf[BUF_W], h->dvec, ((n >> 7) + 1) << 7, (int)Np, 0);
     launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dvec, h->dvec2, n, n, 1);
-    double kdiag = 0.0, prod = 1.0;
-    int cur = h->spec.term[0];
-    for (int f = 0; f < h->spec.nf; ++f) {
-        if (h->spec.term[f] != cur) { kdiag += prod; prod = 1.0; cur = h->spec.term[f]; }
-        prod *= h->theta[h->spec.toff[f]];
-    }
-    kdiag += prod + h->noise + h->jitter;
-    launch_append_finish(s, h->buf[BUF_L], h->buf[BUF_S], (int)Np, n, h->dvec, h->dvec2, h->dz, kdiag, y_new, h->dres + 48,
-                         h->dX, h->dXs, D, h->dY);
-    launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dz, h->dalpha, n + 1, n + 1, 1);
+    const double kdiag = prior_variance(h) + h->noise + h->jitter;
+    launch_append_finish(s, h->buf[BUF_L], h->buf[BUF_S], (int)Np, n, h->dvec, h->dvec2, h->dz, h->dalpha, kdiag, y_new,
+                         h->dres + 48, h->dX, h->dXs, D, h->dY);
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     if (h->hres[51] != 0.0) {
@@ -1110,6 +1103,18 @@ int32_t mfgp_nlml_grad(mfgp_handle* h, double* grad) {
     return 0;
 }
 
+// k(x, x) of the handle's stationary covariance at its current parameters: sum over the terms of the product of their variances
+// (GPy Kdiag)
+static double prior_variance(const mfgp_handle* h) {
+    double kss = 0.0, prod = 1.0;
+    int cur = h->spec.term[0];
+    for (int f = 0; f < h->spec.nf; ++f) {
+        if (h->spec.term[f] != cur) { kss += prod; prod = 1.0; cur = h->spec.term[f]; }
+        prod *= h->theta[h->spec.toff[f]];
+    }
+    return kss + prod;
+}
+
 // make room for a predictive panel of rows_p rows in h->dXs
 static int ensure_xs(mfgp_handle* h, int rows_p) {
     const int D = h->D;
@@ -1134,32 +1139,57 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     double* const var_dev = pinned ? h->dio + mfgp_handle::IO_IN + mfgp_handle::IO_OUT : h->dvec2;
     const int64_t Np = h->Np;
     int rc;
-    // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound skinny product instead of a padded tile GEMM
+    // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound products instead of a padded tile GEMM --
+    // up to 16 rows on the VALU behind one coalesced read of the triangle (trimv_f64.hip: panel, product, ONE finishing launch for
+    // mean and variance), 17 .. 64 rows the MFMA multi-vector form
     static const bool skinny_on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
-    const bool skinny = want_var && skinny_on && rows <= 64;
+    const bool few = skinny_on && rows <= 16;
+    const bool skinny = want_var && skinny_on && rows <= 64 && !few;
     const int rows16 = rows <= 16 ? 1 : (rows <= 32 ? 2 : 4);
-    if (want_var && !skinny && h->pl.predv_rows != rows_p) {
+    if (want_var && !skinny && !few && h->pl.predv_rows != rows_p) {
         // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
         plan_predv(h->pl, rows_p);
         rc = upload_tasks(h);
         if (rc) return rc;
     }
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[6], s));
-    launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
-    launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, mean_dev, rows_p, (int)Np, 2);
-    h->launches += 2;
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
-    if (!pinned) HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (want_var) {
-        h->kinv_valid = false;  // V overwrites the K^-1 storage
-        const int vrows = skinny ? 16 * rows16 : rows_p;
-        if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
-        else if (run_step(h, h->pl.predv_step) != 0) return -1;
-        launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
-        launch_finish_var(s, h->spec, h->dvec2, var_dev, vrows, include_noise ? h->noise : 0.0);
-        h->launches += 2;
+    if (few) {
+        const int R = rows <= 1 ? 1 : (rows <= 2 ? 2 : (rows <= 4 ? 4 : (rows <= 8 ? 8 : 16)));
+        launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
+        h->launches += 1;
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
+        if (want_var) {
+            h->kinv_valid = false;  // V overwrites the K^-1 storage
+            launch_predv_rows(s, R, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np, h->dalpha, mean_dev, (int)rows);
+            launch_predv_finish(s, (int)rows, h->buf[BUF_A], (int)Np, (int)Np, prior_variance(h), include_noise ? h->noise : 0.0,
+                                var_dev);
+            h->launches += 2;
+        } else {
+            launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, mean_dev, (int)rows, (int)Np, 2);
+            h->launches += 1;
+        }
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[8], s));
-        if (!pinned) HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (!pinned) {
+            HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+            if (want_var) HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+    } else {
+        launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
+        launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, mean_dev, rows_p, (int)Np, 2);
+        h->launches += 2;
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
+        if (!pinned) HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (want_var) {
+            h->kinv_valid = false;  // V overwrites the K^-1 storage
+            const int vrows = skinny ? 16 * rows16 : rows_p;
+            if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
+            else if (run_step(h, h->pl.predv_step) != 0) return -1;
+            launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
+            launch_finish_var(s, h->spec, h->dvec2, var_dev, vrows, include_noise ? h->noise : 0.0);
+            h->launches += 2;
+            if (h->timing) HIPCHK(h, hipEventRecord(h->ev[8], s));
+            if (!pinned) HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
     }
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());

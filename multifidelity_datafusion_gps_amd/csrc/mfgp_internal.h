@@ -46,6 +46,14 @@ size_t gemm_lds_bytes(int tile);
 // skinny variance product for <= 64 test rows: V[0 .. 16*rows16) = W X^T (X = L^-1 from the mirrored S); rows16 in {1, 2, 4}
 void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const double* S, double* V, int ld, int Np);
 
+// <= 16 test rows (trimv_f64.hip): V[i][j] = sum_{k <= j} W[i][k] X[j][k] on the VALU behind ONE coalesced read of the triangle;
+// R = the row count rounded up to 1, 2, 4, 8 or 16 (the panel W holds at least that many rows); the same launch forms the means
+// W[i] . alpha of the `rows` real test rows
+void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, double* V, int ld, int Np, const double* alpha,
+                       double* mean, int rows);
+//   and its finish, one workgroup per test row: var[i] = max(kss - |V[i]|^2, 1e-15) + add
+void launch_predv_finish(hipStream_t s, int rows, const double* V, int ld, int Np, double kss, double add, double* var);
+
 // leaf: Cholesky + inverse of the 128x128 diagonal block `blk` of A (ld), in LDS.
 //   L block (zeros above diag) -> Lout[blk,blk];  X = L^-1 -> S[blk,blk] stored mirrored (X + X^T - diag)
 //   half log-det partial -> logdet_part[blk];  first failing pivot (1-based global index) -> info (atomicMin style)
@@ -78,7 +86,7 @@ void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
                    int ncols, int mode, int nbatch = 1, long long mstride = 0, long long xstride = 0, long long ystride = 0);
 void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
-                          double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y);
+                          double* alpha, double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y);
 //   rowsumsq[i] = sum_{k < ncols} M[i][k]^2
 void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols);
 //   scalars[0] = sum z^2 ; scalars[1] = 2*sum logdet_part ; (single small block)

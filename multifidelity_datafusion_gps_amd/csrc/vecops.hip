@@ -8,33 +8,6 @@
 
 namespace mfgp {
 
-// one wave per row, 16 B per lane, rows fully coalesced; mode 0: k<=i, 1: k>=i, 2: all
-// blockIdx.y = set b of a batched evaluation: M, x, y move by b * (mstride, xstride, ystride) elements (0 for a single one)
-__global__ __launch_bounds__(256) void mfgp_rowdot_f64(const double* __restrict__ M, int ld,
-                                                       const double* __restrict__ x, double* __restrict__ y,
-                                                       int nrows, int ncols, int mode, long long mstride, long long xstride,
-                                                       long long ystride) {
-    M += blockIdx.y * mstride; x += blockIdx.y * xstride; y += blockIdx.y * ystride;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
-    int k0 = 0, k1 = ncols;  // [k0, k1)
-    if (mode == 0) k1 = row + 1;
-    if (mode == 1) k0 = row;
-    const double* mp = M + (int64_t)row * ld;
-    double s = 0.0;
-    const int ka = k0 & ~1;  // aligned start (pairs)
-    for (int k = ka + 2 * lane; k < k1; k += 128) {
-        const d2_t m = *reinterpret_cast<const d2_t*>(mp + k);
-        const d2_t v = *reinterpret_cast<const d2_t*>(x + k);
-        if (k >= k0) s += m.x * v.x;
-        if (k + 1 >= k0 && k + 1 < k1) s += m.y * v.y;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) y[row] = s;
-}
-
 __global__ __launch_bounds__(256) void mfgp_rowsumsq_f64(const double* __restrict__ M, int ld,
                                                          double* __restrict__ out, int nrows, int ncols) {
     const int lane = threadIdx.x & 63;
@@ -72,65 +45,23 @@ __global__ __launch_bounds__(256) void mfgp_finish_solve_f64(const double* __res
     }
 }
 
-// alpha = X^T z (rowdot mode 1) AND, in the launch's last workgroup, the scalars of mfgp_finish_solve_f64 (z^T z, log-det):
-// they need z only, which the previous launch completed -- one launch floor (~4.6 us) less per evaluation.
-__global__ __launch_bounds__(256) void mfgp_alpha_finish_f64(const double* __restrict__ S, int ld,
-                                                             const double* __restrict__ z, double* __restrict__ alpha,
-                                                             int Np, const double* __restrict__ logdet_part, int nblk,
-                                                             double* __restrict__ scalars, long long sstride, long long vstride,
-                                                             int ldstride, int scstride) {
-    // blockIdx.y = set b of a batched evaluation: S moves by b * sstride, z and alpha by b * vstride, the log-det partials by
-    // b * ldstride, the scalars by b * scstride elements (all 0 for a single one)
-    S += blockIdx.y * sstride; z += blockIdx.y * vstride; alpha += blockIdx.y * vstride;
-    logdet_part += blockIdx.y * ldstride; scalars += blockIdx.y * scstride;
-    if (blockIdx.x == gridDim.x - 1) {   // the extra workgroup: scalars
-        __shared__ double red[256];
-        const int tid = threadIdx.x;
-        double s = 0.0;
-        for (int i = tid; i < Np; i += 256) s += z[i] * z[i];
-        red[tid] = s;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) red[tid] += red[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            scalars[0] = red[0];
-            double ldet = 0.0;
-            for (int b = 0; b < nblk; ++b) ldet += logdet_part[b];
-            scalars[1] = 2.0 * ldet;
-        }
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Np) return;
-    const double* mp = S + (int64_t)row * ld;
-    double s = 0.0;
-    const int ka = row & ~1;  // aligned start (pairs); columns >= row: the mirrored upper part holds X^T
-    for (int k = ka + 2 * lane; k < Np; k += 128) {
-        const d2_t m = *reinterpret_cast<const d2_t*>(mp + k);
-        const d2_t v = *reinterpret_cast<const d2_t*>(z + k);
-        if (k >= row) s += m.x * v.x;
-        s += m.y * v.y;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) alpha[row] = s;
-}
-
 // rank-1 append: given l = X k (first n entries) and w = X^T l, finish the new row r = n of L and of
-// the mirrored inverse S, the new z entry and the scalars.  One workgroup.
+// the mirrored inverse S, the new z entry, alpha and the scalars.
 //   d = sqrt(kdiag - l.l) ; L[r][0:n] = l, L[r][r] = d ; X[r][0:n] = -w/d, X[r][r] = 1/d (both triangles of S)
 //   z[r] = (y_new - l.z) / d ; out = {d, z_r, l.l, status(0 ok / 1 not PD)}
-// The new training row itself (X[r] <- xs_new, Y[r] <- y_new) is committed HERE and only on success: a rejected
-// append leaves the handle's data exactly as it was (padding row r of X and Y stays zero).
+//   alpha = X^T z with the new row [-w^T/d, 1/d] of X:  alpha[0:n] += X[r][0:n] z_r ; alpha[r] = z_r / d   (O(n): no third pass
+//   over the triangle)
+// Every workgroup forms the two dot products itself (n <= Np doubles out of L2, the same fixed order everywhere, so every
+// workgroup holds the same d and z_r) and then writes its own slice of the new row / column -- the column S[i][r] is n scattered
+// 8-byte stores, which one workgroup alone would issue for ~15 us.  The new training row itself (X[r] <- xs_new, Y[r] <- y_new)
+// is committed HERE, by workgroup 0, and only on success: a rejected append leaves the handle's data exactly as it was (padding
+// row r of X and Y stays zero).
 __global__ __launch_bounds__(256) void mfgp_append_finish_f64(double* __restrict__ L, double* __restrict__ S, int ld,
                                                               int n, const double* __restrict__ l,
                                                               const double* __restrict__ w, double* __restrict__ z,
-                                                              double kdiag, double y_new, double* __restrict__ out,
-                                                              double* __restrict__ X, const double* __restrict__ xs_new,
-                                                              int D, double* __restrict__ Y) {
+                                                              double* __restrict__ alpha, double kdiag, double y_new,
+                                                              double* __restrict__ out, double* __restrict__ X,
+                                                              const double* __restrict__ xs_new, int D, double* __restrict__ Y) {
     __shared__ double red[512];
     const int tid = threadIdx.x;
     double ss = 0.0, lz = 0.0;
@@ -150,46 +81,40 @@ __global__ __launch_bounds__(256) void mfgp_append_finish_f64(double* __restrict
     }
     const double d2 = kdiag - red[0];
     if (!(d2 > 0.0)) {
-        if (tid == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = red[0]; out[3] = 1.0; }
+        if (blockIdx.x == 0 && tid == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = red[0]; out[3] = 1.0; }
         return;
     }
     const double d = sqrt(d2), rd = 1.0 / d;
-    for (int i = tid; i < n; i += 256) {
+    const double zr = (y_new - red[256]) * rd;
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
         const double xv = -w[i] * rd;
         L[(int64_t)n * ld + i] = l[i];
         S[(int64_t)n * ld + i] = xv;
         S[(int64_t)i * ld + n] = xv;
+        alpha[i] = __builtin_fma(xv, zr, alpha[i]);
     }
-    if (tid < D) X[(int64_t)n * D + tid] = xs_new[tid];
-    if (tid == 0) {
-        Y[n] = y_new;
-        L[(int64_t)n * ld + n] = d;
-        S[(int64_t)n * ld + n] = rd;
-        const double zr = (y_new - red[256]) * rd;
-        z[n] = zr;
-        out[0] = d; out[1] = zr; out[2] = red[0]; out[3] = 0.0;
+    if (blockIdx.x == 0) {
+        if (tid < D) X[(int64_t)n * D + tid] = xs_new[tid];
+        if (tid == 0) {
+            Y[n] = y_new;
+            L[(int64_t)n * ld + n] = d;
+            S[(int64_t)n * ld + n] = rd;
+            z[n] = zr;
+            alpha[n] = zr * rd;
+            out[0] = d; out[1] = zr; out[2] = red[0]; out[3] = 0.0;
+        }
     }
 }
 
 void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
-                          double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y) {
-    hipLaunchKernelGGL(mfgp_append_finish_f64, dim3(1), dim3(256), 0, s, L, S, ld, n, l, w, z, kdiag, y_new, out, X,
+                          double* alpha, double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y) {
+    const int nwg = n >= 2048 ? 32 : (n >= 512 ? 8 : 1);
+    hipLaunchKernelGGL(mfgp_append_finish_f64, dim3(nwg), dim3(256), 0, s, L, S, ld, n, l, w, z, alpha, kdiag, y_new, out, X,
                        xs_new, D, Y);
 }
 
-void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows,
-                   int ncols, int mode, int nbatch, long long mstride, long long xstride, long long ystride) {
-    hipLaunchKernelGGL(mfgp_rowdot_f64, dim3((nrows + 3) / 4, nbatch > 0 ? nbatch : 1), dim3(256), 0, s, M, ld, x, y, nrows, ncols,
-                       mode, mstride, xstride, ystride);
-}
 void launch_rowsumsq(hipStream_t s, const double* M, int ld, double* out, int nrows, int ncols) {
     hipLaunchKernelGGL(mfgp_rowsumsq_f64, dim3((nrows + 3) / 4), dim3(256), 0, s, M, ld, out, nrows, ncols);
-}
-void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z, double* alpha, int Np,
-                         const double* logdet_part, int nblk, double* scalars, int nbatch, long long sstride, long long vstride,
-                         int ldstride, int scstride) {
-    hipLaunchKernelGGL(mfgp_alpha_finish_f64, dim3((Np + 3) / 4 + 1, nbatch > 0 ? nbatch : 1), dim3(256), 0, s, S, ld, z, alpha, Np,
-                       logdet_part, nblk, scalars, sstride, vstride, ldstride, scstride);
 }
 void launch_finish_solve(hipStream_t s, const double* z, int Np, const double* logdet_part, int nblk,
                          double* scalars) {
