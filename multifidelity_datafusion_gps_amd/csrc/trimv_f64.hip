@@ -211,11 +211,13 @@ static inline int trimv_blocks(int nrows, int JR) {
     return ((G + 1) / 2 + 3) / 4;
 }
 
-// rows per wave / chunks per batch of the single-vector form (MFGP_TRIMV="JR U": lab override, read once)
+// rows per wave / chunks per batch of the single-vector form: 4 rows x 2 chunks (measured at N = 8192, variance stage incl. its
+// finishing launch / append: "4 2" 0.0498 / 0.132 ms, "1 8" 0.0508 / 0.139, "2 4" 0.0555 / 0.143: profiles/r06_trimv_shapes.txt).
+// MFGP_TRIMV="JR U" selects "2 4" or "1 8" instead (lab switch, read once)
 static void trimv1_shape(int& JR, int& U) {
     static int jr = 0, u = 0;
     if (!jr) {
-        jr = 2; u = 4;
+        jr = 4; u = 2;
         if (const char* e = getenv("MFGP_TRIMV")) {
             int a = 0, b = 0;
             if (sscanf(e, "%d %d", &a, &b) == 2) { jr = a; u = b; }
@@ -235,18 +237,14 @@ void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, doub
     hipLaunchKernelGGL((mfgp_trimv_f64<1, jr, u>), dim3(trimv_blocks(nrows, jr), nb), blk, 0, s, M, ld, x, 0, y, 0, nrows, ncols, \
                        mode, mstride, xstride, ystride)
     if (JR == 1 && U == 8) TRIMV1(1, 8);
-    else if (JR == 1 && U == 4) TRIMV1(1, 4);
-    else if (JR == 2 && U == 2) TRIMV1(2, 2);
-    else if (JR == 2 && U == 8) TRIMV1(2, 8);
-    else if (JR == 4 && U == 2) TRIMV1(4, 2);
-    else if (JR == 4 && U == 4) TRIMV1(4, 4);
-    else TRIMV1(2, 4);
+    else if (JR == 2 && U == 4) TRIMV1(2, 4);
+    else TRIMV1(4, 2);
 #undef TRIMV1
 }
 
 void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z, double* alpha, int Np, const double* logdet_part,
                          int nblk, double* scalars, int nbatch, long long sstride, long long vstride, int ldstride, int scstride) {
-    hipLaunchKernelGGL((mfgp_alpha_finish_f64<2, 4>), dim3(trimv_blocks(Np, 2) + 1, nbatch > 0 ? nbatch : 1), dim3(256), 0, s, S, ld,
+    hipLaunchKernelGGL((mfgp_alpha_finish_f64<4, 2>), dim3(trimv_blocks(Np, 4) + 1, nbatch > 0 ? nbatch : 1), dim3(256), 0, s, S, ld,
                        z, alpha, Np, logdet_part, nblk, scalars, sstride, vstride, ldstride, scstride);
 }
 
@@ -269,6 +267,117 @@ __global__ __launch_bounds__(256) void mfgp_predv_rows_f64(const double* __restr
     trimv_wave<R, JR, U>(S, ld, W, ld, V, ld, Np, Np, 0, wv, lane);
 }
 
+// The same product for 8 and 16 test rows: the R right-hand sides would cost R / JR times the bytes of S in L2 -> L1 reads and
+// fill the wave's memory queue (measured: 3.8 / 2.9 TB/s at R = 8 / 16 in the form above), so the NW waves of a workgroup walk
+// the SAME chunks of NW JR consecutive rows in lock step and share the R x 128 tile of W through LDS: W crosses L1 once per
+// NW JR rows of S, the fragments come out of LDS (ds_read_b128, conflict-free).  The tile is staged by LDS-DMA
+// (global_load_lds_dwordx4: one wave-instruction lands 1 KiB = one row's chunk lane-linearly, no staging registers) D steps
+// ahead into D + 1 buffers, and S is fetched D chunks ahead in registers (D + 1 register sets taking turns): vmcnt counts in
+// order, so the wait for a tile retires everything issued before it -- the distance of the TILE is what bounds the bytes of S a
+// wave keeps in flight (measured at R = 16: 3.3 TB/s with the tile fetched inside the step or two steps ahead, whatever the
+// distance of S).  One barrier per chunk.  Row block b is paired with block NB-1-b as above; sums and their order per (i, j)
+// are exactly those of trimv_wave -- a row's result does not depend on which of the two forms produced it.
+// The waits on the DMA are counted by hand against the ISSUE order, which the sched_barriers pin (tile, then S, then the
+// step's arithmetic); `hipcc -S` of this file shows, per step: WQ global_load_lds, JR global_load_dwordx4, ..., s_waitcnt
+// vmcnt(JR + (D - 1)(WQ + JR)), s_barrier.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int R, int JR, int NW, int D>
+__global__ __launch_bounds__(64 * NW) void mfgp_predv_rows_lds_f64(const double* __restrict__ S, int ld, const double* __restrict__ W,
+                                                                  double* __restrict__ V, int Np, const double* __restrict__ alpha,
+                                                                  double* __restrict__ mean, int rows) {
+    static_assert(R % NW == 0, "the waves stage R / NW rows of the W tile each");
+    constexpr int BR = NW * JR;                // rows of S per workgroup and block
+    constexpr int NS = D + 1;
+    constexpr int WQ = R / NW;
+    __shared__ __attribute__((aligned(1024))) d2_t wl[NS][R][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x == gridDim.x - 1) {
+        if (wave < 4) trimv_wave<1, 2, 4>(W, ld, alpha, 0, mean, 0, rows, Np, 2, wave, lane);
+        return;
+    }
+    const int NB = Np / BR;
+    const int bA = blockIdx.x, bB = NB - 1 - bA;                       // (NB is even: Np is a multiple of 128, 2 BR divides 128)
+    const int nA = ((bA * BR + BR - 1) >> 7) + 1, nB = ((bB * BR + BR - 1) >> 7) + 1;
+    const int T = nA + nB;
+    auto row0 = [&](int t) { return (t < nA ? bA : bB) * BR + wave * JR; };
+    auto chunk = [&](int t) { return t < nA ? t : t - nA; };
+    d2_t ss[NS][JR];
+    double acc[JR][R];
+#pragma unroll
+    for (int r = 0; r < JR; ++r)
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[r][i] = 0.0;
+    auto load_s = [&](int t, d2_t (&s)[JR]) {
+        t = min(t, T - 1);
+        const double* p = S + (int64_t)row0(t) * ld + (chunk(t) << 7) + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < JR; ++r) s[r] = *reinterpret_cast<const d2_t*>(p + (int64_t)r * ld);
+    };
+    const double* const w_lane = W + (int64_t)(wave * WQ) * ld + 2 * lane;
+    auto dma_w = [&](int t, int buf) {          // this wave's WQ rows of tile t -> wl[buf]
+        t = min(t, T - 1);
+        const int c = chunk(t) << 7;
+#pragma unroll
+        for (int i = 0; i < WQ; ++i)
+            __builtin_amdgcn_global_load_lds(w_lane + ((int64_t)i * ld + c), (lds_ptr_t)&wl[buf][wave * WQ + i][0], 16, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u) dma_w(u, u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tiles 0 .. D-1 have landed (this wave's part); once per workgroup
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        __builtin_amdgcn_sched_barrier(0);      // (program order = issue order: the waits below are counted against it)
+        load_s(u, ss[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // one step: consume chunk t out of register set / tile buffer t mod NS, fetch chunk and tile t + D into the set and the
+    // buffer step t - 1 consumed (a rotation by copies would have to wait for the loads it copies)
+    auto step = [&](int t, int buf, const d2_t (&cur)[JR], d2_t (&nxt)[JR]) {
+        dma_w(t + D, buf == 0 ? NS - 1 : buf - 1);   // the tile first, and kept first
+        __builtin_amdgcn_sched_barrier(0);
+        load_s(t + D, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int j0 = row0(t), k = (chunk(t) << 7) + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < JR; ++r) {
+            const double m0 = (k <= j0 + r) ? cur[r].x : 0.0;
+            const double m1 = (k + 1 <= j0 + r) ? cur[r].y : 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const d2_t w = wl[buf][i][lane];
+                acc[r][i] = __builtin_fma(m0, w.x, acc[r][i]);
+                acc[r][i] = __builtin_fma(m1, w.y, acc[r][i]);
+            }
+        }
+        if (t == nA - 1 || t == T - 1) {
+#pragma unroll
+            for (int r = 0; r < JR; ++r)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const double v = wave_sum_f64(acc[r][i]);
+                    if (lane == 0) V[(int64_t)i * ld + j0 + r] = v;
+                    acc[r][i] = 0.0;
+                }
+        }
+        // tile t + 1 (issued at the top of step t + 1 - D) has landed: younger than it are that step's S loads and the D - 1
+        // steps since
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JR + (D - 1) * (WQ + JR)) : "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    int buf = 0;
+    for (int t = 0; t < T; t += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (t + u >= T) break;
+            step(t + u, buf, ss[u], ss[(u + D) % NS]);
+            buf = buf == NS - 1 ? 0 : buf + 1;
+        }
+    }
+}
+
 void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, double* V, int ld, int Np, const double* alpha,
                        double* mean, int rows) {
     const dim3 blk(256);
@@ -278,16 +387,20 @@ void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, d
     hipLaunchKernelGGL((mfgp_predv_rows_f64<r, jr, u>), dim3(trimv_blocks(Np, jr) + 1), blk, 0, s, S, ld, W, V, Np, alpha, mean, rows)
     if (R <= 1) {
         if (JR1 == 1 && U1 == 8) TRIMVR(1, 1, 8);
-        else if (JR1 == 1 && U1 == 4) TRIMVR(1, 1, 4);
-        else if (JR1 == 2 && U1 == 2) TRIMVR(1, 2, 2);
-        else if (JR1 == 2 && U1 == 8) TRIMVR(1, 2, 8);
-        else if (JR1 == 4 && U1 == 2) TRIMVR(1, 4, 2);
-        else if (JR1 == 4 && U1 == 4) TRIMVR(1, 4, 4);
-        else TRIMVR(1, 2, 4);
-    } else if (R <= 2) TRIMVR(2, 2, 4);
+        else if (JR1 == 2 && U1 == 4) TRIMVR(1, 2, 4);
+        else TRIMVR(1, 4, 2);
+    } else if (R <= 2) TRIMVR(2, 4, 2);
     else if (R <= 4) TRIMVR(4, 4, 2);
-    else if (R <= 8) TRIMVR(8, 4, 2);
-    else TRIMVR(16, 4, 1);
+    else {
+        static const int lds = getenv("MFGP_TRIMV_LDS") ? atoi(getenv("MFGP_TRIMV_LDS")) : 1;
+#define PREDV_LDS(r, jr, nw, d)                                                                                           \
+    hipLaunchKernelGGL((mfgp_predv_rows_lds_f64<r, jr, nw, d>), dim3(Np / (nw * jr) / 2 + 1), dim3(64 * nw), 0, s, S, ld, W, V, Np, alpha, \
+                       mean, rows)
+        if (lds == 0) { if (R <= 8) TRIMVR(8, 4, 2); else TRIMVR(16, 4, 1); }
+        else if (R <= 8) PREDV_LDS(8, 4, 4, 2);
+        else PREDV_LDS(16, 2, 4, 3);
+#undef PREDV_LDS
+    }
 #undef TRIMVR
 }
 
