@@ -471,12 +471,16 @@ constexpr int BULK_THREADS = 256;                 // bulk tile kernels: 4 waves 
 //   mfgp_kinv_syrk_f64           : the ONE launch per evaluation that forms K^-1 = L^-T L^-1 (N^3/3 flops)
 //   mfgp_predvar_f64             : the predictive-variance product V = K(X*,X) L^-T
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_gemm_nt_f64_t128(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld, long long bstride) {
+        const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<128, 128, 2, 2, 16, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_gemm_nt_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld, long long bstride) {
+        const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<64, 64, 2, 2, 32, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
@@ -485,7 +489,9 @@ __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_gemm_nt_f64_t64(const Ge
 // other stream (160 KB per CU, allocated in 1280-byte granules: 32 KB would miss by 768 bytes) instead of waiting
 // ~60 us for one to retire; raised wave priority so its MFMAs issue first.
 __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_chain(const GemmTask* __restrict__ tasks, const double* A,
-                                                                 const double* B, double* C, double* C2, int ld, long long bstride) {
+                                                                 const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     __builtin_amdgcn_s_setprio(3);
     gemm_nt_tile<64, 64, GW_M, GW_N, 1, 16>(tasks[blockIdx.x], A, B, C, C2, ld);
@@ -496,28 +502,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void mfgp_gemm_nt_f64_chain(const 
 // K-steps: panel launch 12 -> 9.5 us, in-macro update 13-20 -> 10-17 us (N = 4096), one evaluation at N = 2048 1.20 -> 1.03 ms.
 // (Measured beside it: K-steps of 16, single- and double-buffered: 1.07 / 1.08 ms.)
 __global__ __launch_bounds__(256, 5) void mfgp_gemm_nt_f64_chain32(const GemmTask* __restrict__ tasks, const double* A,
-                                                          const double* B, double* C, double* C2, int ld, long long bstride) {
+                                                          const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     __builtin_amdgcn_s_setprio(3);
     gemm_nt_tile<32, 32, 2, 2, 1, 32>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_kinv_syrk_f64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld, long long bstride) {
+        const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<128, 128, 2, 2, 16, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_kinv_syrk_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld, long long bstride) {
+        const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<64, 64, 2, 2, 32, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_predvar_f64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld, long long bstride) {
+        const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<128, 128, 2, 2, 16, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
 __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_predvar_f64_t64(const GemmTask* __restrict__ tasks, const double* A,
-        const double* B, double* C, double* C2, int ld, long long bstride) {
+        const double* B, double* C, double* C2, int ld, long long bstride,
+        const int* __restrict__ flag, int epoch) {
+    if (flag && flag[blockIdx.y] == epoch) return;   // this evaluation has already failed (leaf_f64.hip): nothing downstream is used
     A += blockIdx.y * bstride; B += blockIdx.y * bstride; C += blockIdx.y * bstride; C2 += blockIdx.y * bstride;
     gemm_nt_dma<64, 64, 2, 2, 32, 2>(tasks[blockIdx.x], A, B, C, C2, ld);
 }
@@ -525,12 +541,12 @@ __global__ __launch_bounds__(BULK_THREADS, 2) void mfgp_predvar_f64_t64(const Ge
 // bulk kernels: two stages of (tile + tile) rows x 16 columns (128-tiles) or x 32 columns (64-tiles): 64 KB / 32 KB
 size_t gemm_lds_bytes(int tile) { return (size_t)2 * (tile + tile) * (tile == 128 ? 16 : 32) * sizeof(double); }
 
-typedef void (*gemm_kernel_t)(const GemmTask*, const double*, const double*, double*, double*, int, long long);
+typedef void (*gemm_kernel_t)(const GemmTask*, const double*, const double*, double*, double*, int, long long, const int*, int);
 
 // -> 0, or -1 when the planner asked for a (tile, role) pair no kernel exists for (a planner bug: reported through the
 // C-ABI's status like every other error, never by terminating the host process)
 int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
-                const double* B, double* C, double* C2, int ld, int role, int nbatch, long long bstride) {
+                const double* B, double* C, double* C2, int ld, int role, int nbatch, long long bstride, const int* flag, int epoch) {
     if (ntasks <= 0) return 0;
     static const gemm_kernel_t table[3][2] = {{mfgp_gemm_nt_f64_t128, mfgp_gemm_nt_f64_t64},
                                               {mfgp_kinv_syrk_f64, mfgp_kinv_syrk_f64_t64},
@@ -550,12 +566,12 @@ int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, cons
     const dim3 grid(ntasks, nbatch > 0 ? nbatch : 1);
     if (tile == 32) {                // chain step at chain-bound sizes: 32x32 tiles, 4 waves, 16 KB
         hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain32, grid, dim3(256), (size_t)(32 + 32) * 32 * sizeof(double), s, tasks, A, B,
-                           C, C2, ld, bstride);
+                           C, C2, ld, bstride, flag, epoch);
         return 0;
     }
     if (role == 3 && tile == 64) {   // serial-chain step: slim workgroups that co-reside with the bulk update
         hipLaunchKernelGGL(mfgp_gemm_nt_f64_chain, grid, dim3(GEMM_THREADS), (size_t)(64 + 64) * 16 * sizeof(double), s, tasks, A, B,
-                           C, C2, ld, bstride);
+                           C, C2, ld, bstride, flag, epoch);
         return 0;
     }
     // roles: 0 bulk, 1 K^-1, 2 predictive variance (distinct symbols over one body); 3 = a chain step -- only its 64-tile
@@ -563,7 +579,7 @@ int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, cons
     // by tile == 32 above)
     if ((tile != 128 && tile != 64) || role < 0 || (role > 3 && role != 5)) return -1;
     const gemm_kernel_t k = table[role >= 3 ? 0 : role][tile == 128 ? 0 : 1];
-    hipLaunchKernelGGL(k, grid, dim3(BULK_THREADS), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld, bstride);
+    hipLaunchKernelGGL(k, grid, dim3(BULK_THREADS), gemm_lds_bytes(tile), s, tasks, A, B, C, C2, ld, bstride, flag, epoch);
     return 0;
 }
 

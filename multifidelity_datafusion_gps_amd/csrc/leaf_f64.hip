@@ -58,7 +58,8 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 // finished row j of Y enters row k's sum.  Both lane groups execute the SAME instructions (v[j] *= y_j, v[k] -= v[j] * l_kj):
 // the inverse costs nothing per pivot and no extra communication.
 template <int YP = LP>
-__device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lane, int* info, int pivot0, double* col_buf) {
+__device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lane, int* info, int pivot0, double* col_buf,
+                                             int* flag, int epoch) {
     const int i = lane & 15;
     const bool inv_lane = (lane & 16) != 0;
     double v[16];
@@ -141,7 +142,10 @@ __device__ __forceinline__ void micro_chol16(double* blk, double* y_out, int lan
     // first failed pivot, if any: the first diagonal entry that is not a positive number (read back: same wave, LDS is in order)
     const double dg = blk[i * LP + i];
     const unsigned long long bad = __ballot(lane < 16 && !(dg > 0.0));
-    if (bad != 0 && lane == 0 && *info == 0) *info = pivot0 + __ffsll((long long)bad);
+    if (bad != 0 && lane == 0) {
+        if (*info == 0) *info = pivot0 + __ffsll((long long)bad);
+        if (flag) *flag = epoch;    // device-resident mark of a failed evaluation: the sweep's later launches return at once
+    }
 }
 
 // 16x16x16 block products: four v_mfma_f64_16x16x4 on one accumulator.  (The v_mfma_f64_4x4x4_4b form the tile GEMM moved to in
@@ -225,7 +229,7 @@ __device__ __forceinline__ void bfirst_block(double* sL, const double* Y, int jb
 
 
 __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restrict__ A, double* Lout, double* S, int ld, int blk,
-                                             double* logdet_part, int* info) {
+                                             double* logdet_part, int* info, int* flag, int epoch) {
     double* sL = smem;                       // 128 x LP: lower = A -> L, strictly upper 16-blocks = B -> X^T
     double* sY = smem + 128 * LP;            // 2 x (16 x YP16): Y_jj = L_jj^-1, slot jb & 1
     double* sc = sY + SY_SIZE;               // scratch
@@ -251,7 +255,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
             const int e = lane + 64 * u;
             *reinterpret_cast<d2_t*>(sL + (e >> 3) * LP + 2 * (e & 7)) = v[u];
         }
-        micro_chol16<YP16>(sL, sY, lane, info, blk * NB, sc + 16);    // (same wave wrote the tile: LDS program order suffices)
+        micro_chol16<YP16>(sL, sY, lane, info, blk * NB, sc + 16, flag, epoch);    // (same wave wrote the tile: LDS program order suffices)
     } else {
         // the 35 other tiles of the lower block triangle (tile tl = I(I+1)/2 + J, J <= I), 128 pairs of doubles each
         constexpr int NLD = 10;   // ceil(35 * 128 / 448 lanes)
@@ -338,7 +342,7 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
         if (wave == 0) {
             // the next diagonal block is factorised (and inverted) while waves 1-7 do the rest of panel jb
             micro_chol16<YP16>(sL + (jb * 16 + 16) * LP + jb * 16 + 16, sY + ((jb + 1) & 1) * 16 * YP16, lane, info,
-                               blk * NB + jb * 16 + 16, sc + 16);
+                               blk * NB + jb * 16 + 16, sc + 16, flag, epoch);
         } else {
             const int nP = 6 - jb;                   // block column jb+1 of A below its diagonal block: the next panel's solves read it
             const int m = 6 - jb;                    // A: block columns jb+2 .. 7, lower blocks
@@ -384,16 +388,22 @@ __device__ __forceinline__ void leaf_body_v3(double* smem, const double* __restr
 __global__ __launch_bounds__(LEAF_THREADS, 1) void mfgp_leaf_cholinv_f64(const double* __restrict__ A,
                                                                          double* Lout, double* S, int ld, int blk,
                                                                          double* logdet_part, int* info, long long bstride,
-                                                                         int ldstride, int istride) {
+                                                                         int ldstride, int istride, int* flag, int epoch) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // flag[set] == epoch: an earlier diagonal block of THIS evaluation was not positive definite -- nothing downstream is used
+    // (the host reports the pivot), so the rest of the sweep returns at once instead of costing a whole factorisation
+    if (flag) {
+        flag += blockIdx.x;
+        if (*flag == epoch) return;
+    }
     const long long off = (long long)blockIdx.x * bstride;
     leaf_body_v3(smem, A + off, Lout + off, S + off, ld, blk, logdet_part + (int)blockIdx.x * ldstride,
-                 info + (int)blockIdx.x * istride);
+                 info + (int)blockIdx.x * istride, flag, epoch);
 }
 
 
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
-                 double* logdet_part, int* info, int nbatch, long long bstride, int ldstride, int istride) {
+                 double* logdet_part, int* info, int nbatch, long long bstride, int ldstride, int istride, int* flag, int epoch) {
     constexpr size_t lds = (size_t)(128 * LP + SY_SIZE + SC_SIZE) * sizeof(double);
     static std::once_flag attr_once[MFGP_MAX_DEVICES];   // per device, thread-safe (see launch_gemm)
     int dev = 0;
@@ -403,7 +413,7 @@ void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     hipLaunchKernelGGL(mfgp_leaf_cholinv_f64, dim3(nbatch > 0 ? nbatch : 1), dim3(LEAF_THREADS), lds, s, A, Lout, S, ld, blk,
-                       logdet_part, info, bstride, ldstride, istride);
+                       logdet_part, info, bstride, ldstride, istride, flag, epoch);
 }
 
 }  // namespace mfgp

@@ -47,9 +47,11 @@ static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nb
     if (s.kind == 0) {
         if (batched)
             launch_leaf(st, base(BUF_A), base(BUF_L), base(BUF_S), (int)h->Np, s.blk, h->blogdet,
-                        reinterpret_cast<int*>(h->bdres + 30), nbatch, bstride, (int)(h->cap / NB), 2 * mfgp_handle::BRES);
+                        reinterpret_cast<int*>(h->bdres + 30), nbatch, bstride, (int)(h->cap / NB), 2 * mfgp_handle::BRES,
+                        h->dflag + 1, h->epoch);
         else
-            launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo);
+            launch_leaf(st, h->buf[BUF_A], h->buf[BUF_L], h->buf[BUF_S], (int)h->Np, s.blk, h->dlogdet, h->dinfo, 1, 0, 0, 0,
+                        h->dflag, h->epoch);
         h->launches++;
     } else if (s.kind == 1) {
         // a launch that carries a chunk of the K^-1 accumulation has a second task list for gradient evaluations
@@ -57,7 +59,8 @@ static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nb
         const int n = g ? s.gcount : s.count;
         if (n > 0) {
             if (launch_gemm(st, s.tile, dtasks + (g ? s.gfirst : s.first), n, base(s.a), base(s.b), base(s.c),
-                            s.c2 >= 0 ? base(s.c2) : nullptr, (int)h->Np, s.role, batched ? nbatch : 1, bstride) != 0)
+                            s.c2 >= 0 ? base(s.c2) : nullptr, (int)h->Np, s.role, batched ? nbatch : 1, bstride,
+                            batched ? h->dflag + 1 : h->dflag, h->epoch) != 0)
                 return fail(h, -1, "planner bug: no tile-GEMM kernel for tile " + std::to_string(s.tile) + ", role " +
                                        std::to_string(s.role));
             h->launches++;
@@ -68,9 +71,10 @@ static int run_step(mfgp_handle* h, const Step& s, bool want_grad = true, int nb
         const int size = h->pls.shard.size, rank = h->pls.shard.rank, c = s.blk, Np = (int)h->Np;
         if (s.kind == STEP_COMM_DIAG) {
             const int root = shard_owner(c, size);
-            if (root == rank) launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c, h->ddist, h->dlogdet, h->dinfo, false);
+            if (root == rank) launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c, h->ddist, h->dlogdet, h->dinfo, false);   // (pack)
             if (int rc = comm_bcast_words(h, h->ddist, 2 * (size_t)NB * NB + 2, root, st)) return rc;
-            if (root != rank) launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c, h->ddist, h->dlogdet, h->dinfo, true);
+            if (root != rank)
+                launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c, h->ddist, h->dlogdet, h->dinfo, true, h->dflag, h->epoch);
         } else {
             std::vector<int> cnt((size_t)size, 0);
             for (int i = c + 1; i < h->nblk; ++i) cnt[(size_t)shard_owner(i, size)]++;
@@ -143,6 +147,10 @@ static int create_body(mfgp_handle* h, int device_id) {
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dio), h->hio, 0));
     h->dinfo = reinterpret_cast<int*>(h->dres + 30);   // the pivot status lives beside the results
     h->hinfo = reinterpret_cast<int*>(h->hres + 30);
+    // ... and, for the kernels, a failure mark per matrix set in DEVICE memory (the status word is a PCIe read away): a mark holds
+    // the number of the evaluation that failed, so nothing has to clear it between evaluations
+    HIPCHK(h, hipMalloc(&h->dflag, (size_t)(1 + MFGP_BATCH_MAX) * sizeof(int)));
+    HIPCHK(h, hipMemset(h->dflag, 0, (size_t)(1 + MFGP_BATCH_MAX) * sizeof(int)));
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device_id));
     char tmp[256];
@@ -199,6 +207,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->drow_off) hipFree(h->drow_off);
     if (h->ddist) hipFree(h->ddist);
     if (h->dctl) hipFree(h->dctl);
+    if (h->dflag) hipFree(h->dflag);
     if (h->hctl) hipHostFree(h->hctl);
     comm_release(h);
     if (h->dstage) hipFree(h->dstage);
@@ -356,6 +365,7 @@ static int enqueue_eval(mfgp_handle* h, const double* theta, double noise, doubl
         if (rc_) return rc_;
     }
     *h->hinfo = 0;   // (the previous call synchronised the stream)
+    ++h->epoch;
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], s));
     if (!prebuilt) {
         launch_kbuild_tri(s, h->spec, h->dX, (int)h->N, (int)h->Np, h->buf[BUF_A], (int)h->Np);
@@ -582,6 +592,7 @@ int32_t mfgp_eval_batch(mfgp_handle* h, int32_t B, const double* thetas, const d
         *reinterpret_cast<int*>(r + 30) = 0;
         for (int i = 0; i < np; ++i) r[128 + i] = specs[b].theta[i];        // the gradient's finishing kernel divides by them
     }
+    ++h->epoch;
     // from the first launch on, an error exit waits for what is already in flight on both streams: the next call rewrites the mapped
     // result blocks and the per-set parameter words from the host
     auto bail = [&](int code) {
@@ -751,6 +762,7 @@ static int sharded_pass(mfgp_handle* h, const double* theta, double noise, doubl
     const int Np = (int)h->Np;
     h->launches = 0;
     *h->hinfo = 0;
+    ++h->epoch;
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], s));
     launch_kbuild_tri(s, h->spec, h->dX, (int)h->N, Np, h->buf[BUF_A], Np);
     h->launches++;

@@ -40,8 +40,11 @@ constexpr int MFGP_MAX_GROUPS = 3;
 //       3 = a step on the serial Cholesky chain (64-tile only: mfgp_gemm_nt_f64_chain), 5 = its 32-tile form
 // nbatch / bstride: the same task list over nbatch matrix sets lying bstride elements apart (mfgp_eval_batch); 1 / 0 otherwise
 // -> 0, or -1 for a (tile, role) pair no kernel exists for
+// flag / epoch: the device-resident failure marks of the handle's evaluations (one int per matrix set; leaf_f64.hip sets
+// flag[set] = epoch when a diagonal block is not positive definite) -- a launch whose set is marked returns at once; nullptr: no check
 int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, const double* A,
-                const double* B, double* C, double* C2, int ld, int role = 0, int nbatch = 1, long long bstride = 0);
+                const double* B, double* C, double* C2, int ld, int role = 0, int nbatch = 1, long long bstride = 0,
+                const int* flag = nullptr, int epoch = 0);
 size_t gemm_lds_bytes(int tile);
 // skinny variance product for <= 64 test rows: V[0 .. 16*rows16) = W X^T (X = L^-1 from the mirrored S); rows16 in {1, 2, 4}
 void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const double* S, double* V, int ld, int Np);
@@ -58,8 +61,10 @@ void launch_predv_finish(hipStream_t s, int rows, const double* V, int ld, int N
 //   L block (zeros above diag) -> Lout[blk,blk];  X = L^-1 -> S[blk,blk] stored mirrored (X + X^T - diag)
 //   half log-det partial -> logdet_part[blk];  first failing pivot (1-based global index) -> info (atomicMin style)
 //   batched: nbatch workgroups, set b at A + b * bstride (and Lout, S), logdet_part + b * ldstride, info + b * istride
+//   flag / epoch: see launch_gemm (the leaf both checks and sets the mark)
 void launch_leaf(hipStream_t s, const double* A, double* Lout, double* S, int ld, int blk,
-                 double* logdet_part, int* info, int nbatch = 1, long long bstride = 0, int ldstride = 0, int istride = 0);
+                 double* logdet_part, int* info, int nbatch = 1, long long bstride = 0, int ldstride = 0, int istride = 0,
+                 int* flag = nullptr, int epoch = 0);
 
 // covariance builders
 //   tri: lower-triangle 64x64 tiles of Ky = K + (noise+jitter) I over padded Np (identity padding)
@@ -113,7 +118,8 @@ void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* 
                             int rank, int size, bool unpack, bool lower = false);
 //   exchange steps of a distributed Cholesky (plan.h Shard::dist): the diagonal blocks + the leaf's words to / from one message; the
 //   blocks of block column c of L below the diagonal to / from the all-gather's buffer (chunk doubles per rank)
-void launch_dist_diag_copy(hipStream_t s, double* L, double* S, int ld, int c, double* stage, double* logdet, int* info, bool unpack);
+void launch_dist_diag_copy(hipStream_t s, double* L, double* S, int ld, int c, double* stage, double* logdet, int* info, bool unpack,
+                           int* flag = nullptr, int epoch = 0);
 void launch_dist_panel_copy(hipStream_t s, double* L, int ld, int nblk, int c, double* stage, long long chunk, int rank, int size,
                             bool unpack);
 //   nbatch sets: K^-1 of set b at Kinv + b * kstride, alpha + b * astride, partials + b * pstride, out + b * ostride; thetas =
@@ -150,6 +156,8 @@ struct mfgp_handle {
     double *dlogdet = nullptr, *dres = nullptr, *dpart = nullptr, *dvec = nullptr,
            *dvec2 = nullptr;
     int* dinfo = nullptr;
+    int* dflag = nullptr;            // device-resident failure marks: [0] the handle's own evaluation, [1 + b] set b of a batch
+    int epoch = 0;                   // number of the evaluation in flight: a mark equal to it says "this one has failed"
     mfgp::GemmTask* dtasks = nullptr;
     size_t tasks_cap = 0;
     int xs_cap_rows = 0, xs_cap_D = 0;

@@ -170,7 +170,7 @@ void launch_shard_rows_copy(hipStream_t s, double* S, int ld, int nblk, double* 
 // contiguous message of 2 * 128^2 + 2 doubles: packed by the owner, unpacked by everybody else.  One workgroup per block row.
 __global__ __launch_bounds__(128) void mfgp_dist_diag_copy_f64(double* __restrict__ L, double* __restrict__ S, int ld, int c,
                                                                double* __restrict__ stage, double* __restrict__ logdet,
-                                                               int* __restrict__ info, int unpack) {
+                                                               int* __restrict__ info, int unpack, int* __restrict__ flag, int epoch) {
     const int r = blockIdx.x, k = threadIdx.x;
     double* pl = L + (long long)(c * 128 + r) * ld + c * 128 + k;
     double* ps = S + (long long)(c * 128 + r) * ld + c * 128 + k;
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(128) void mfgp_dist_diag_copy_f64(double* __restric
             logdet[c] = stage[2 * 128 * 128];
             const int st = (int)stage[2 * 128 * 128 + 1];
             if (st != 0 && *info == 0) *info = st;
+            if (st != 0 && flag) *flag = epoch;          // the owner's leaf failed: this rank's later launches return at once too
         }
     } else {
         stage[r * 128 + k] = *pl;
@@ -191,8 +192,10 @@ __global__ __launch_bounds__(128) void mfgp_dist_diag_copy_f64(double* __restric
         }
     }
 }
-void launch_dist_diag_copy(hipStream_t s, double* L, double* S, int ld, int c, double* stage, double* logdet, int* info, bool unpack) {
-    hipLaunchKernelGGL(mfgp_dist_diag_copy_f64, dim3(128), dim3(128), 0, s, L, S, ld, c, stage, logdet, info, unpack ? 1 : 0);
+void launch_dist_diag_copy(hipStream_t s, double* L, double* S, int ld, int c, double* stage, double* logdet, int* info, bool unpack,
+                           int* flag, int epoch) {
+    hipLaunchKernelGGL(mfgp_dist_diag_copy_f64, dim3(128), dim3(128), 0, s, L, S, ld, c, stage, logdet, info, unpack ? 1 : 0, flag,
+                       epoch);
 }
 // COMM_PANEL(c): block column c of L below the diagonal.  Block (i, c), i > c, belongs to shard_owner(i); it is the k-th block of its
 // owner in this column (k = the owner's blocks in (c, i)) and travels at [owner * chunk + k * 128^2) of the all-gather's buffer.
