@@ -253,7 +253,12 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=170.0):
         lap["seconds_of_one_hf_eval"] = round(lap["dpotrf_s"] + lap["dtrtri_s"] + lap["dpotri_s"], 3)
         lap["share_of_one_hf_eval"] = round(lap["seconds_of_one_hf_eval"] / hf_eval_s, 3)
     total_s = n_lf_evals * lf_eval_s + n_hf_evals * hf_eval_s + lf_means_s + hf_predict_s
+    # ... and the same evaluations priced at the LAPACK routines alone (both levels factorise an N x N matrix): what a host code
+    # without numpy's N^2 temporaries could not go below
+    lapack_only_ms = (round((n_lf_evals + n_hf_evals) * lap["seconds_of_one_hf_eval"] * 1e3, 1) if "error" not in lap else None)
     return {"value": round(total_s * 1e3, 1), "unit": "ms", "cores": int(blas["threads"]), "kind": "port-extrapolated",
+            "lapack_only_ms": lapack_only_ms,
+            "lapack_only_is": "(LF + HF evaluations the GPU run issued) x the measured dpotrf + dtrtri + dpotri seconds of one N x N evaluation",
             "blas": blas, "blas_threads_tried_gflops": tried,
             "blas_threads_tried_per_routine_n4096": getattr(_pick_blas_threads, "detail", None), "host_cpu": _host_cpu(),
             "measured_s": round(measured, 2),
@@ -471,6 +476,8 @@ def main():
     ap.add_argument("--aux-order", default="natural", choices=["natural", "reversed"])
     ap.add_argument("--lend-main", type=int, default=0, help="1: the main engine joins the restarts' pool after restart 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip `extra_configs` (cfg2 / cfg3 / cfg5 of BASELINE.json measured after the timed region, outside `value`: bench_extra.py, ~10 s)")
     ap.add_argument("--power", action="store_true", help="sample socket power / sclk beside the timed region (a child process; "
                                                          "off by default: it costs host CPU beside the optimiser threads; never under a profiler)")
     ap.add_argument("--no-power", action="store_true", help="(accepted for old command lines; power sampling is off unless --power)")
@@ -658,7 +665,11 @@ def main():
                        "shard_groups_formed": int(getattr(comm, "groups_formed", 0)),   # (communicators created beside the world's: once per group, not per step)
                        "ranks": world, "rccl_ranks": int(engines["lf"].comm_size), "library_build_id": build_id,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
-                       "sharding": sharding_note(world, args.restarts, int(engines["lf"].comm_size))},
+                       "sharding": sharding_note(world, args.restarts, int(engines["lf"].comm_size)),
+                       # first hardware contact decides by measurement: what a collective of the world communicator cost when
+                       # it was formed, and what the planner makes of it for the LF level's shared evaluations
+                       "sharding_calibration": ({"world_communicator": getattr(comm, "calibration", None),
+                                                 "lf_level_decision": engines["lf"].shard_decision()} if world > 1 else None)},
             # the dominant work: ONE sweep per evaluation = Cholesky + triangular inverse%s, timed with HIP events on the
             # engine's main stream around the sweep (the bulk stream joins before the closing event)
             "roofline": {"kernel": "factorisation sweep per evaluation: mfgp_leaf_cholinv_f64 + mfgp_gemm_nt_f64_{t128,t64,chain} on v_mfma_f64_4x4x4_4b "
@@ -752,10 +763,17 @@ def main():
             out["power"] = power
         if rowblock is not None:
             out["rowblock_allgather"] = rowblock
+        if world == 1 and not args.no_extra:
+            # the non-headline configurations of BASELINE.json, driver-run: after the timed region, never part of `value`
+            import bench_extra
+            out["extra_configs"] = bench_extra.extra_configs()
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args, data, clf["evals"] / args.steps, chf["evals"] / args.steps)
             out["cpu_baseline"] = cb
             out["config"]["gpu_over_cpu"] = round(cb["value"] / ms_per_step, 2)
+            if cb.get("lapack_only_ms"):
+                # the comparator that is not about numpy temporaries: the same evaluations priced at the measured dpotrf + dtrtri + dpotri
+                out["config"]["gpu_over_cpu_lapack_only"] = round(cb["lapack_only_ms"] / ms_per_step, 2)
         print(json.dumps(out), flush=True)
     comm.barrier()
     if world > 1 and comm.transport == "rccl":

@@ -186,6 +186,23 @@ int32_t mfgp_comm_destroy(mfgp_handle* h);
  *   returns -4 and the process is expected to END with an error, so that its launcher stops the peers.  The same deadline guards
  *   mfgp_allgather_rows and mfgp_allgather_host: a gather the peers never join returns -4 after it instead of blocking for ever. */
 int32_t mfgp_comm_state(mfgp_handle* h);
+/* Collective (every rank of the handle's communicator, same arguments): what one small collective of this group costs on the
+ * handle's stream, MEASURED -- the median of `reps` ncclBroadcast of a diagonal message (2 x 128^2 + 2 doubles) and of `reps`
+ * in-place ncclAllGather of `panel_blocks` 128 x 128 blocks per rank (0: what a middle block column of the current matrix carries),
+ * host clock from the enqueue to the stream running dry, two untimed repetitions first; rank 0's medians are broadcast so that
+ * every rank holds the same figures.  out6 = {broadcast us, all-gather us, all-gather bytes per rank, all-gather GB/s received,
+ * reps, this rank's own worst median us}.  The figure stays on the handle and decides, when a shared evaluation is planned,
+ * whether its Cholesky is distributed over the group as well (2 nblk - 1 such collectives on the serial chain) or replicated
+ * (mfgp_shard_decision); without a calibration it is replicated.  There is no counterpart in the reference (one process, no GPU). */
+int32_t mfgp_comm_calibrate(mfgp_handle* h, int32_t reps, int32_t panel_blocks, double* out6);
+/* the choice a shared evaluation of the handle's current matrix will be planned under: out6 = {1 distributed / 0 replicated
+ * Cholesky, projected saving ms, cost ms = collectives x measured us, collectives on the chain, measured us per collective
+ * (0: never calibrated), 1 if MFGP_DIST_CHOL forced the choice} */
+int32_t mfgp_shard_decision(mfgp_handle* h, double* out6);
+/* the rule itself (pure host arithmetic, no handle, no GPU): 1 if a group of `size` ranks should distribute the Cholesky of an
+ * nblk x 128 matrix when one collective costs coll_us microseconds (saving: (1 - 1/size) N^3/3 flops at 60 TFLOP/s; cost:
+ * (2 nblk - 1) collectives; taken at saving > 1.25 x cost, never at coll_us <= 0) */
+int32_t mfgp_dist_cholesky_pays(int32_t nblk, int32_t size, double coll_us, double* saving_ms, double* cost_ms);
 int32_t mfgp_allgather_rows(mfgp_handle* h);
 int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, double* recv);
 /* mfgp_eval_sharded: mfgp_eval as ONE evaluation across the ranks of the handle's communicator (collective: every rank calls it
@@ -279,6 +296,11 @@ int32_t mfgp_dbg_eval_as_rank(mfgp_handle* h, const double* theta, double noise,
 /* Cholesky + inverse of one SPD 128x128 block through the leaf kernel: Lout, Xout are 128x128. */
 /* test hook: the n-th sharded pass from now (leader or follower form) fails on THIS rank after the control exchange (0: off) */
 int32_t mfgp_dbg_fail_sharded_after(mfgp_handle* h, int32_t n);
+/* test hook: the n-th ncclAllGather this handle issues from now (mfgp_allgather_rows, mfgp_allgather_host, the exchange of a shared
+ * pass) comes back with an RCCL error WITHOUT having been issued (0: off) -- what the failure path of a gather does is then
+ * observable: the communicator is aborted, the handle's collective calls are poisoned (mfgp_comm_state = -1), the peers give up at
+ * their deadline */
+int32_t mfgp_dbg_fail_collective_after(mfgp_handle* h, int32_t n);
 int32_t mfgp_dbg_leaf(mfgp_handle* h, const double* A, double* Lout, double* Xout, double* logdet_half);
 #ifdef __cplusplus
 }

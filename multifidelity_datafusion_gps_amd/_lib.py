@@ -29,9 +29,10 @@ EXPORTED_SYMBOLS = [
     "mfgp_augment", "mfgp_predict_chained",
     "mfgp_get_K", "mfgp_get_L", "mfgp_get_Linv", "mfgp_get_Kinv", "mfgp_get_alpha", "mfgp_get_timings",
     "mfgp_get_counters", "mfgp_device_synchronize",
-    "mfgp_comm_unique_id", "mfgp_comm_init", "mfgp_comm_destroy", "mfgp_comm_state", "mfgp_allgather_rows", "mfgp_allgather_host",
+    "mfgp_comm_unique_id", "mfgp_comm_init", "mfgp_comm_destroy", "mfgp_comm_state", "mfgp_comm_calibrate", "mfgp_shard_decision", "mfgp_dist_cholesky_pays", "mfgp_allgather_rows", "mfgp_allgather_host",
     "mfgp_rows_download", "mfgp_rows_upload",
     "mfgp_dbg_gemm_nt", "mfgp_dbg_leaf", "mfgp_dbg_eval_as_rank", "mfgp_dbg_fail_sharded_after",
+    "mfgp_dbg_fail_collective_after",
 ]
 
 
@@ -149,7 +150,11 @@ def load_library(path=None):
         "mfgp_comm_init": (i32, [H, ctypes.POINTER(ctypes.c_uint8), i32, i32]),
         "mfgp_comm_destroy": (i32, [H]),
         "mfgp_comm_state": (i32, [H]),
+        "mfgp_comm_calibrate": (i32, [H, i32, i32, dp]),
+        "mfgp_shard_decision": (i32, [H, dp]),
+        "mfgp_dist_cholesky_pays": (i32, [i32, i32, ctypes.c_double, dp, dp]),
         "mfgp_dbg_fail_sharded_after": (i32, [H, i32]),
+        "mfgp_dbg_fail_collective_after": (i32, [H, i32]),
         "mfgp_allgather_rows": (i32, [H]),
         "mfgp_allgather_host": (i32, [H, dp, i64, dp]),
         "mfgp_rows_download": (i32, [H, i64, i64, dp]),
@@ -417,8 +422,30 @@ class Engine:
         and the process should end with an error (mfgp_comm_state == -1)"""
         return self._h is not None and int(self._lib.mfgp_comm_state(self._h)) < 0
 
+    def comm_calibrate(self, reps=20, panel_blocks=0):
+        """collective: measure what a small collective of this handle's communicator costs (mfgp_comm_calibrate) -> dict; the figure
+        stays on the handle and decides whether a shared evaluation's Cholesky is distributed over the group"""
+        out = np.zeros(6)
+        self._check(self._lib.mfgp_comm_calibrate(self._h, int(reps), int(panel_blocks), _dptr(out)), "mfgp_comm_calibrate")
+        return {"broadcast_us": float(out[0]), "allgather_us": float(out[1]), "allgather_bytes_per_rank": int(out[2]),
+                "allgather_GBps": float(out[3]), "reps": int(out[4]), "own_worst_median_us": float(out[5])}
+
+    def shard_decision(self):
+        """-> dict: how a shared evaluation of the current matrix will be planned (mfgp_shard_decision)"""
+        out = np.zeros(6)
+        self._check(self._lib.mfgp_shard_decision(self._h, _dptr(out)), "mfgp_shard_decision")
+        return {"cholesky": "distributed" if out[0] else "replicated", "projected_saving_ms": float(out[1]), "collective_cost_ms": float(out[2]),
+                "collectives_on_chain": int(out[3]), "measured_us_per_collective": float(out[4]), "forced_by_MFGP_DIST_CHOL": bool(out[5]),
+                "why": ("MFGP_DIST_CHOL set" if out[5] else
+                        ("no calibration: replicated until a collective of this group has been measured" if out[4] <= 0 else
+                         "%d collectives x %.1f us = %.2f ms against %.2f ms of Cholesky flops saved (taken at saving > 1.25 x cost)"
+                         % (int(out[3]), out[4], out[2], out[1])))}
+
     def dbg_fail_sharded_after(self, n):
         self._check(self._lib.mfgp_dbg_fail_sharded_after(self._h, int(n)), "mfgp_dbg_fail_sharded_after")
+
+    def dbg_fail_collective_after(self, n):
+        self._check(self._lib.mfgp_dbg_fail_collective_after(self._h, int(n)), "mfgp_dbg_fail_collective_after")
 
     def allgather_rows(self):
         """RCCL all-gather of the ranks' 128-row blocks of the device matrix (after kbuild_owned_rows with the communicator's rank and

@@ -17,6 +17,7 @@
 // over whatever the host side uses for rendezvous (sharding.SocketComm: TCP on 127.0.0.1).
 #include <dlfcn.h>
 #include <string.h>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -77,10 +78,29 @@ RcclApi& rccl() {
 int rccl_fail(mfgp_handle* h, const char* what, ncclResult_t r) {
     return fail(h, -4, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error"));
 }
+
+// ncclAllGather, or -- test hook mfgp_dbg_fail_collective_after -- the error RCCL would have returned without the call being made
+ncclResult_t all_gather(mfgp_handle* h, const void* send, void* recv, size_t count, hipStream_t s) {
+    if (h->dbg_fail_collective_in > 0 && --h->dbg_fail_collective_in == 0) return ncclInternalError;
+    return rccl().AllGather(send, recv, count, ncclDouble, static_cast<ncclComm_t>(h->comm), s);
+}
+
+// a gather whose ncclAllGather was refused: the peers are inside (or on their way into) a collective this rank will never join.
+// Exactly what shard_broken does for a shared pass: tear the communicator down without them (which also poisons the handle's
+// further collective calls), let what this call had already enqueued drain, report -4 -- the peers give up at their deadline
+int gather_broken(mfgp_handle* h, hipStream_t s, const char* what, ncclResult_t r) {
+    const int rc = rccl_fail(h, what, r);
+    const std::string why = h->err;
+    comm_abort(h);
+    (void)hipStreamSynchronize(s);
+    h->err = why + " [the communicator was aborted, no further collective is issued]";
+    return rc;
+}
 }  // namespace
 
 namespace mfgp {
 void comm_release(mfgp_handle* h) {
+    if (h) { h->coll_us = 0.0; for (double& v : h->calib) v = 0.0; }
     if (h && h->comm) {
         rccl().CommDestroy(static_cast<ncclComm_t>(h->comm));
         h->comm = nullptr;
@@ -149,8 +169,7 @@ int comm_stream_wait(mfgp_handle* h, hipStream_t s, const char* what) {
 int comm_allgather_chunks(mfgp_handle* h, double* base, size_t chunk, hipStream_t s) {
     if (int rc = comm_usable(h, "ncclAllGather (rows of X^T)")) return rc;
     if (!h->comm || h->comm_size <= 1) return 0;
-    ncclResult_t r = rccl().AllGather(base + (size_t)h->comm_rank * chunk, base, chunk, ncclDouble,
-                                      static_cast<ncclComm_t>(h->comm), s);
+    ncclResult_t r = all_gather(h, base + (size_t)h->comm_rank * chunk, base, chunk, s);
     if (r != ncclSuccess) return rccl_fail(h, "ncclAllGather (rows of X^T)", r);
     return 0;
 }
@@ -195,6 +214,9 @@ int32_t mfgp_comm_init(mfgp_handle* h, const uint8_t* id128, int32_t rank, int32
     if (size < 1 || rank < 0 || rank >= size) return fail(h, -1, "mfgp_comm_init: need 0 <= rank < size");
     RcclApi& api = rccl();
     if (!api.lib) return fail(h, -4, "mfgp_comm_init: " + api.load_error);
+    // every "nothing hangs" guarantee of the collective calls rests on ncclCommAbort (it ends a collective kernel of this rank that
+    // waits for an absent peer): a communicator of several ranks is not created without it
+    if (size > 1 && !api.CommAbort) return fail(h, -4, "mfgp_comm_init: librccl lacks ncclCommAbort");
     HIPCHK(h, hipSetDevice(h->device));
     comm_release(h);
     ncclUniqueId id;
@@ -218,6 +240,111 @@ int32_t mfgp_comm_destroy(mfgp_handle* h) {
 int32_t mfgp_comm_state(mfgp_handle* h) {
     if (!h) return 0;
     return h->comm_aborted ? -1 : (h->comm ? h->comm_size : 0);
+}
+
+// What one small collective of THIS communicator costs on a stream, measured (the planner's choice between the
+// replicated and the distributed Cholesky of a shared evaluation rested on a constant derived from a one-GPU projection).
+// Collective: every rank of the communicator calls it with the same `reps`.  Two shapes, the two exchange steps of a distributed
+// Cholesky's block column (plan.h): ncclBroadcast of a diagonal message (2 x 128^2 + 2 doubles, root 0) and an in-place
+// ncclAllGather of `panel_blocks` 128 x 128 blocks per rank (0: what a column in the middle of the handle's current matrix
+// carries per rank, at least one block) -- each timed `reps` times by the host clock from the enqueue to the stream running dry
+// (that is what the serial chain waits for), after two untimed repetitions (connections are set up lazily); medians.  Rank 0's
+// medians are then broadcast, so that every rank of the group holds the SAME figures and plans alike:
+//   out[0] broadcast us, out[1] all-gather us, out[2] all-gather bytes per rank, out[3] all-gather GB/s (bytes received / time),
+//   out[4] reps, out[5] the worst of this rank's OWN two medians (diagnostic).
+// Stored on the handle: coll_us = the larger of out[0], out[1] + 8 us for the pack and unpack launches around an exchange.
+int32_t mfgp_comm_calibrate(mfgp_handle* h, int32_t reps, int32_t panel_blocks, double* out6) {
+    if (!h) return fail(h, -1, "mfgp_comm_calibrate: NULL");
+    if (int rc = comm_usable(h, "mfgp_comm_calibrate")) return rc;
+    if (reps < 1 || reps > 1000 || panel_blocks < 0) return fail(h, -1, "mfgp_comm_calibrate: need 1 <= reps <= 1000, panel_blocks >= 0");
+    for (double& v : h->calib) v = 0.0;
+    h->coll_us = 0.0;
+    if (!h->comm || h->comm_size <= 1) {
+        if (out6) for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+        return 0;
+    }
+    RcclApi& api = rccl();
+    if (!api.Broadcast) return fail(h, -4, "librccl lacks ncclBroadcast");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int size = h->comm_size;
+    const size_t diag = 2 * (size_t)NB * NB + 2;
+    const int blocks = panel_blocks > 0 ? panel_blocks : std::max(1, (h->have_data ? h->nblk / 2 : 32) / size);
+    const size_t chunk = (size_t)blocks * NB * NB;
+    const size_t need = std::max(diag, chunk * size) + 8;
+    if (need > h->stage_cap) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (h->dstage) HIPCHK(h, hipFree(h->dstage));
+        h->dstage = nullptr;
+        h->stage_cap = need;
+        HIPCHK(h, hipMalloc(&h->dstage, h->stage_cap * sizeof(double)));
+    }
+    HIPCHK(h, hipMemsetAsync(h->dstage, 0, need * sizeof(double), s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    std::vector<double> tb, tg;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    for (int it = 0; it < reps + 2; ++it) {
+        const auto t0 = now();
+        ncclResult_t r = api.Broadcast(h->dstage, h->dstage, diag, ncclDouble, 0, static_cast<ncclComm_t>(h->comm), s);
+        if (r != ncclSuccess) return gather_broken(h, s, "mfgp_comm_calibrate: ncclBroadcast", r);
+        if (int rc = comm_stream_wait(h, s, "mfgp_comm_calibrate: waiting for a broadcast")) return rc;
+        if (it >= 2) tb.push_back(std::chrono::duration<double>(now() - t0).count() * 1e6);
+    }
+    for (int it = 0; it < reps + 2; ++it) {
+        const auto t0 = now();
+        ncclResult_t r = all_gather(h, h->dstage + (size_t)h->comm_rank * chunk, h->dstage, chunk, s);
+        if (r != ncclSuccess) return gather_broken(h, s, "mfgp_comm_calibrate: ncclAllGather", r);
+        if (int rc = comm_stream_wait(h, s, "mfgp_comm_calibrate: waiting for an all-gather")) return rc;
+        if (it >= 2) tg.push_back(std::chrono::duration<double>(now() - t0).count() * 1e6);
+    }
+    std::sort(tb.begin(), tb.end());
+    std::sort(tg.begin(), tg.end());
+    double mine[2] = {tb[tb.size() / 2], tg[tg.size() / 2]}, agreed[2] = {0, 0};
+    // rank 0's medians to everybody (through the staging buffer: the collectives work on device memory)
+    HIPCHK(h, hipMemcpy(h->dstage, mine, sizeof mine, hipMemcpyHostToDevice));
+    ncclResult_t r = api.Broadcast(h->dstage, h->dstage, 2, ncclDouble, 0, static_cast<ncclComm_t>(h->comm), s);
+    if (r != ncclSuccess) return gather_broken(h, s, "mfgp_comm_calibrate: ncclBroadcast (agreed figures)", r);
+    if (int rc = comm_stream_wait(h, s, "mfgp_comm_calibrate: waiting for the agreed figures")) return rc;
+    HIPCHK(h, hipMemcpy(agreed, h->dstage, sizeof agreed, hipMemcpyDeviceToHost));
+    h->calib[0] = agreed[0];
+    h->calib[1] = agreed[1];
+    h->calib[2] = (double)(chunk * sizeof(double));
+    h->calib[3] = agreed[1] > 0 ? (double)(chunk * sizeof(double)) * (size - 1) / (agreed[1] * 1e-6) / 1e9 : 0.0;
+    h->calib[4] = reps;
+    h->calib[5] = std::max(mine[0], mine[1]);
+    h->coll_us = std::max(agreed[0], agreed[1]) + 8.0;
+    if (out6) for (int i = 0; i < 6; ++i) out6[i] = h->calib[i];
+    return 0;
+}
+
+// What the planner makes of it for the handle's current matrix and communicator -- the decision mfgp_eval_sharded /
+// mfgp_sharded_lead will plan under (MFGP_DIST_CHOL = 0 / 1 overrides it):
+//   out[0] 1 = the Cholesky distributed over the group, 0 = replicated on every rank; out[1] projected saving ms; out[2] cost ms
+//   (collectives x measured us); out[3] collectives on the chain; out[4] the measured us per collective (0: never calibrated);
+//   out[5] 1 if an environment switch forced the choice
+int32_t mfgp_shard_decision(mfgp_handle* h, double* out6) {
+    if (!h || !out6) return fail(h, -1, "mfgp_shard_decision: NULL argument");
+    if (!h->have_data) return fail(h, -1, "mfgp_shard_decision: mfgp_set_data not called");
+    const int size = h->comm ? h->comm_size : 1;
+    const DistDecision d = dist_cholesky_pays(h->nblk, size, h->coll_us);
+    const int forced = h->pl.opts.dist_chol;
+    out6[0] = size > 1 && (forced >= 0 ? forced != 0 : d.dist) ? 1.0 : 0.0;
+    out6[1] = d.saving_ms; out6[2] = d.cost_ms; out6[3] = d.collectives; out6[4] = h->coll_us; out6[5] = forced >= 0 ? 1.0 : 0.0;
+    return 0;
+}
+
+// The planner's rule itself, without a handle (pure host arithmetic: testable where there is no GPU)
+int32_t mfgp_dist_cholesky_pays(int32_t nblk, int32_t size, double coll_us, double* saving_ms, double* cost_ms) {
+    const DistDecision d = dist_cholesky_pays(nblk, size, coll_us);
+    if (saving_ms) *saving_ms = d.saving_ms;
+    if (cost_ms) *cost_ms = d.cost_ms;
+    return d.dist ? 1 : 0;
+}
+
+int32_t mfgp_dbg_fail_collective_after(mfgp_handle* h, int32_t n) {
+    if (!h || n < 0) return fail(h, -1, "mfgp_dbg_fail_collective_after: bad argument");
+    h->dbg_fail_collective_in = n;
+    return 0;
 }
 
 int32_t mfgp_row_block_owner(int32_t block, int32_t size) { return block < 0 ? -1 : shard_owner(block, size); }
@@ -273,12 +400,8 @@ int32_t mfgp_allgather_rows(mfgp_handle* h) {
     }
     double* A = h->buf[BUF_A];
     launch_shard_rows_copy(s, A, (int)h->Np, nblk, stage, h->drow_off, h->row_chunk, rank, size, false, true);
-    ncclResult_t r = rccl().AllGather(stage + (size_t)rank * (size_t)h->row_chunk, stage, (size_t)h->row_chunk, ncclDouble,
-                                      static_cast<ncclComm_t>(h->comm), s);
-    if (r != ncclSuccess) {
-        (void)hipStreamSynchronize(s);
-        return rccl_fail(h, "ncclAllGather (row blocks of Ky, lower part)", r);
-    }
+    ncclResult_t r = all_gather(h, stage + (size_t)rank * (size_t)h->row_chunk, stage, (size_t)h->row_chunk, s);
+    if (r != ncclSuccess) return gather_broken(h, s, "ncclAllGather (row blocks of Ky, lower part)", r);
     launch_shard_rows_copy(s, A, (int)h->Np, nblk, stage, h->drow_off, h->row_chunk, rank, size, true, true);
     if (int rc = comm_stream_wait(h, s, "mfgp_allgather_rows: waiting for the all-gather of the row blocks")) return rc;
     HIPCHK(h, hipGetLastError());
@@ -301,9 +424,8 @@ int32_t mfgp_allgather_host(mfgp_handle* h, const double* send, int64_t count, d
     }
     double* mine = h->dstage + (size_t)h->comm_rank * count;
     HIPCHK(h, hipMemcpyAsync(mine, send, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    ncclResult_t r = rccl().AllGather(mine, h->dstage, (size_t)count, ncclDouble, static_cast<ncclComm_t>(h->comm),
-                                      h->stream);
-    if (r != ncclSuccess) return rccl_fail(h, "ncclAllGather (host vectors)", r);
+    ncclResult_t r = all_gather(h, mine, h->dstage, (size_t)count, h->stream);
+    if (r != ncclSuccess) return gather_broken(h, h->stream, "ncclAllGather (host vectors)", r);   // (the copy above drains there)
     // the deadline wait BEFORE the copy back: a copy into pageable memory blocks the host until the stream reaches it
     if (int rc = comm_stream_wait(h, h->stream, "mfgp_allgather_host: waiting for the all-gather")) return rc;
     HIPCHK(h, hipMemcpy(recv, h->dstage, total * sizeof(double), hipMemcpyDeviceToHost));

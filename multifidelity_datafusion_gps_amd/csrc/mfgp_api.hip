@@ -697,10 +697,15 @@ int32_t mfgp_batch_mem(mfgp_handle* h, int32_t sets, int64_t* bytes, int64_t* ca
 // every tile is computed by exactly the tasks the single evaluation runs, the tile sums of the gradient meet in ONE array
 // (sum over ranks of arrays that are zero where a rank holds nothing) and are finished in the same fixed order.
 static int ensure_shard_plan(mfgp_handle* h, int rank, int size) {
+    // (the measured collective cost is an input of the plan -- it decides whether the Cholesky is distributed too -- and is the
+    // communicator's: a plan made before the calibration, or for another group, is planned again)
+    const double coll_us = (h->comm && h->comm_size == size) ? h->coll_us : 0.0;
     if (h->pls.nblk == h->nblk && h->pls.ld == h->Np && h->pls.shard.rank == rank && h->pls.shard.size == size &&
-        h->pls.stride == (int64_t)h->cap * h->cap)
+        h->pls.stride == (int64_t)h->cap * h->cap && h->pls.shard.coll_us == coll_us)
         return 0;
-    build_plan(h->pls, h->nblk, h->Np, (int64_t)h->cap * h->cap, h->pl.opts, 1, Shard{rank, size});
+    Shard sh;
+    sh.rank = rank; sh.size = size; sh.coll_us = coll_us;
+    build_plan(h->pls, h->nblk, h->Np, (int64_t)h->cap * h->cap, h->pl.opts, 1, sh);
     while ((int)h->evpool.size() < h->pls.n_events) {
         hipEvent_t e;
         HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -813,6 +818,14 @@ int32_t mfgp_eval_sharded(mfgp_handle* h, const double* theta, double noise, dou
     if (rc) return rc;
     if (!theta) return fail(h, -1, "mfgp_eval_sharded: theta is NULL");
     HIPCHK(h, hipSetDevice(h->device));
+    // everything that can be refused WITHOUT a collective in flight is checked first (as mfgp_sharded_lead does): a non-finite
+    // parameter or a failed allocation is an ordinary, recoverable error of this call -- the communicator stays
+    for (int i = 0; i < h->spec.np; ++i)
+        if (!(theta[i] > 0.0) || !isfinite(theta[i])) return fail(h, -1, "parameters must be positive and finite");
+    if (!(noise >= 0.0) || !(jitter >= 0.0)) return fail(h, -1, "noise and jitter must be >= 0");
+    if (h->comm_aborted) return fail(h, -4, "mfgp_eval_sharded: the group's communicator was aborted after a failed pass");
+    rc = ensure_shard_plan(h, h->comm_rank, h->comm_size);
+    if (rc) return rc;
     const bool group = h->comm && h->comm_size > 1;      // (a failure inside a pass the peers run too: see shard_broken)
     rc = sharded_pass(h, theta, noise, jitter, want_grad != 0, h->comm_rank, h->comm_size, true);
     if (rc) return group ? shard_broken(h, rc) : rc;

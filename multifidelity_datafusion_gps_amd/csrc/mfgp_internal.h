@@ -189,7 +189,10 @@ struct mfgp_handle {
     // multi-GPU (comm_rccl.hip): one RCCL communicator per handle, created by mfgp_comm_init; opaque here
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 1;
+    double coll_us = 0.0;                // measured cost of one small collective of this communicator (mfgp_comm_calibrate; 0: not measured)
+    double calib[6] = {0, 0, 0, 0, 0, 0};  //   {bcast_us, gather_us, gather bytes per rank, gather GB/s, repetitions, this rank's own worst median us}
     bool comm_aborted = false;           // the communicator was torn down after a failed / unmatched collective (comm_abort): no further one is issued
+    int dbg_fail_collective_in = 0;      // test hook (mfgp_dbg_fail_collective_after): the n-th all-gather from now returns an RCCL error without being issued
     int dbg_fail_sharded_in = 0;         // test hook (mfgp_dbg_fail_sharded_after): the n-th sharded pass from now fails after the control exchange
     double* dstage = nullptr;            // device staging of mfgp_allgather_host
     size_t stage_cap = 0;

@@ -833,11 +833,22 @@ static void plan_sweep(Plan& p) {
     }
 }
 
+DistDecision dist_cholesky_pays(int nblk, int size, double coll_us) {
+    DistDecision d{};
+    d.collectives = 2 * nblk - 1;
+    const double n = 128.0 * nblk;
+    d.saving_ms = size > 1 ? (1.0 - 1.0 / size) * (n * n * n / 3.0) / 60e12 * 1e3 : 0.0;
+    d.cost_ms = d.collectives * coll_us * 1e-3;
+    d.dist = size > 1 && coll_us > 0.0 && d.saving_ms > 1.25 * d.cost_ms;
+    return d;
+}
+
 void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& opts, int t128_div, const Shard& shard) {
     p = Plan{};
     p.opts = opts;
     p.shard = shard;
-    p.shard.dist = shard.size > 1 && (shard.dist || opt(opts.dist_chol, nblk >= 128) != 0);
+    p.shard.dist = shard.size > 1 && (shard.dist || (opts.dist_chol >= 0 ? opts.dist_chol != 0
+                                                                         : dist_cholesky_pays(nblk, shard.size, shard.coll_us).dist));
     if (shard.size > 1) p.opts.kind = 0;      // a sharded evaluation always runs the sweep
     p.t128_min = std::max(1, (opts.t128_min > 0 ? opts.t128_min : (nblk >= 56 ? 600 : 300)) / std::max(1, t128_div));
     p.batch_div = std::max(1, t128_div);

@@ -64,9 +64,9 @@ struct PlanOpts {
     int kinv_stream = -1;  // MFGP_KINV_STREAM
     int chain_slim = -1;   // MFGP_CHAIN_SLIM
     int t128_min = 0;      // MFGP_T128_MIN: tiles per launch from which 128-tiles are used
-    int dist_chol = -1;    // MFGP_DIST_CHOL: a sharded evaluation's Cholesky distributed over the group too (Shard::dist; default: from 128
-                           // block columns, N >= 16384 -- below, one GPU factorises faster than the group exchanges panels:
-                           // profiles/r05_dist_projection.txt)
+    int dist_chol = -1;    // MFGP_DIST_CHOL: a sharded evaluation's Cholesky distributed over the group too (Shard::dist): 1 / 0 force
+                           // it on / off; default (-1): decided from the group's MEASURED collective latency (Shard::coll_us,
+                           // dist_cholesky_pays) -- and off while nothing has been measured
 };
 // Row ownership of a sharded evaluation (mfgp_eval_sharded): the work on the image of the identity / the rows of X^T and the rows
 // of K^-1 -- 2 N^3 / 3 of an evaluation's N^3 flops -- splits by 128-row block with no dependency between blocks; block b belongs
@@ -81,8 +81,23 @@ struct PlanOpts {
 // single evaluation's own tasks, so no result bit changes.
 struct Shard {
     int rank = 0, size = 1;
-    bool dist = false;     // (set by build_plan from PlanOpts::dist_chol and the size)
+    bool dist = false;     // (set by build_plan from PlanOpts::dist_chol, or from the measurement below)
+    double coll_us = 0.0;  // microseconds one small collective of THIS group costs on the chain, measured on its own stream when the
+                           // communicator was formed (mfgp_comm_calibrate: the slower of the medians of ncclBroadcast of a diagonal
+                           // message and ncclAllGather of a panel chunk, rank 0's figures on every rank); 0: never measured
 };
+// Does distributing the Cholesky pay for a group of `size` ranks at `nblk` block columns, given what one collective costs?  The
+// distributed plan saves (1 - 1/G) of the Cholesky's N^3 / 3 flops per rank -- priced at 60 TFLOP/s, what the one-GPU projections
+// of round 5 gave for the saving at N = 8192 / 16384 / 32768 on 8 ranks (59 / 68 / 68: profiles/r05_dist_projection.txt) -- and
+// puts 2 nblk - 1 collectives (each with its pack and unpack launch) on the serial chain.  It is taken when the saving exceeds
+// 1.25 x that cost; never without a measurement (coll_us <= 0).  Pure arithmetic on its arguments: every rank of a group holds
+// the same coll_us and decides alike.
+struct DistDecision {
+    bool dist;
+    double saving_ms, cost_ms;
+    int collectives;
+};
+DistDecision dist_cholesky_pays(int nblk, int size, double coll_us);
 enum StepKind { STEP_LEAF = 0, STEP_GEMM = 1, STEP_JOIN = 2, STEP_COMM_DIAG = 3, STEP_COMM_PANEL = 4 };
 inline int shard_owner(int blk, int size) {
     if (size <= 1) return 0;

@@ -166,6 +166,7 @@ class ShardGroup:
 
     def __init__(self, engine, index, size):
         self.engine, self.index, self.size = engine, int(index), int(size)
+        self.calibration = None          # the measured cost of a collective of this group (Engine.comm_calibrate), where it was formed here
 
     @property
     def leads(self):
@@ -241,6 +242,7 @@ class SocketComm:
     def __init__(self, rank, size, addr="127.0.0.1", port=29650, timeout=120.0, token=None):
         self.rank, self.size = int(rank), int(size)
         self.transport = "tcp"
+        self.calibration = None          # Engine.comm_calibrate of the world communicator (attach_engine)
         self._engine = None
         self._peers = []       # hub: sockets of ranks 1..size-1, in rank order
         self._hub = None       # spoke: socket to rank 0
@@ -413,6 +415,10 @@ class SocketComm:
         if not errs:
             self._engine = engine
             self.transport = "rccl"
+            # first contact with the links: what a small collective of this communicator costs, measured (collective; ~20 + 20
+            # repetitions, milliseconds).  The figure stays on the engine handle and decides whether a shared evaluation distributes
+            # its Cholesky over the ranks as well (Engine.shard_decision); bench.py prints both.
+            self.calibration = engine.comm_calibrate() if hasattr(engine, "comm_calibrate") else None
             return True
         self.rccl_error = errs[0]
         if any(h for _, h in reports):
@@ -501,7 +507,11 @@ class SocketComm:
                 except Exception:  # noqa: BLE001
                     pass
             return None
-        return ShardGroup(engine, members.index(self.rank), len(members)) if mine else None
+        if not mine:
+            return None
+        group = ShardGroup(engine, members.index(self.rank), len(members))
+        group.calibration = engine.comm_calibrate() if hasattr(engine, "comm_calibrate") else None      # (collective over the members)
+        return group
 
     def allgather_rows(self, arr):
         """concatenate per-rank row blocks (ragged allowed: counts are exchanged first, blocks padded)"""

@@ -109,3 +109,26 @@ def test_committed_counters_are_only_reported_for_the_library_build_they_were_ta
     del pmc["csrc_hash"]
     (prof / "pmc.json").write_text(json.dumps(pmc))
     assert bench.pmc_traffic("sweep", 8192, lib_id) == (None, "profiles/pmc.json carries no csrc_hash (taken before the sources were stamped)")
+
+
+def test_the_planners_rule_for_distributing_the_cholesky_is_arithmetic_on_a_measurement():
+    """VERDICT r5 #4 / ADVICE r5: whether a shared evaluation's Cholesky is distributed over the rank group is decided from the
+    MEASURED cost of one collective of that group (mfgp_comm_calibrate) -- never without one.  The rule itself is host arithmetic
+    inside the library (plan.cpp dist_cholesky_pays), exported for exactly this check: saving = (1 - 1/G) N^3/3 flops at 60 TFLOP/s,
+    cost = (2 nblk - 1) collectives, taken at saving > 1.25 x cost."""
+    import ctypes
+    from multifidelity_datafusion_gps_amd import _lib
+    lib = _lib.load_library()
+    sv, ct = ctypes.c_double(), ctypes.c_double()
+
+    def pays(nblk, size, us):
+        return lib.mfgp_dist_cholesky_pays(nblk, size, us, ctypes.byref(sv), ctypes.byref(ct)), sv.value, ct.value
+
+    assert pays(128, 8, 0.0)[0] == 0                       # no measurement: replicated, whatever the size
+    assert pays(256, 8, -1.0)[0] == 0
+    yes, saving, cost = pays(128, 8, 20.0)                 # N = 16384 on 8 ranks, 20 us per collective
+    assert yes == 1 and abs(saving - 0.875 * 16384.0 ** 3 / 3 / 60e12 * 1e3) < 1e-9 and abs(cost - 255 * 20e-3) < 1e-12
+    assert pays(128, 8, 100.0)[0] == 0                     # ... at 100 us the 255 collectives cost more than they save
+    assert pays(64, 8, 20.0)[0] == 0 and pays(64, 8, 10.0)[0] == 1      # N = 8192: break-even between 10 and 20 us
+    assert pays(64, 1, 1.0)[0] == 0                        # a group of one has nothing to distribute
+    assert pays(256, 2, 100.0)[0] == 1 and pays(64, 2, 100.0)[0] == 0   # two ranks over a slow transport: only the large size

@@ -228,10 +228,13 @@ def _rccl_worker(rank, world, port, q, dist_everywhere=False):
                     f3, g3 = e.eval(th * 1.03, nz, 1e-8)
                     res["dist"]["lead"] = (f2, g2, f3, g3)
             if world == 2 and not dist_everywhere:
-                # ... and at the size where the planner turns it on BY ITSELF (128 block columns): no switch in the environment
+                # ... and WITHOUT a switch in the environment the planner decides from what a collective of this group was MEASURED to
+                # cost when the communicator was formed (comm.attach_engine -> Engine.comm_calibrate): on this rig --
+                # two ranks on one GPU over RCCL's socket transport -- a collective costs far more than the 2 nb - 1 of them save,
+                # so the north-star size is planned with the Cholesky REPLICATED, and the decision says why
                 del os.environ["MFGP_DIST_CHOL"]
-                rng = np.random.default_rng(16384)
-                Xb = rng.uniform(size=(16384, 4))
+                rng = np.random.default_rng(8192)
+                Xb = rng.uniform(size=(8192, 4))
                 Xba = np.hstack([Xb, cases.lf_4d(Xb)[:, None]])
                 Yb = cases.hf_4d(Xb)
                 e.set_data(Xba, Yb)
@@ -240,20 +243,28 @@ def _rccl_worker(rank, world, port, q, dist_everywhere=False):
                 f0, g0 = e.eval(th, nzb, 1e-8)
                 comm.barrier()
                 f1, g1 = e.eval_sharded(th, nzb, 1e-8)
-                res["dist"]["default_16384"] = (f0, g0, f1, g1)
-                # ... and at N = 32768, the size SURVEY 8(e) names for it (256 block columns, a 34 GB slab per rank, 4.3 GB of panels
-                # through 511 exchange steps)
-                rng = np.random.default_rng(32768)
-                Xc = rng.uniform(size=(32768, 4))
-                Yc = cases.hf_4d(Xc)
-                e.set_data(np.hstack([Xc, cases.lf_4d(Xc)[:, None]]), Yc)
-                e.set_kernel(cases.composite(4, 1))
-                nzc = 0.01 * Yc.var()
-                f0, g0 = e.eval(th, nzc, 1e-8)
-                comm.barrier()
-                f1, g1 = e.eval_sharded(th, nzc, 1e-8)
-                res["dist"]["default_32768"] = (f0, g0, f1, g1)
+                res["dist"]["measured_8192"] = (f0, g0, f1, g1)
+                res["dist"]["calibration"] = comm.calibration
+                res["dist"]["decision_8192"] = e.shard_decision()
+                # ... the distributed plan at N = 16384 (128 block columns, 255 exchange steps), switched on; skipped where the device
+                # has no room for two ranks' slabs
                 os.environ["MFGP_DIST_CHOL"] = "1"
+                free, _ = e.mem_info()
+                if free > 2 * (4 * 16384 ** 2 * 8) + (8 << 30):
+                    rng = np.random.default_rng(16384)
+                    Xb = rng.uniform(size=(16384, 4))
+                    Xba = np.hstack([Xb, cases.lf_4d(Xb)[:, None]])
+                    Yb = cases.hf_4d(Xb)
+                    e.set_data(Xba, Yb)
+                    e.set_kernel(cases.composite(4, 1))
+                    nzb = 0.01 * Yb.var()
+                    f0, g0 = e.eval(th, nzb, 1e-8)
+                    comm.barrier()
+                    f1, g1 = e.eval_sharded(th, nzb, 1e-8)
+                    res["dist"]["forced_16384"] = (f0, g0, f1, g1)
+                    res["dist"]["decision_16384"] = e.shard_decision()
+                else:
+                    res["dist"]["forced_16384"] = "skipped: %.1f GB free" % (free / 1e9)
             Xd = np.vstack([Xa[:700], Xa[300:600]])        # duplicated rows, no noise, no jitter: not positive definite
             e.set_data(Xd, np.concatenate([Y[:700], Y[300:600]]))
             e.set_kernel(cases.composite(4, 1))
@@ -345,9 +356,20 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world, dist_everywhere):
             if r == 0:
                 assert f2 == f3 and np.array_equal(g2, g3)
             if world == 2 and not dist_everywhere:
-                for key in ("default_16384", "default_32768"):
-                    f0, g0, f1, g1 = o["dist"][key]
-                    assert f1 == f0 and np.array_equal(g1, g0), key
+                f0, g0, f1, g1 = o["dist"]["measured_8192"]
+                assert f1 == f0 and np.array_equal(g1, g0)
+                cal, dec = o["dist"]["calibration"], o["dist"]["decision_8192"]
+                assert cal is not None and cal["broadcast_us"] > 0 and cal["allgather_us"] > 0 and cal["reps"] == 20, cal
+                # the rig's collectives go through RCCL's socket transport on loopback: far above what 127 of them may cost
+                assert dec["cholesky"] == "replicated" and not dec["forced_by_MFGP_DIST_CHOL"], dec
+                assert dec["collectives_on_chain"] == 127 and dec["measured_us_per_collective"] > 0, dec
+                assert dec["collective_cost_ms"] * 1.25 >= dec["projected_saving_ms"] and "collectives x" in dec["why"], dec
+                if r == 0:
+                    print("2-rank rig: calibration %s -> N = 8192: %s" % (cal, dec))
+                if not isinstance(o["dist"]["forced_16384"], str):
+                    f0, g0, f1, g1 = o["dist"]["forced_16384"]
+                    assert f1 == f0 and np.array_equal(g1, g0)
+                    assert o["dist"]["decision_16384"]["cholesky"] == "distributed" and o["dist"]["decision_16384"]["forced_by_MFGP_DIST_CHOL"]
             p_single, p_dist = o["dist"]["not_pd"]
             assert p_single > 0 and p_dist == p_single, o["dist"]["not_pd"]
 
@@ -475,7 +497,7 @@ def test_a_leader_that_fails_inside_a_shared_pass_ends_the_group_instead_of_hang
     assert [p.exitcode for p in procs] == [7, 7]
 
 
-def _unmatched_gather_worker(rank, port, q):
+def _unmatched_gather_worker(rank, port, q, mode="absent_peer"):
     import os
     import sys
     import time
@@ -487,12 +509,21 @@ def _unmatched_gather_worker(rank, port, q):
     e = Engine(0)
     comm.attach_engine(e, required=True, init_timeout=90)
     np.testing.assert_array_equal(e.allgather_host(np.full(3, float(rank))).reshape(-1), np.repeat([0.0, 1.0], 3))    # a matched gather first
+    rows = mode == "rccl_error_rows"
+    if rows:
+        rng = np.random.default_rng(5)
+        X = rng.uniform(size=(700, 3))
+        e.set_data(X, cases.hf_3d(X)); e.set_kernel(cases.single(cases.RBF, 3))
+        e.kbuild_owned_rows(np.array([1.0, 0.4]), 0.01, 1e-8, rank, 2)
     comm.barrier()
     res = {"rank": rank, "error": None}
     t0 = time.perf_counter()
-    if rank == 0:
+    gather = (lambda: e.allgather_rows()) if rows else (lambda: e.allgather_host(np.arange(5.0)))
+    if rank == 0 or mode != "absent_peer":
+        if rank == 0 and mode != "absent_peer":
+            e.dbg_fail_collective_after(1)                 # this rank's ncclAllGather "returns an error": the peer's is never matched
         try:
-            e.allgather_host(np.arange(5.0))               # rank 1 never issues its half
+            gather()                                       # absent_peer: rank 1 never issues its half
         except RuntimeError as ex:
             res["error"] = str(ex)
         res["seconds"] = time.perf_counter() - t0
@@ -512,16 +543,13 @@ def _unmatched_gather_worker(rank, port, q):
     os._exit(0)
 
 
-def test_a_gather_the_peer_never_joins_gives_up_after_the_deadline():
-    """Every wait for a stream that carries a collective is the poll with a deadline (comm_stream_wait), the small host gathers and
-    the row-block gather included: a peer that never issues its half costs MFGP_SHARD_TIMEOUT_S, then the communicator is aborted,
-    the call fails with a message that says so, and further collectives on the handle are refused."""
+def _run_gather_pair(mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_unmatched_gather_worker, args=(r, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_unmatched_gather_worker, args=(r, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     try:
@@ -531,7 +559,31 @@ def test_a_gather_the_peer_never_joins_gives_up_after_the_deadline():
             p.join(timeout=30)
             if p.is_alive():
                 p.kill()
+    return out
+
+
+def test_a_gather_the_peer_never_joins_gives_up_after_the_deadline():
+    """Every wait for a stream that carries a collective is the poll with a deadline (comm_stream_wait), the small host gathers and
+    the row-block gather included: a peer that never issues its half costs MFGP_SHARD_TIMEOUT_S, then the communicator is aborted,
+    the call fails with a message that says so, and further collectives on the handle are refused."""
+    out = _run_gather_pair("absent_peer")
     lone = out[0]
     assert lone["error"] is not None and "no progress for 5 s" in lone["error"], lone
     assert lone["aborted"] and 4.0 < lone["seconds"] < 30.0, lone
     assert lone["again"] != "issued" and "aborted" in lone["again"], lone
+
+
+@pytest.mark.parametrize("mode", ["rccl_error_host", "rccl_error_rows"])
+def test_a_gather_whose_rccl_call_fails_aborts_the_communicator_and_frees_the_peer(mode):
+    """an ncclAllGather that comes back with an error (injected: mfgp_dbg_fail_collective_after) used to return -4
+    with the communicator intact -- the peer then sat in its half of the collective until ITS deadline with nothing telling the
+    failed rank's later calls to stay away.  Now the failing rank aborts its communicator at once (state -1, further collectives
+    refused, what it had enqueued drained), and the peer is out of the collective within its deadline with the same state."""
+    out = _run_gather_pair(mode)
+    failed, peer = out[0], out[1]
+    assert failed["error"] is not None and "communicator was aborted" in failed["error"], failed
+    assert failed["aborted"] and failed["seconds"] < 3.0, failed
+    assert failed["again"] != "issued" and "aborted" in failed["again"], failed
+    assert peer["error"] is not None and "no progress for 5 s" in peer["error"], peer
+    assert peer["aborted"] and 4.0 < peer["seconds"] < 30.0, peer
+    assert peer["again"] != "issued" and "aborted" in peer["again"], peer
