@@ -11,8 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmfgp_hip.so")
-SOURCES = ["gemm_f64.hip", "leaf_f64.hip", "covariance.hip", "vecops.hip", "trimv_f64.hip", "comm_rccl.hip", "plan.cpp", "mfgp_api.hip"]
-HEADERS = ["mfgp_internal.h", "plan.h", os.path.join("..", "..", "include", "mfgp.h")]
+SOURCES = ["gemm_f64.hip", "leaf_f64.hip", "covariance.hip", "vecops.hip", "trimv_f64.hip", "comm_rccl.hip", "plan.cpp", "mfgp_api.hip", "api_batch.hip",
+           "api_sharded.hip", "api_predict.hip", "api_debug.hip"]
+HEADERS = ["mfgp_internal.h", "api_shared.h", "plan.h", os.path.join("..", "..", "include", "mfgp.h")]
 
 
 def source_hash():

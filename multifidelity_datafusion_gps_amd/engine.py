@@ -32,527 +32,12 @@ from scipy import optimize as _sciopt
 from . import _lib
 from . import lbfgsb as _lbfgsb
 from ._lib import KERN_ARD, KERN_MATERN32, KERN_MATERN52, KERN_RBF, NotPositiveDefinite
+from .kern import *  # noqa: F401,F403  (Param, RBF, Matern32, Matern52, Prod, Add, Gaussian, ...: this module stays the one import of the L3 code)
+from .kern import (_LIM_VAL, _LOG_LIM_VAL, _ParamSelection, _ParamVector, _Combination, _logexp_f, _logexp_finv,  # noqa: F401
+                   _logexp_gradfactor)
+from .lockstep import *  # noqa: F401,F403
+from .lockstep import (_BudgetExhausted, _EVAL_ERRORS, _F_FAILED, _G_CLIP_FAILED, _OptRun, _capped, _check_parameters)  # noqa: F401
 
-_LIM_VAL = 36.0
-_LOG_LIM_VAL = np.log(np.finfo(np.float64).max)  # paramz: _log_lim_val
-CONST_JITTER = 1e-8  # GPy adds this to the diagonal in exact inference [GPy-recall]
-
-
-# ------------------------------------------------------------------------------------------------
-# parameters
-# ------------------------------------------------------------------------------------------------
-def _logexp_f(x):
-    # paramz 0.9.5 transformations.Logexp.f: log1p(exp(clip(x, -log(DBL_MAX), 36))), x itself above 36; the trailing
-    # "+ epsilon" is commented out upstream, so nothing is added [GPy-recall]
-    x = np.asarray(x, dtype=np.float64)
-    return np.where(x > _LIM_VAL, x, np.log1p(np.exp(np.clip(x, -_LOG_LIM_VAL, _LIM_VAL))))
-
-
-def _logexp_finv(f):
-    f = np.asarray(f, dtype=np.float64)
-    return np.where(f > _LIM_VAL, f, np.log(np.expm1(np.minimum(f, _LIM_VAL))))
-
-
-def _logexp_gradfactor(f, df):
-    f = np.asarray(f, dtype=np.float64)
-    return df * np.where(f > _LIM_VAL, 1.0, -np.expm1(-f))
-
-
-class Param:
-    """One positive scalar hyper-parameter (variance, lengthscale, noise variance)."""
-
-    def __init__(self, name, value, owner=None):
-        self.name = name
-        self._value = float(value)
-        self.fixed = False
-        self.gradient = 0.0
-        self._observers = []
-        if owner is not None:
-            self._observers.append(owner)
-
-    @property
-    def value(self):
-        return self._value
-
-    @value.setter
-    def value(self, v):
-        v = float(np.asarray(v).reshape(-1)[0])
-        if v == self._value:
-            # assigning the value a parameter already has changes nothing the factorisation depends on:
-            # no notification, so no O(N^3) refactorisation (MultifidelityDataFusion.predict re-assigns
-            # likelihood.variance = 1e-6 on every call with add_noise=True, src/MFDataFusion.py:154-155;
-            # SURVEY 8(b) allows the lazy form)
-            return
-        self._value = v
-        for o in self._observers:
-            o._param_changed(self)
-
-    # GPy-style handles
-    def fix(self):
-        self.fixed = True
-        return self
-
-    def unfix(self):
-        self.fixed = False
-        return self
-
-    def constrain_positive(self):  # every parameter here already lives in the positive (Logexp) domain
-        return self
-
-    def __float__(self):
-        return self._value
-
-    def __getitem__(self, i):  # GPy params are arrays: kern.lengthscale[0]
-        return np.atleast_1d(self._value)[i]
-
-    def __repr__(self):
-        return "Param(%s=%.6g%s)" % (self.name, self._value, ", fixed" if self.fixed else "")
-
-
-class _ParamVector:
-    """the ARD lengthscales of one kernel seen as GPy sees them: one array-valued parameter"""
-
-    def __init__(self, params):
-        self.params = list(params)
-
-    @property
-    def values(self):
-        return np.array([p.value for p in self.params])
-
-    def __getitem__(self, i):
-        return self.values[i]
-
-    def __len__(self):
-        return len(self.params)
-
-    def __iter__(self):
-        return iter(self.values)
-
-    def fix(self):
-        for p in self.params:
-            p.fix()
-        return self
-
-    def unfix(self):
-        for p in self.params:
-            p.unfix()
-        return self
-
-    def constrain_positive(self):
-        return self
-
-    def __repr__(self):
-        return "ParamVector(lengthscale=%s)" % np.array2string(self.values, precision=6)
-
-
-# ------------------------------------------------------------------------------------------------
-# kernel specification objects
-# ------------------------------------------------------------------------------------------------
-class Kern:
-    """Base of the kernel *spec* objects: they hold parameters and column sets; the GPU evaluates them."""
-
-    def __mul__(self, other):
-        return Prod([self, other])
-
-    def __add__(self, other):
-        return Add([self, other])
-
-    def _terms(self):
-        """-> list of terms, each a list of Stationary factors (sum of products expansion)."""
-        raise NotImplementedError
-
-    def parameters(self):
-        """distinct Param objects in a stable order"""
-        out = []
-        for term in self._terms():
-            for f in term:
-                for p in [f.variance] + f.lengthscales:
-                    if not any(p is q for q in out):
-                        out.append(p)
-        return out
-
-    def engine_parts(self):
-        """flatten to the C-ABI description: parts [(type, c0, c1, term)], and per part (variance, [lengthscale Params]):
-        one lengthscale for an isotropic factor, one per active column for an ARD factor (include/mfgp.h layout)"""
-        parts, plist = [], []
-        for t, term in enumerate(self._terms()):
-            for f in term:
-                parts.append((f.ktype | (KERN_ARD if f.ARD else 0), f.col_begin, f.col_end, t))
-                plist.append((f.variance, list(f.lengthscales)))
-        if sum(1 + len(ls) for _, ls in plist) > _lib.MAX_THETA:
-            raise NotImplementedError("kernel has more than %d parameters" % _lib.MAX_THETA)
-        if len(parts) > _lib.MAX_PARTS:
-            raise NotImplementedError("kernel expands to %d factors; the engine supports %d" % (len(parts), _lib.MAX_PARTS))
-        return parts, plist
-
-    def _set_owner(self, owner):
-        # a kernel object is linked to one live model at a time (the reference re-uses self.kernel for
-        # every refit, src/MFDataFusion.py:69,96: hyper-parameters warm-start; the previous model lets go)
-        for p in self.parameters():
-            p._observers = [owner]
-
-    def Kdiag_value(self):
-        return sum(np.prod([f.variance.value for f in term]) for term in self._terms())
-
-
-class Stationary(Kern):
-    ktype = None
-    _default_name = "stationary"
-
-    def __init__(self, input_dim, variance=1.0, lengthscale=None, ARD=False, active_dims=None, name=None):
-        # ARD=True: one lengthscale per input dimension (GPy Stationary [GPy-recall]; the "ARD weights" of the reference's model
-        # docstrings, src/models/NARGP.py:13 -- the reference never passes the flag, its kern_class hooks are where a user would)
-        self.ARD = bool(ARD)
-        self.input_dim = int(input_dim)
-        if active_dims is None:
-            active_dims = np.arange(self.input_dim)
-        active_dims = np.asarray(active_dims, dtype=int).reshape(-1)
-        if len(active_dims) != self.input_dim:
-            raise ValueError("len(active_dims) must equal input_dim")
-        if len(active_dims) > 1 and np.any(np.diff(active_dims) != 1):
-            raise NotImplementedError("active_dims must be a contiguous, ascending column range")
-        self.active_dims = active_dims
-        self.col_begin = int(active_dims[0])
-        self.col_end = int(active_dims[-1]) + 1
-        self.name = name or self._default_name
-        self.variance = Param("variance", variance)
-        ls = np.ones(self.input_dim if self.ARD else 1) if lengthscale is None else np.asarray(lengthscale, dtype=np.float64).reshape(-1)
-        if self.ARD and ls.size == 1:
-            ls = np.full(self.input_dim, ls[0])
-        if ls.size != (self.input_dim if self.ARD else 1):
-            raise ValueError("lengthscale must have %d entries" % (self.input_dim if self.ARD else 1))
-        self.lengthscales = [Param("lengthscale" if not self.ARD else "lengthscale[%d]" % i, v) for i, v in enumerate(ls)]
-        # GPy spelling: kern.lengthscale (a 1-vector, or one entry per dimension with ARD)
-        self.lengthscale = self.lengthscales[0] if not self.ARD else _ParamVector(self.lengthscales)
-
-    def _terms(self):
-        return [[self]]
-
-    def to_dict(self):
-        return {"class": "GPy.kern." + type(self).__name__, "name": self.name, "input_dim": self.input_dim,
-                "active_dims": self.active_dims.tolist(), "variance": [self.variance.value],
-                "lengthscale": [p.value for p in self.lengthscales], "ARD": self.ARD}
-
-
-class RBF(Stationary):
-    ktype = KERN_RBF
-    _default_name = "rbf"
-
-
-class Matern32(Stationary):
-    ktype = KERN_MATERN32
-    _default_name = "Mat32"
-
-
-class Matern52(Stationary):
-    ktype = KERN_MATERN52
-    _default_name = "Mat52"
-
-
-class _Combination(Kern):
-    def __init__(self, parts, name):
-        self.parts = list(parts)
-        self.name = name
-
-    def to_dict(self):
-        return {"class": "GPy.kern." + type(self).__name__, "name": self.name,
-                "parts": {i: p.to_dict() for i, p in enumerate(self.parts)}}
-
-
-class Prod(_Combination):
-    def __init__(self, parts, name="mul"):
-        flat = []
-        for p in parts:
-            flat.extend(p.parts if isinstance(p, Prod) else [p])
-        super().__init__(flat, name)
-
-    def _terms(self):
-        terms = [[]]
-        for p in self.parts:  # distribute products over sums
-            terms = [a + b for a in terms for b in p._terms()]
-        return terms
-
-
-class Add(_Combination):
-    def __init__(self, parts, name="sum"):
-        flat = []
-        for p in parts:
-            flat.extend(p.parts if isinstance(p, Add) else [p])
-        super().__init__(flat, name)
-
-    def _terms(self):
-        out = []
-        for p in self.parts:
-            out.extend(p._terms())
-        return out
-
-
-# ------------------------------------------------------------------------------------------------
-# likelihood
-# ------------------------------------------------------------------------------------------------
-class Gaussian:
-    """Gaussian likelihood: one noise variance (GPy.likelihoods.Gaussian, name 'Gaussian_noise')."""
-
-    def __init__(self, variance=1.0, owner=None):
-        self._variance = Param("Gaussian_noise.variance", variance, owner)
-
-    @property
-    def variance(self):
-        return self._variance
-
-    @variance.setter
-    def variance(self, v):  # model.likelihood.variance = 1e-6 (src/MFDataFusion.py:155)
-        self._variance.value = v
-
-
-class _ParamSelection:
-    """result of model['regex']: forwards fix/unfix/constrain_positive to the matched parameters"""
-
-    def __init__(self, params):
-        self.params = params
-
-    def fix(self):
-        for p in self.params:
-            p.fix()
-        return self
-
-    def unfix(self):
-        for p in self.params:
-            p.unfix()
-        return self
-
-    def constrain_positive(self):
-        return self
-
-    @property
-    def values(self):
-        return np.array([p.value for p in self.params])
-
-    def __len__(self):
-        return len(self.params)
-
-
-# ------------------------------------------------------------------------------------------------
-# the model
-# ------------------------------------------------------------------------------------------------
-class _BudgetExhausted(Exception):
-    pass
-
-
-_F_FAILED = np.finfo(np.float64).max   # objective reported for a failed evaluation [GPy-recall: paramz Model._objective_grads
-_G_CLIP_FAILED = 1e10                  # returns DBL_MAX, not inf -- an infinite value turns L-BFGS-B's cubic line-search
-                                       # interpolation into NaN steps -- and the previous gradient clipped to +-1e10]
-
-
-# what a failed evaluation raises (paramz Model._objective_grads catches exactly these [GPy-recall]): thrown INTO the objective generator
-# by whoever drives it, so that the objective's own policy (jitter retries, DBL_MAX and the previous gradient) deals with them
-_EVAL_ERRORS = (np.linalg.LinAlgError, ZeroDivisionError, ValueError)
-
-
-def _check_parameters(theta, noise):
-    """a NaN / infinite / non-positive parameter (a line search gone astray) is a FAILED evaluation, handled like a failed
-    Cholesky (GPy: the NaNs end in jitchol's LinAlgError), not an argument error of the engine"""
-    if not (np.all(np.isfinite(theta)) and np.all(theta > 0.0) and np.isfinite(noise) and noise >= 0.0):
-        raise np.linalg.LinAlgError("hyper-parameters left the positive finite domain")
-
-
-def _capped(f_fp, cap, x0):
-    """-> (f, state): f evaluates f_fp at most `cap` times and then raises _BudgetExhausted; state holds the best point
-    seen.  scipy's maxfun is only checked between iterations, so a run may overshoot it by a line search; a benchmark
-    that compares code versions at a FIXED evaluation budget needs the count exact (cap = None: no cap)."""
-    state = {"n": 0, "f": np.inf, "x": np.array(x0, dtype=np.float64)}
-    if not cap:
-        return f_fp, state
-
-    def f(x):
-        if state["n"] >= cap:
-            raise _BudgetExhausted()
-        state["n"] += 1
-        val, g = f_fp(x)
-        if val < state["f"]:
-            state["f"], state["x"] = float(val), np.array(x, dtype=np.float64)
-        return val, g
-    return f, state
-
-
-class _OptRun:
-    def __init__(self, x_opt, f_opt, n_evals, status, background=False):
-        self.x_opt, self.f_opt, self.n_evals, self.status = x_opt, f_opt, n_evals, status
-        self.background = background     # a randomized restart that ran beside the model's own sequential runs
-
-
-class LockstepEvaluator:
-    """Independent L-BFGS-B runs on ONE engine handle, one evaluation per run and round: every run asks for its next objective
-    (+ gradient) through `evaluate` and blocks; when all runs still alive have asked, the round goes to the GPU as ONE batched
-    pass (`Engine.eval_batch`: the B matrix sets side by side in every launch of the factorisation sweep) and everybody gets
-    its own result back.  The restarts of the reference's recipe (optimize_restarts(6, ...), src/abstractMFGP.py:137) are such
-    runs: by paramz' semantics they start from fresh N(0,1) draws and never look at each other.  A batched evaluation is
-    bitwise the single one, so every run takes exactly the steps it takes alone -- only the wall clock changes: at N <= 4096 one
-    evaluation leaves most of the GPU idle (its serial Cholesky chain), B of them cost little more than one."""
-
-    def __init__(self, engine, n_slots):
-        import threading
-        self._eng = engine
-        self._cv = threading.Condition()
-        self._active = int(n_slots)
-        self._pending = {}
-        self._results = {}
-        self.rounds = 0
-        self.evals = 0
-        self.round_sizes = []
-        self.engine_s = 0.0       # wall seconds inside eval_batch (the rest of a fit's time is the hosts' L-BFGS-B steps and hand-offs)
-        self.oom_fallbacks = 0    # rounds whose batch did not fit the device and went request by request
-
-    def evaluate(self, slot, theta, noise, jitter):
-        """-> (nlml, grad) of THIS slot's point; raises NotPositiveDefinite for it alone"""
-        with self._cv:
-            self._pending[slot] = (np.array(theta, dtype=np.float64), float(noise), float(jitter))
-            if len(self._pending) >= self._active:
-                self._run_round()
-            while slot not in self._results:
-                self._cv.wait()
-            res = self._results.pop(slot)
-        if isinstance(res, BaseException):
-            raise res
-        return res
-
-    def retire(self, slot):
-        """this slot's run is over (it asks for nothing more): the others no longer wait for it"""
-        with self._cv:
-            self._active -= 1
-            if self._pending and len(self._pending) >= self._active:
-                self._run_round()
-
-    def _run_round(self):
-        # called with the lock held; every live run is blocked in evaluate(), so nothing else touches the engine
-        slots = sorted(self._pending)
-        reqs = [self._pending.pop(k) for k in slots]
-        cap = getattr(self._eng, "MAX_BATCH", 16)
-        t0 = time.perf_counter()
-        try:
-            for c0 in range(0, len(slots), cap):
-                part, sl = reqs[c0:c0 + cap], slots[c0:c0 + cap]
-                try:
-                    nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
-                                                               [r[2] for r in part], want_grad=True)
-                except _lib.EngineOutOfMemory:       # the sets do not fit: request by request on the handle's own slab (same results)
-                    self.oom_fallbacks += 1
-                    for r, k in zip(part, sl):
-                        try:
-                            f, g = self._eng.eval(r[0], r[1], r[2], want_grad=True)
-                            self._results[k] = (float(f), np.array(g))
-                        except NotPositiveDefinite as ex:
-                            self._results[k] = ex
-                    continue
-                for j, k in enumerate(sl):
-                    self._results[k] = (NotPositiveDefinite(int(status[j])) if status[j] != 0
-                                        else (float(nlml[j]), np.array(grads[j])))
-        except BaseException as ex:  # noqa: BLE001 - an engine error ends every run of the round, not just the caller's
-            for k in slots:
-                self._results.setdefault(k, ex)
-        self.engine_s += time.perf_counter() - t0
-        self.rounds += 1
-        self.evals += len(slots)
-        self.round_sizes.append(len(slots))
-        self._cv.notify_all()
-
-
-class LockstepLane:
-    """Several independent L-BFGS-B runs on ONE engine handle, advanced in lock step by ONE loop: every live run is a generator
-    (`GPRegression._run_gen` and the programs built from it) that yields the engine evaluation it needs next; a round collects the
-    requests of all live runs, evaluates them as one batched pass (`Engine.eval_batch`) and sends every run its own result.  No
-    thread per run, no hand-off per evaluation (the form of `LockstepEvaluator`, kept for a scipy whose L-BFGS-B core cannot be
-    driven by reverse communication): the host side of a round is the runs' own L-BFGS-B steps and nothing else.  Same statistics
-    as LockstepEvaluator (rounds, evals, round_sizes, engine_s)."""
-
-    def __init__(self, engine, max_batch=None):
-        self._eng = engine
-        self.rounds = 0
-        self.evals = 0
-        self.round_sizes = []
-        self.engine_s = 0.0
-        # memory policy (round 5): the most sets one pass may carry -- the engine's limit, or less where the caller sized it from the
-        # device's free memory (AbstractMFGP._ard_lockstep) -- halved whenever the engine answers EngineOutOfMemory; at 1 the lane
-        # evaluates request by request with eval(), which needs no batch slab.  A batched evaluation is bitwise the single one, so
-        # the runs take the same steps at every width.
-        cap = int(getattr(engine, "MAX_BATCH", 16))
-        self.max_batch = cap if not max_batch else max(1, min(cap, int(max_batch)))
-        self.oom_fallbacks = []       # (sets asked for, sets per pass from then on)
-
-    def _evaluate(self, part):
-        """-> the results of the requests `part` (at most max_batch of them): (nlml, grad) or the exception of that request"""
-        if len(part) > self.max_batch:                # (the lane narrowed since the caller cut its chunks)
-            out, c0 = [], 0
-            while c0 < len(part):
-                n = self.max_batch
-                out += self._evaluate(part[c0:c0 + n])
-                c0 += n
-            return out
-        while len(part) > 1 and self.max_batch > 1:
-            try:
-                nlml, grads, status = self._eng.eval_batch(np.array([r[0] for r in part]), [r[1] for r in part],
-                                                           [r[2] for r in part], want_grad=True)
-            except _lib.EngineOutOfMemory:
-                n_ = min(len(part), self.max_batch)
-                new = (n_ + 1) // 2 if n_ > 2 else 1          # 6 -> 3 -> 2 -> 1
-                self.oom_fallbacks.append((len(part), new))
-                self.max_batch = new
-                return self._evaluate(part)
-            except _EVAL_ERRORS as ex:               # the pass as a whole failed: a failed evaluation of every run in it
-                return [ex] * len(part)
-            return [NotPositiveDefinite(int(status[j])) if status[j] != 0 else (float(nlml[j]), np.array(grads[j]))
-                    for j in range(len(part))]
-        out = []
-        for theta, noise, jitter in part:            # one request, or a lane narrowed to one set: the handle's own evaluation
-            try:
-                if self.max_batch > 1 or not hasattr(self._eng, "eval"):
-                    nlml, grads, status = self._eng.eval_batch(np.array([theta]), [noise], [jitter], want_grad=True)
-                    out.append(NotPositiveDefinite(int(status[0])) if status[0] != 0 else (float(nlml[0]), np.array(grads[0])))
-                else:
-                    f, g = self._eng.eval(theta, noise, jitter, want_grad=True)
-                    out.append((float(f), np.array(g)))
-            except _lib.EngineOutOfMemory:           # (not even one set fits: single evaluations from here on)
-                self.oom_fallbacks.append((1, 1))
-                self.max_batch = 1
-                try:
-                    f, g = self._eng.eval(theta, noise, jitter, want_grad=True)
-                    out.append((float(f), np.array(g)))
-                except (NotPositiveDefinite,) + _EVAL_ERRORS as ex:
-                    out.append(ex)
-            except (NotPositiveDefinite,) + _EVAL_ERRORS as ex:
-                out.append(ex)
-        return out
-
-    def drive(self, programs):
-        """run the generators to their end; a program that raises ends every program of the lane (the exception propagates)"""
-        live = {}
-        for k, prog in enumerate(programs):
-            try:
-                live[k] = (prog, next(prog))
-            except StopIteration:
-                pass
-        while live:
-            slots = sorted(live)
-            results = {}
-            t0 = time.perf_counter()
-            c0 = 0
-            while c0 < len(slots):
-                sl = slots[c0:c0 + self.max_batch]
-                for k, res in zip(sl, self._evaluate([live[k][1] for k in sl])):
-                    results[k] = res
-                c0 += len(sl)
-            self.engine_s += time.perf_counter() - t0
-            self.rounds += 1
-            self.evals += len(slots)
-            self.round_sizes.append(len(slots))
-            for k in slots:
-                prog = live[k][0]
-                res = results[k]
-                try:
-                    req = prog.throw(res) if isinstance(res, BaseException) else prog.send(res)
-                    live[k] = (prog, req)
-                except StopIteration:
-                    del live[k]
 
 
 class GPRegression:

@@ -124,6 +124,7 @@ def test_probe_peaks(engine):
     import probes
     runs = [probes.basic(0) for _ in range(3)]
     tf, gbs = max(r[0] for r in runs), max(r[1] for r in runs)
-    print("fp64 MFMA probe: %.1f TFLOP/s, copy probe: %.0f GB/s" % (tf, gbs))
+    wr, rd = (max(v) for v in zip(*[probes.bandwidth(0) for _ in range(2)]))
+    print("fp64 MFMA probe: %.1f TFLOP/s, copy probe: %.0f GB/s, write-only %.0f GB/s, read-only %.0f GB/s" % (tf, gbs, wr, rd))
     assert tf > 30.0
-    assert gbs > 1000.0
+    assert gbs > 1000.0 and wr > 1000.0 and rd > 1000.0

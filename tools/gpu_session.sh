@@ -3,7 +3,7 @@
 #   usage (on the GPU box, through gpurun):  bash tools/gpu_session.sh <session> [outdir-name]
 # Every session writes under gpurun_out/<outdir-name>/ and chains its steps with && -- a step that fails or times out ends the session.
 set -o pipefail
-session=${1:?session name}; out=gpurun_out/${2:-r05_$session}; mkdir -p $out
+session=${1:?session name}; out=gpurun_out/${2:-r06_$session}; mkdir -p $out
 export MFGP_HW_QUEUES=${MFGP_HW_QUEUES:-2}
 last_json() { python - "$1" <<'EOF'
 import json, sys
@@ -100,7 +100,16 @@ profile)
     f=$(find $out/pmc_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmc_${c}_time_eval_8192.csv
     rm -rf $out/pmc_$c
   done
-  (cd $R && python3 tools/pmc_summary.py 8192 $out/pmc.json FETCH_SIZE=$out/pmc_FETCH_SIZE_time_eval_8192.csv WRITE_SIZE=$out/pmc_WRITE_SIZE_time_eval_8192.csv > $out/pmc_summary.log 2>&1; tail -40 $out/pmc_summary.log)
+  echo "== the adaptation loop's kernels (predict N* = 1 .. 64, rank-1 append at N = 8128): kernel stats, then the two traffic passes"
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/adapt_stats -- python3 $R/tools/predv_once.py 8192 > $out/adapt_stats.log 2>&1
+  f=$(find $out/adapt_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/adapt_kernel_stats.csv && head -16 $out/adapt_kernel_stats.csv
+  rm -rf $out/adapt_stats
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/apmc_$c -- python3 $R/tools/predv_once.py 8192 > $out/apmc_$c.log 2>&1
+    f=$(find $out/apmc_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmc_${c}_predv_once_8192.csv
+    rm -rf $out/apmc_$c
+  done
+  (cd $R && python3 tools/pmc_summary.py 8192 $out/pmc.json FETCH_SIZE=$out/pmc_FETCH_SIZE_time_eval_8192.csv WRITE_SIZE=$out/pmc_WRITE_SIZE_time_eval_8192.csv ADAPT_FETCH_SIZE=$out/pmc_FETCH_SIZE_predv_once_8192.csv ADAPT_WRITE_SIZE=$out/pmc_WRITE_SIZE_predv_once_8192.csv ADAPT_STATS=$out/adapt_kernel_stats.csv > $out/pmc_summary.log 2>&1; tail -60 $out/pmc_summary.log)
   echo "== PMC pass: matrix-pipe busy"
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmcA_eval_d -- python3 $R/tools/time_eval.py 8192 > $out/pmcA_eval.log 2>&1
   f=$(find $out/pmcA_eval_d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmcA_eval.csv
