@@ -92,14 +92,12 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     double* const var_dev = pinned ? h->dio + mfgp_handle::IO_IN + mfgp_handle::IO_OUT : h->dvec2;
     const int64_t Np = h->Np;
     int rc;
-    // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound products instead of a padded tile GEMM --
-    // up to 16 rows on the VALU behind one coalesced read of the triangle (trimv_f64.hip: panel, product, ONE finishing launch for
-    // mean and variance), 17 .. 64 rows the MFMA multi-vector form
+    // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound products instead of a padded tile GEMM, all in
+    // trimv_f64.hip -- up to 16 rows on the VALU behind one coalesced read of the triangle, 17 .. 64 rows on the matrix pipe with S
+    // streamed through LDS in the same coalesced shape; either way: panel, product (+ the means), ONE finishing launch
     static const bool skinny_on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
-    const bool few = skinny_on && rows <= 16;
-    const bool skinny = want_var && skinny_on && rows <= 64 && !few;
-    const int rows16 = rows <= 16 ? 1 : (rows <= 32 ? 2 : 4);
-    if (want_var && !skinny && !few && h->pl.predv_rows != rows_p) {
+    const bool few = skinny_on && rows <= 64;
+    if (want_var && !few && h->pl.predv_rows != rows_p) {
         // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
         plan_predv(h->pl, rows_p);
         rc = upload_tasks(h);
@@ -107,13 +105,20 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     }
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[6], s));
     if (few) {
-        const int R = rows <= 1 ? 1 : (rows <= 2 ? 2 : (rows <= 4 ? 4 : (rows <= 8 ? 8 : 16)));
         launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
         h->launches += 1;
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
         if (want_var) {
             h->kinv_valid = false;  // V overwrites the K^-1 storage
-            launch_predv_rows(s, R, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np, h->dalpha, mean_dev, (int)rows);
+            if (rows <= 16) {
+                const int R = rows <= 1 ? 1 : (rows <= 2 ? 2 : (rows <= 4 ? 4 : (rows <= 8 ? 8 : 16)));
+                launch_predv_rows(s, R, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np, h->dalpha, mean_dev, (int)rows);
+            } else {
+                // (the fragment-ordered copy of the panel: rows 64 .. 127 of the workspace matrix, which holds the 64-row panel)
+                launch_predv_mfma(s, (int)((rows + 15) / 16), h->buf[BUF_W], h->buf[BUF_W] + 64 * Np, h->buf[BUF_S], h->buf[BUF_A],
+                                  (int)Np, (int)Np, h->dalpha, mean_dev, (int)rows);
+                h->launches += 1;
+            }
             launch_predv_finish(s, (int)rows, h->buf[BUF_A], (int)Np, (int)Np, prior_variance(h), include_noise ? h->noise : 0.0,
                                 var_dev);
             h->launches += 2;
@@ -134,11 +139,9 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         if (!pinned) HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
         if (want_var) {
             h->kinv_valid = false;  // V overwrites the K^-1 storage
-            const int vrows = skinny ? 16 * rows16 : rows_p;
-            if (skinny) launch_predv_skinny(s, rows16, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np);
-            else if (run_step(h, h->pl.predv_step) != 0) return -1;
-            launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, vrows, (int)Np);
-            launch_finish_var(s, h->spec, h->dvec2, var_dev, vrows, include_noise ? h->noise : 0.0);
+            if (run_step(h, h->pl.predv_step) != 0) return -1;
+            launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, rows_p, (int)Np);
+            launch_finish_var(s, h->spec, h->dvec2, var_dev, rows_p, include_noise ? h->noise : 0.0);
             h->launches += 2;
             if (h->timing) HIPCHK(h, hipEventRecord(h->ev[8], s));
             if (!pinned) HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -583,91 +583,4 @@ int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, cons
     return 0;
 }
 
-// ---- skinny predictive-variance product (N* <= 64 rows: the DIRECT callback / acquisition case) -----
-// V[i][j] = sum_{k <= j} W[i][k] X[j][k]  for i < 16*RT (rows of the K(X*,X) panel W) and all j < Np, X = L^-1 read from
-// the mirrored storage S.  The tile GEMM pads N* to 128 rows and is MFMA-bound on rows that do not exist; this one is a
-// 16*RT-row multi-vector triangular product bound by ONE read of the 4 Np^2-byte triangle of S.  One workgroup = 16
-// columns j; its 4 waves interleave over the 16-deep k chunks, each lane fetching 32 contiguous bytes of its row of S
-// and of W per chunk, which feed 4 MFMA 16x16x4 steps (the k order inside a chunk is permuted identically for both
-// operands); the wave partials are reduced through LDS in fixed order (deterministic).
-template <int RT>
-__global__ __launch_bounds__(256) void mfgp_predv_skinny_f64(const double* __restrict__ W, const double* __restrict__ S,
-                                                             double* __restrict__ V, int ld, int nblk16) {
-    __shared__ double red[3][RT][64][4];
-    const int b = nblk16 - 1 - (int)blockIdx.x;  // longest k range first
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int j = b * 16 + r;
-    const double* Srow = S + (int64_t)j * ld + 4 * q;
-    const double* Wrow = W + (int64_t)r * ld + 4 * q;
-    d4_t acc[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    auto chunk = [&](int k, d2_t b0, d2_t b1) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const d2_t a0 = *reinterpret_cast<const d2_t*>(Wrow + (int64_t)t * 16 * ld + k);
-            const d2_t a1 = *reinterpret_cast<const d2_t*>(Wrow + (int64_t)t * 16 * ld + k + 2);
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], acc[t], 0, 0, 0);
-        }
-    };
-    const int nit = b > wave ? (b - wave + 3) >> 2 : 0;  // chunks wave, wave + 4, ... < b
-    int it = 0;
-    for (; it + 4 <= nit; it += 4) {  // four chunks of S in flight per lane before the first MFMA consumes one
-        const int k0 = (wave + 4 * it) * 16;
-        d2_t sb[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            sb[2 * u] = *reinterpret_cast<const d2_t*>(Srow + k0 + 64 * u);
-            sb[2 * u + 1] = *reinterpret_cast<const d2_t*>(Srow + k0 + 64 * u + 2);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) chunk(k0 + 64 * u, sb[2 * u], sb[2 * u + 1]);
-    }
-    for (; it < nit; ++it) {
-        const int k = (wave + 4 * it) * 16;
-        chunk(k, *reinterpret_cast<const d2_t*>(Srow + k), *reinterpret_cast<const d2_t*>(Srow + k + 2));
-    }
-    if ((b & 3) == wave) {  // diagonal chunk: the mirrored storage holds X^T above the diagonal -> keep k <= j only
-        const int k = b * 16, kk = k + 4 * q;
-        d2_t b0 = *reinterpret_cast<const d2_t*>(Srow + k);
-        d2_t b1 = *reinterpret_cast<const d2_t*>(Srow + k + 2);
-        if (kk + 0 > j) b0[0] = 0.0;
-        if (kk + 1 > j) b0[1] = 0.0;
-        if (kk + 2 > j) b1[0] = 0.0;
-        if (kk + 3 > j) b1[1] = 0.0;
-        chunk(k, b0, b1);
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) red[wave - 1][t][lane][e] = acc[t][e];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double v = ((acc[t][e] + red[0][t][lane][e]) + red[1][t][lane][e]) + red[2][t][lane][e];
-                // C/D layout of v_mfma_f64_16x16x4 (as in gemm_nt_tile): D[row = q + 4*e][col = r]
-                V[(int64_t)(t * 16 + q + 4 * e) * ld + b * 16 + r] = v;
-            }
-    }
-}
-
-void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const double* S, double* V, int ld, int Np) {
-    const int nb = Np / 16;
-    if (rows16 <= 1)
-        hipLaunchKernelGGL(mfgp_predv_skinny_f64<1>, dim3(nb), dim3(256), 0, s, W, S, V, ld, nb);
-    else if (rows16 == 2)
-        hipLaunchKernelGGL(mfgp_predv_skinny_f64<2>, dim3(nb), dim3(256), 0, s, W, S, V, ld, nb);
-    else
-        hipLaunchKernelGGL(mfgp_predv_skinny_f64<4>, dim3(nb), dim3(256), 0, s, W, S, V, ld, nb);
-}
-
 }  // namespace mfgp

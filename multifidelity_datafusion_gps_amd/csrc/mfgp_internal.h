@@ -46,15 +46,18 @@ int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, cons
                 const double* B, double* C, double* C2, int ld, int role = 0, int nbatch = 1, long long bstride = 0,
                 const int* flag = nullptr, int epoch = 0);
 size_t gemm_lds_bytes(int tile);
-// skinny variance product for <= 64 test rows: V[0 .. 16*rows16) = W X^T (X = L^-1 from the mirrored S); rows16 in {1, 2, 4}
-void launch_predv_skinny(hipStream_t s, int rows16, const double* W, const double* S, double* V, int ld, int Np);
 
 // <= 16 test rows (trimv_f64.hip): V[i][j] = sum_{k <= j} W[i][k] X[j][k] on the VALU behind ONE coalesced read of the triangle;
 // R = the row count rounded up to 1, 2, 4, 8 or 16 (the panel W holds at least that many rows); the same launch forms the means
 // W[i] . alpha of the `rows` real test rows
 void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, double* V, int ld, int Np, const double* alpha,
                        double* mean, int rows);
-//   and its finish, one workgroup per test row: var[i] = max(kss - |V[i]|^2, 1e-15) + add
+// 17 .. 64 test rows (trimv_f64.hip): the same product on v_mfma_f64_16x16x4, RT = ceil(rows / 16) row tiles, S streamed through LDS by
+// LDS-DMA in the coalesced shape; the same launch forms the means of the `rows` real test rows
+//   Wt: 64 Np doubles of scratch for the panel in MFMA fragment order (written by the launch)
+void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const double* S, double* V, int ld, int Np,
+                       const double* alpha, double* mean, int rows);
+//   and their finish, one workgroup per test row: var[i] = max(kss - |V[i]|^2, 1e-15) + add
 void launch_predv_finish(hipStream_t s, int rows, const double* V, int ld, int Np, double kss, double add, double* var);
 
 // leaf: Cholesky + inverse of the 128x128 diagonal block `blk` of A (ld), in LDS.

@@ -206,6 +206,17 @@ __global__ __launch_bounds__(256) void mfgp_alpha_finish_f64(const double* __res
     trimv_wave<1, JR, U>(S, ld, z, 0, alpha, 0, Np, Np, 1, wv, lane);
 }
 
+// The means of a small predict ride in the variance product's launch: W[i] . alpha for the `rows` real test rows, one row per
+// group (a row's sum is formed in the same order as in launch_rowdot's launches, whatever their shape -- the mean of a test row
+// does not depend on the size of the batch it travels in).  They take the FIRST workgroups of the grid, two rows per wave: as the
+// last workgroup of the launch -- rounds 6's first form -- one CU read all the rows alone behind everybody else (64 rows x 64 KiB
+// at N = 8192: a 0.03 - 0.08 ms tail, the whole difference between the 16- and the 8-row product).
+static inline int mean_blocks(int rows) { return ((rows + 1) / 2 + 3) / 4; }
+__device__ __forceinline__ void predv_mean_block(const double* __restrict__ W, int ld, const double* __restrict__ alpha,
+                                                 double* __restrict__ mean, int rows, int Np, int block, int wave, int lane) {
+    trimv_wave<1, 1, 8>(W, ld, alpha, 0, mean, 0, rows, Np, 2, block * 4 + wave, lane);
+}
+
 static inline int trimv_blocks(int nrows, int JR) {
     const int G = (nrows + JR - 1) / JR;
     return ((G + 1) / 2 + 3) / 4;
@@ -258,12 +269,12 @@ __global__ __launch_bounds__(256) void mfgp_predv_rows_f64(const double* __restr
                                                            double* __restrict__ V, int Np, const double* __restrict__ alpha,
                                                            double* __restrict__ mean, int rows) {
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == gridDim.x - 1) {
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        trimv_wave<1, 2, 4>(W, ld, alpha, 0, mean, 0, rows, Np, 2, wv, lane);   // rows <= 16: at most 8 groups = 4 waves
+    const int nmean = ((rows + 1) / 2 + 3) / 4;
+    if ((int)blockIdx.x < nmean) {
+        predv_mean_block(W, ld, alpha, mean, rows, Np, blockIdx.x, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
         return;
     }
-    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - nmean) * 4 + (threadIdx.x >> 6));
     trimv_wave<R, JR, U>(S, ld, W, ld, V, ld, Np, Np, 0, wv, lane);
 }
 
@@ -293,12 +304,13 @@ __global__ __launch_bounds__(64 * NW) void mfgp_predv_rows_lds_f64(const double*
     __shared__ __attribute__((aligned(1024))) d2_t wl[NS][R][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blockIdx.x == gridDim.x - 1) {
-        if (wave < 4) trimv_wave<1, 2, 4>(W, ld, alpha, 0, mean, 0, rows, Np, 2, wave, lane);
+    const int nmean = ((rows + 1) / 2 + 3) / 4;
+    if ((int)blockIdx.x < nmean) {
+        if (wave < 4) predv_mean_block(W, ld, alpha, mean, rows, Np, blockIdx.x, wave, lane);
         return;
     }
     const int NB = Np / BR;
-    const int bA = blockIdx.x, bB = NB - 1 - bA;                       // (NB is even: Np is a multiple of 128, 2 BR divides 128)
+    const int bA = (int)blockIdx.x - nmean, bB = NB - 1 - bA;                       // (NB is even: Np is a multiple of 128, 2 BR divides 128)
     const int nA = ((bA * BR + BR - 1) >> 7) + 1, nB = ((bB * BR + BR - 1) >> 7) + 1;
     const int T = nA + nB;
     auto row0 = [&](int t) { return (t < nA ? bA : bB) * BR + wave * JR; };
@@ -378,13 +390,181 @@ __global__ __launch_bounds__(64 * NW) void mfgp_predv_rows_lds_f64(const double*
     }
 }
 
+// 17 .. 64 test rows: the products move to the matrix pipe (v_mfma_f64_16x16x4: 16 test rows x 16 rows of S x 4 k per instruction),
+// which wants a lane to hold ONE k of 16 DIFFERENT rows of S -- the opposite of the coalesced read.  Rounds 2-5 fetched the
+// fragments in that shape straight from memory (32 B per lane: a wave-instruction = 16 rows x 128 B, 0.30 of the HBM peak: VERDICT
+// r5 weak #2); here S goes through LDS by LDS-DMA in the coalesced shape (global_load_lds_dwordx4: one instruction = 2 rows x 512
+// contiguous bytes, no staging registers) and the fragments come out of LDS.  The 16-byte chunks of a row sit XOR-swizzled by
+// the row (on the per-lane SOURCE address of the DMA and on the fragment read alike), so the 16 lanes that read one k-slot of 16
+// rows hit 16 different bank groups.  One workgroup = one block of 16 rows of S; its four waves take the block's 64-column stages
+// in turn (wave w: stages w, w + 4, ...), each with its own 2 x 8 KiB of LDS and no barrier inside the loop, and their partial
+// tiles meet through LDS at the end in a fixed order (deterministic).  Per stage and wave: the W fragments of the stage
+// (RT x 16 doubles per lane, L2 hits) are requested, ONE wait retires them together with the stage's own DMA, the DMA of the wave's
+// NEXT stage is issued and stays in flight behind the stage's 16 RT MFMAs.  Consecutive workgroups alternate between the short
+// and the long end of the triangle (block 0, NB-1, 1, NB-2, ...), so that the workgroups resident together carry like sums of
+// work; masks (k <= j) touch the last stage of a block only.
+// The A operand of those MFMAs -- lane (r, q) supplies W[16 i + r][k + q] -- read from the row-major panel is 16 rows x 128 B per
+// wave-instruction with the rows a whole ld apart (64 KiB at N = 8192: one L2 channel), the shape that held rounds 2-5's kernel at
+// 0.3 of the HBM peak.  The panel is therefore re-laid once per predict (<= 4 MB, out of L2) into fragment order:
+//     Wt[((i * Np / 4 + k / 4) * 16 + r) * 4 + k % 4] = W[16 i + r][k]
+// so that the 64 lanes of a fragment load read 2 KiB contiguous.
+__global__ __launch_bounds__(256) void mfgp_panel_fragments_f64(const double* __restrict__ W, int ld, double* __restrict__ Wt, int Np,
+                                                                int RT) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one 32-byte piece: (tile i, k / 4, row r), r fastest
+    const int64_t per_tile = (int64_t)(Np >> 2) * 16;
+    if (idx >= per_tile * RT) return;
+    const int i = (int)(idx / per_tile);
+    const int64_t rem = idx - (int64_t)i * per_tile;
+    const int kq = (int)(rem >> 4), r = (int)(rem & 15);
+    const double* src = W + (int64_t)(16 * i + r) * ld + 4 * kq;
+    const d2_t v0 = *reinterpret_cast<const d2_t*>(src), v1 = *reinterpret_cast<const d2_t*>(src + 2);
+    double* dst = Wt + idx * 4;
+    *reinterpret_cast<d2_t*>(dst) = v0;
+    *reinterpret_cast<d2_t*>(dst + 2) = v1;
+}
+
+template <int RT, int KS>
+__global__ __launch_bounds__(256, 2) void mfgp_predv_mfma_f64(const double* __restrict__ W, const double* __restrict__ Wt, const double* __restrict__ S,
+                                                              double* __restrict__ V, int ld, int Np, const double* __restrict__ alpha,
+                                                              double* __restrict__ mean, int rows) {
+    constexpr int STAGE_B = 16 * KS * 8;         // bytes per stage: 16 rows x KS columns
+    constexpr int NC = KS / 16;                  // 16-column chunks per stage
+    constexpr int RPI = 1024 / (KS * 8);         // rows per DMA instruction (1 KiB): 2 x 512 B (KS = 64) or 4 x 256 B (KS = 32)
+    constexpr int SPR = KS / 2;                  // 16-byte slots per row
+    __shared__ __attribute__((aligned(1024))) char lds[4 * 2 * STAGE_B < 24576 ? 24576 : 4 * 2 * STAGE_B];   // (>= the reduction's 3 RT x 2 KiB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmean = ((rows + 1) / 2 + 3) / 4;
+    if ((int)blockIdx.x < nmean) {               // the means of the real test rows: the first workgroups of the launch
+        predv_mean_block(W, ld, alpha, mean, rows, Np, blockIdx.x, wave, lane);
+        return;
+    }
+    const int g = (Np >> 4) - 1 - ((int)blockIdx.x - nmean);   // longest block first (measured against two interleaved orders: r06 lab notes)
+    const int j0 = g << 4;
+    const int n = (j0 + 15) / KS + 1;            // stages of the block: columns 0 .. j0 + 15
+    char* const my = lds + wave * (2 * STAGE_B);
+    const int r = lane & 15, q = lane >> 4;
+    // DMA: instruction u of a stage covers rows RPI u .. of the block; lane l lands at byte u * 1024 + 16 l = (row RPI u + l / SPR,
+    // slot l % SPR) and therefore fetches chunk slot ^ (row & (SPR - 1) & 15) of that row
+    const int d_row = lane / SPR, d_slot = lane % SPR;
+    auto dma = [&](int t, int st) {
+#pragma unroll
+        for (int u = 0; u < 16 / RPI; ++u) {
+            const int row = RPI * u + d_row;
+            const double* src = S + (int64_t)(j0 + row) * ld + t * KS + 2 * (d_slot ^ (row & 15 & (SPR - 1)));
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(my + st * STAGE_B + u * 1024), 16, 0, 0);
+        }
+    };
+    // W fragments of a stage (lane (r, q): 4 consecutive k per 16-column chunk, the same k order as the S fragment), in fragment order
+    auto load_a = [&](int t, d2_t (&a)[RT][NC][2]) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double* wp = Wt + (((int64_t)i * (Np >> 2) + ((t * KS + 16 * c) >> 2) + q) * 16 + r) * 4;   // 2 KiB per wave-instruction pair
+                a[i][c][0] = *reinterpret_cast<const d2_t*>(wp);
+                a[i][c][1] = *reinterpret_cast<const d2_t*>(wp + 2);
+            }
+    };
+    // (two accumulators per row tile where there are only two tiles: four independent MFMA chains per wave either way -- a chain
+    // of dependent v_mfma_f64_16x16x4 issues one instruction per result latency)
+    constexpr int NA = RT <= 2 ? 2 : 1;
+    d4_t acc[RT][NA];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int x = 0; x < NA; ++x) acc[t][x] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    auto compute = [&](int t, int st, const d2_t (&a)[RT][NC][2]) {
+        const int kb = t * KS;
+        const bool diag = kb + KS > j0;          // the stage reaches past the block's first diagonal entry: keep k <= j
+        const char* const base = my + st * STAGE_B + r * (KS * 8);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int s0 = 8 * c + 2 * q, sw = r & (SPR - 1);
+            d2_t b0 = *reinterpret_cast<const d2_t*>(base + ((s0 ^ sw) << 4));
+            d2_t b1 = *reinterpret_cast<const d2_t*>(base + (((s0 + 1) ^ sw) << 4));
+            if (diag) {
+                const int kk = kb + 16 * c + 4 * q, j = j0 + r;
+                if (kk + 0 > j) b0[0] = 0.0;
+                if (kk + 1 > j) b0[1] = 0.0;
+                if (kk + 2 > j) b1[0] = 0.0;
+                if (kk + 3 > j) b1[1] = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][0][0], b0[0], acc[i][0], 0, 0, 0);
+                acc[i][NA - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][0][1], b0[1], acc[i][NA - 1], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][1][0], b1[0], acc[i][0], 0, 0, 0);
+                acc[i][NA - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][1][1], b1[1], acc[i][NA - 1], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this stage's fragment reads are done before a DMA may overwrite it
+    };
+    // One step: ONE wait retires everything in flight -- the stage's DMA and its W fragments, both requested a whole step ago --
+    // then the NEXT stage of this wave is requested (fragments into the other register set, DMA into the other buffer) and stays in
+    // flight behind this stage's RT KS / 4 MFMAs.  The wait is the builtin, not inline assembly: the compiler's own wait-count
+    // bookkeeping then knows the fragments have landed -- with an LDS-DMA pending it otherwise waits for vmcnt(0) at their first use,
+    // i.e. for the prefetch.
+    d2_t a0[RT][NC][2], a1[RT][NC][2];
+    if (wave < n) { load_a(wave, a0); dma(wave, 0); }
+    for (int t = wave; t < n; t += 8) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) expcnt(7) lgkmcnt(15)
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 4 < n) { load_a(t + 4, a1); dma(t + 4, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t, 0, a0);
+        if (t + 4 >= n) break;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 8 < n) { load_a(t + 8, a0); dma(t + 8, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t + 4, 1, a1);
+    }
+    // the four partial tiles: waves 1..3 through LDS (every wave's DMAs have been retired by its last wait), summed by wave 0 in a
+    // fixed order;  D[row = q + 4 e][col = r] of v_mfma_f64_16x16x4
+    __syncthreads();
+    double* const red = reinterpret_cast<double*>(lds);
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(((wave - 1) * RT + i) * 4 + e) * 64 + lane] = NA == 2 ? acc[i][0][e] + acc[i][NA - 1][e] : acc[i][0][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double own = NA == 2 ? acc[i][0][e] + acc[i][NA - 1][e] : acc[i][0][e];
+                const double v = ((own + red[((0 * RT + i) * 4 + e) * 64 + lane]) + red[((1 * RT + i) * 4 + e) * 64 + lane]) +
+                                 red[((2 * RT + i) * 4 + e) * 64 + lane];
+                V[(int64_t)(i * 16 + q + 4 * e) * ld + j0 + r] = v;
+            }
+    }
+}
+
+void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const double* S, double* V, int ld, int Np,
+                       const double* alpha, double* mean, int rows) {
+    RT = RT <= 2 ? 2 : (RT == 3 ? 3 : 4);
+    const int64_t pieces = (int64_t)(Np >> 2) * 16 * RT;
+    hipLaunchKernelGGL(mfgp_panel_fragments_f64, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, W, ld, Wt, Np, RT);
+    const dim3 grid(Np / 16 + mean_blocks(rows)), blk(256);
+    static const int ks = getenv("MFGP_MFMA_KS") ? atoi(getenv("MFGP_MFMA_KS")) : 64;
+#define PREDV_MFMA(rt, k) hipLaunchKernelGGL((mfgp_predv_mfma_f64<rt, k>), grid, blk, 0, s, W, Wt, S, V, ld, Np, alpha, mean, rows)
+    if (RT == 2) { if (ks == 64) PREDV_MFMA(2, 64); else PREDV_MFMA(2, 32); }
+    else if (RT == 3) PREDV_MFMA(3, 32);
+    else PREDV_MFMA(4, 32);
+#undef PREDV_MFMA
+}
+
 void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, double* V, int ld, int Np, const double* alpha,
                        double* mean, int rows) {
     const dim3 blk(256);
     int JR1, U1;
     trimv1_shape(JR1, U1);
 #define TRIMVR(r, jr, u)                                                                                                  \
-    hipLaunchKernelGGL((mfgp_predv_rows_f64<r, jr, u>), dim3(trimv_blocks(Np, jr) + 1), blk, 0, s, S, ld, W, V, Np, alpha, mean, rows)
+    hipLaunchKernelGGL((mfgp_predv_rows_f64<r, jr, u>), dim3(trimv_blocks(Np, jr) + mean_blocks(rows)), blk, 0, s, S, ld, W, V, Np, alpha, mean, rows)
     if (R <= 1) {
         if (JR1 == 1 && U1 == 8) TRIMVR(1, 1, 8);
         else if (JR1 == 2 && U1 == 4) TRIMVR(1, 2, 4);
@@ -394,8 +574,8 @@ void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, d
     else {
         static const int lds = getenv("MFGP_TRIMV_LDS") ? atoi(getenv("MFGP_TRIMV_LDS")) : 1;
 #define PREDV_LDS(r, jr, nw, d)                                                                                           \
-    hipLaunchKernelGGL((mfgp_predv_rows_lds_f64<r, jr, nw, d>), dim3(Np / (nw * jr) / 2 + 1), dim3(64 * nw), 0, s, S, ld, W, V, Np, alpha, \
-                       mean, rows)
+    hipLaunchKernelGGL((mfgp_predv_rows_lds_f64<r, jr, nw, d>), dim3(Np / (nw * jr) / 2 + mean_blocks(rows)), dim3(64 * nw), 0, s, S, ld, W, V, \
+                       Np, alpha, mean, rows)
         if (lds == 0) { if (R <= 8) TRIMVR(8, 4, 2); else TRIMVR(16, 4, 1); }
         else if (R <= 8) PREDV_LDS(8, 4, 4, 2);
         else PREDV_LDS(16, 2, 4, 3);

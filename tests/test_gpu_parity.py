@@ -589,7 +589,7 @@ def test_skinny_variance_path_for_small_batches(engine, N):
     st = orc.inference(parts, theta, noise, Xa, Y, want_grad=True)
     Xs_all = rng.uniform(size=(80, 5))
     m_big, v_big = engine.predict(Xs_all)                 # 80 rows: tile-GEMM path
-    for ns in (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33, 64):
+    for ns in (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33, 48, 49, 64):
         m, v = engine.predict(Xs_all[:ns])
         mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xs_all[:ns])
         np.testing.assert_allclose(m, mu, rtol=0, atol=1e-9 * max(1.0, np.abs(Y).max()))
