@@ -466,14 +466,15 @@ __global__ __launch_bounds__(256, 2) void mfgp_predv_mfma_f64(const double* __re
                 a[i][c][1] = *reinterpret_cast<const d2_t*>(wp + 2);
             }
     };
-    // (two accumulators per row tile where there are only two tiles: four independent MFMA chains per wave either way -- a chain
-    // of dependent v_mfma_f64_16x16x4 issues one instruction per result latency)
-    constexpr int NA = RT <= 2 ? 2 : 1;
-    d4_t acc[RT][NA];
+    // acc[tile][4]: the four result registers of one 16 x 16 tile, D[row = q + 4 e][col = r].  (The v_mfma_f64_4x4x4_4b form the
+    // tile GEMM uses -- four rotations of the A fragment, here by DPP row rotations of the loaded registers -- was measured against
+    // this one in round 6 and lost, 0.092 / 0.160 ms against 0.085 / 0.130 at 32 / 64 test rows: the rotations' v_mov_dpp compete
+    // with the MFMAs for the SIMD's issue slot.  The 16x16x4 kernel runs the matrix pipe 0.54 / 0.71 busy: profiles/r06_adapt_sq.txt.)
+    double acc[RT][4];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int x = 0; x < NA; ++x) acc[t][x] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int x = 0; x < 4; ++x) acc[t][x] = 0.0;
     auto compute = [&](int t, int st, const d2_t (&a)[RT][NC][2]) {
         const int kb = t * KS;
         const bool diag = kb + KS > j0;          // the stage reaches past the block's first diagonal entry: keep k <= j
@@ -490,12 +491,15 @@ __global__ __launch_bounds__(256, 2) void mfgp_predv_mfma_f64(const double* __re
                 if (kk + 2 > j) b1[0] = 0.0;
                 if (kk + 3 > j) b1[1] = 0.0;
             }
+            const double bv[4] = {b0[0], b0[1], b1[0], b1[1]};
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][0][0], b0[0], acc[i][0], 0, 0, 0);
-                acc[i][NA - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][0][1], b0[1], acc[i][NA - 1], 0, 0, 0);
-                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][1][0], b1[0], acc[i][0], 0, 0, 0);
-                acc[i][NA - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][1][1], b1[1], acc[i][NA - 1], 0, 0, 0);
+                d4_t d = (d4_t){acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][0][0], bv[0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][0][1], bv[1], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][1][0], bv[2], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][1][1], bv[3], d, 0, 0, 0);
+                acc[i][0] = d[0]; acc[i][1] = d[1]; acc[i][2] = d[2]; acc[i][3] = d[3];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this stage's fragment reads are done before a DMA may overwrite it
@@ -521,14 +525,14 @@ __global__ __launch_bounds__(256, 2) void mfgp_predv_mfma_f64(const double* __re
         compute(t + 4, 1, a1);
     }
     // the four partial tiles: waves 1..3 through LDS (every wave's DMAs have been retired by its last wait), summed by wave 0 in a
-    // fixed order;  D[row = q + 4 e][col = r] of v_mfma_f64_16x16x4
+    // fixed order
     __syncthreads();
     double* const red = reinterpret_cast<double*>(lds);
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[(((wave - 1) * RT + i) * 4 + e) * 64 + lane] = NA == 2 ? acc[i][0][e] + acc[i][NA - 1][e] : acc[i][0][e];
+            for (int e = 0; e < 4; ++e) red[(((wave - 1) * RT + i) * 4 + e) * 64 + lane] = acc[i][e];
     }
     __syncthreads();
     if (wave == 0) {
@@ -536,8 +540,7 @@ __global__ __launch_bounds__(256, 2) void mfgp_predv_mfma_f64(const double* __re
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const double own = NA == 2 ? acc[i][0][e] + acc[i][NA - 1][e] : acc[i][0][e];
-                const double v = ((own + red[((0 * RT + i) * 4 + e) * 64 + lane]) + red[((1 * RT + i) * 4 + e) * 64 + lane]) +
+                const double v = ((acc[i][e] + red[((0 * RT + i) * 4 + e) * 64 + lane]) + red[((1 * RT + i) * 4 + e) * 64 + lane]) +
                                  red[((2 * RT + i) * 4 + e) * 64 + lane];
                 V[(int64_t)(i * 16 + q + 4 * e) * ld + j0 + r] = v;
             }
