@@ -93,7 +93,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     const int64_t Np = h->Np;
     int rc;
     // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound products instead of a padded tile GEMM, all in
-    // trimv_f64.hip -- up to 16 rows on the VALU behind one coalesced read of the triangle, 17 .. 64 rows on the matrix pipe with S
+    // trimv_f64.hip -- up to 8 rows on the VALU behind one coalesced read of the triangle, 9 .. 64 rows on the matrix pipe with S
     // streamed through LDS in the same coalesced shape; either way: panel, product (+ the means), ONE finishing launch
     static const bool skinny_on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
     const bool few = skinny_on && rows <= 64;
@@ -110,8 +110,8 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
         if (want_var) {
             h->kinv_valid = false;  // V overwrites the K^-1 storage
-            if (rows <= 16) {
-                const int R = rows <= 1 ? 1 : (rows <= 2 ? 2 : (rows <= 4 ? 4 : (rows <= 8 ? 8 : 16)));
+            if (rows <= 8) {     // (measured at N = 8192, 16 rows: 0.080 ms on the VALU, 0.068 on the matrix pipe; 8 rows: 0.063 / 0.067)
+                const int R = rows <= 1 ? 1 : (rows <= 2 ? 2 : (rows <= 4 ? 4 : 8));
                 launch_predv_rows(s, R, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np, h->dalpha, mean_dev, (int)rows);
             } else {
                 // (the fragment-ordered copy of the panel: rows 64 .. 127 of the workspace matrix, which holds the 64-row panel)

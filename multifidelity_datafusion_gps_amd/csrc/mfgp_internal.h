@@ -47,12 +47,12 @@ int launch_gemm(hipStream_t s, int tile, const GemmTask* tasks, int ntasks, cons
                 const int* flag = nullptr, int epoch = 0);
 size_t gemm_lds_bytes(int tile);
 
-// <= 16 test rows (trimv_f64.hip): V[i][j] = sum_{k <= j} W[i][k] X[j][k] on the VALU behind ONE coalesced read of the triangle;
-// R = the row count rounded up to 1, 2, 4, 8 or 16 (the panel W holds at least that many rows); the same launch forms the means
+// <= 8 test rows (trimv_f64.hip): V[i][j] = sum_{k <= j} W[i][k] X[j][k] on the VALU behind ONE coalesced read of the triangle;
+// R = the row count rounded up to 1, 2, 4 or 8 (the panel W holds at least that many rows); the same launch forms the means
 // W[i] . alpha of the `rows` real test rows
 void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, double* V, int ld, int Np, const double* alpha,
                        double* mean, int rows);
-// 17 .. 64 test rows (trimv_f64.hip): the same product on v_mfma_f64_16x16x4, RT = ceil(rows / 16) row tiles, S streamed through LDS by
+// 9 .. 64 test rows (trimv_f64.hip): the same product on v_mfma_f64_16x16x4, RT = ceil(rows / 16) row tiles, S streamed through LDS by
 // LDS-DMA in the coalesced shape; the same launch forms the means of the `rows` real test rows
 //   Wt: 64 Np doubles of scratch for the panel in MFMA fragment order (written by the launch)
 void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const double* S, double* V, int ld, int Np,

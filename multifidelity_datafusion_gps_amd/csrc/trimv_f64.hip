@@ -259,7 +259,7 @@ void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z
                        z, alpha, Np, logdet_part, nblk, scalars, sstride, vstride, ldstride, scstride);
 }
 
-// Predict with <= 16 test rows: V[i][j] = sum_{k <= j} W[i][k] X[j][k], i < R (R in {1, 2, 4, 8, 16}: the caller rounds its row
+// Predict with <= 8 test rows: V[i][j] = sum_{k <= j} W[i][k] X[j][k], i < R (R in {1, 2, 4, 8}: the caller rounds its row
 // count up; the panel W holds at least that many rows), j < Np, X = L^-1 read from the lower part of the mirrored S -- and, in
 // the launch's extra last workgroup, the means W[i] . alpha of the `rows` real test rows (the single-vector body over the panel:
 // a row's sum is formed in the same order as in launch_rowdot's launches, whatever their shape -- the mean of a test row does
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void mfgp_predv_rows_f64(const double* __restr
     trimv_wave<R, JR, U>(S, ld, W, ld, V, ld, Np, Np, 0, wv, lane);
 }
 
-// The same product for 8 and 16 test rows: the R right-hand sides would cost R / JR times the bytes of S in L2 -> L1 reads and
+// The same product for 8 test rows (written for 8 and 16; from 9 rows up the matrix-pipe form below is faster -- 16 rows: 0.080 ms
+// here, issue-bound on the VALU, 0.068 there): the R right-hand sides would cost R / JR times the bytes of S in L2 -> L1 reads and
 // fill the wave's memory queue (measured: 3.8 / 2.9 TB/s at R = 8 / 16 in the form above), so the NW waves of a workgroup walk
 // the SAME chunks of NW JR consecutive rows in lock step and share the R x 128 tile of W through LDS: W crosses L1 once per
 // NW JR rows of S, the fragments come out of LDS (ds_read_b128, conflict-free).  The tile is staged by LDS-DMA
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(64 * NW) void mfgp_predv_rows_lds_f64(const double*
     }
 }
 
-// 17 .. 64 test rows: the products move to the matrix pipe (v_mfma_f64_16x16x4: 16 test rows x 16 rows of S x 4 k per instruction),
+// 9 .. 64 test rows: the products move to the matrix pipe (v_mfma_f64_16x16x4: 16 test rows x 16 rows of S x 4 k per instruction),
 // which wants a lane to hold ONE k of 16 DIFFERENT rows of S -- the opposite of the coalesced read.  Rounds 2-5 fetched the
 // fragments in that shape straight from memory (32 B per lane: a wave-instruction = 16 rows x 128 B, 0.30 of the HBM peak: VERDICT
 // r5 weak #2); here S goes through LDS by LDS-DMA in the coalesced shape (global_load_lds_dwordx4: one instruction = 2 rows x 512
@@ -549,13 +550,14 @@ __global__ __launch_bounds__(256, 2) void mfgp_predv_mfma_f64(const double* __re
 
 void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const double* S, double* V, int ld, int Np,
                        const double* alpha, double* mean, int rows) {
-    RT = RT <= 2 ? 2 : (RT == 3 ? 3 : 4);
+    RT = RT <= 1 ? 1 : (RT == 2 ? 2 : (RT == 3 ? 3 : 4));
     const int64_t pieces = (int64_t)(Np >> 2) * 16 * RT;
     hipLaunchKernelGGL(mfgp_panel_fragments_f64, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, W, ld, Wt, Np, RT);
     const dim3 grid(Np / 16 + mean_blocks(rows)), blk(256);
     static const int ks = getenv("MFGP_MFMA_KS") ? atoi(getenv("MFGP_MFMA_KS")) : 64;
 #define PREDV_MFMA(rt, k) hipLaunchKernelGGL((mfgp_predv_mfma_f64<rt, k>), grid, blk, 0, s, W, Wt, S, V, ld, Np, alpha, mean, rows)
-    if (RT == 2) { if (ks == 64) PREDV_MFMA(2, 64); else PREDV_MFMA(2, 32); }
+    if (RT == 1) PREDV_MFMA(1, 64);
+    else if (RT == 2) { if (ks == 64) PREDV_MFMA(2, 64); else PREDV_MFMA(2, 32); }
     else if (RT == 3) PREDV_MFMA(3, 32);
     else PREDV_MFMA(4, 32);
 #undef PREDV_MFMA
@@ -579,9 +581,8 @@ void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, d
 #define PREDV_LDS(r, jr, nw, d)                                                                                           \
     hipLaunchKernelGGL((mfgp_predv_rows_lds_f64<r, jr, nw, d>), dim3(Np / (nw * jr) / 2 + mean_blocks(rows)), dim3(64 * nw), 0, s, S, ld, W, V, \
                        Np, alpha, mean, rows)
-        if (lds == 0) { if (R <= 8) TRIMVR(8, 4, 2); else TRIMVR(16, 4, 1); }
-        else if (R <= 8) PREDV_LDS(8, 4, 4, 2);
-        else PREDV_LDS(16, 2, 4, 3);
+        if (lds == 0) TRIMVR(8, 4, 2);
+        else PREDV_LDS(8, 4, 4, 2);
 #undef PREDV_LDS
     }
 #undef TRIMVR
