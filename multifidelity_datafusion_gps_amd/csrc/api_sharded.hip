@@ -51,7 +51,7 @@ static int ensure_shard_plan(mfgp_handle* h, int rank, int size) {
     }
     h->shard_chunk = *std::max_element(fill.begin(), fill.end());
     if (h->pls.shard.dist) {   // one panel column, padded to the largest rank's share, + the diagonal message
-        const size_t need = std::max((size_t)(h->nblk / size + 2) * size * NB * NB, 2 * (size_t)NB * NB + 2);
+        const size_t need = std::max(((size_t)(h->nblk / size + 2) * NB * NB + 2 * (size_t)NB * NB + 2) * size, 2 * (size_t)NB * NB + 2);
         if (need > h->dist_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (h->ddist) HIPCHK(h, hipFree(h->ddist));

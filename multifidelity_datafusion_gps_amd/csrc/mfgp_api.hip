@@ -79,10 +79,21 @@ int run_step(mfgp_handle* h, const Step& s, bool want_grad, int nbatch, const Ge
         } else {
             std::vector<int> cnt((size_t)size, 0);
             for (int i = c + 1; i < h->nblk; ++i) cnt[(size_t)shard_owner(i, size)]++;
-            const long long chunk = (long long)*std::max_element(cnt.begin(), cnt.end()) * NB * NB;
+            // per rank: its blocks of the panel column, padded to the largest share, then -- one exchange per column (Step::carry) --
+            // room for the diagonal message of block c + 1 (used by its owner's chunk only)
+            const long long panel_part = (long long)*std::max_element(cnt.begin(), cnt.end()) * NB * NB;
+            const long long chunk = panel_part + (s.carry ? 2LL * NB * NB + 2 : 0);
+            const int next_own = shard_owner(c + 1, size);
             launch_dist_panel_copy(st, h->buf[BUF_L], Np, h->nblk, c, h->ddist, chunk, rank, size, false);
+            if (s.carry && next_own == rank)
+                launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c + 1, h->ddist + (long long)rank * chunk + panel_part, h->dlogdet,
+                                      h->dinfo, false);
             if (int rc = comm_allgather_chunks(h, h->ddist, (size_t)chunk, st)) return rc;
             launch_dist_panel_copy(st, h->buf[BUF_L], Np, h->nblk, c, h->ddist, chunk, rank, size, true);
+            if (s.carry && next_own != rank)
+                launch_dist_diag_copy(st, h->buf[BUF_L], h->buf[BUF_S], Np, c + 1, h->ddist + (long long)next_own * chunk + panel_part,
+                                      h->dlogdet, h->dinfo, true, h->dflag, h->epoch);
+            if (s.carry) h->launches += 1;
         }
         h->launches += 2;
     }   // kind 2: join -- the wait above is all there is

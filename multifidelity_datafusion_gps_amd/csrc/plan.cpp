@@ -28,6 +28,7 @@ PlanOpts plan_opts_from_env() {
     o.chain_slim = env_int("MFGP_CHAIN_SLIM", -1);
     o.t128_min = std::max(0, env_int("MFGP_T128_MIN", 0));
     o.dist_chol = env_int("MFGP_DIST_CHOL", -1);
+    o.dist_fuse = env_int("MFGP_DIST_FUSE", -1);
     return o;
 }
 static int opt(int v, int dflt) { return v >= 0 ? v : dflt; }
@@ -514,7 +515,7 @@ static void plan_sweep(Plan& p) {
     //   6144 6.02 / 6.21 / 6.22 / 6.24 / 6.29;  8192 12.27 / 12.05 / 11.80 / 11.92 / 12.00 / 12.35 / 13.5;
     //   12288 - / - / 34.50 / 34.48 / 34.66 / 36.0 / 37.2;  16384 - / - / 75.9 / 75.7 / 77.6 / 77.9 / 81.7
     // (rounds 1-2 had 2 / 3 / 4 / 6 / 8 / 16 from 14 / 33 / 41 / 52 / 64 / 96 block columns up).
-    const int MB = p.opts.macro > 0 ? p.opts.macro : (nb >= 80 ? 5 : (nb >= 56 ? 4 : (nb >= 25 ? 2 : (nb > 13 ? 3 : nb))));
+    const int MB = sweep_macro_columns(nb, p.opts);
     const bool shift = opt(p.opts.shift, nb < 48) != 0;   // the chain's K = 128 updates also cover the next macro's first column (see plan_potrf_rl)
     // slim (16 KB LDS) chain workgroups fit on a CU beside a 128 KB bulk workgroup; the 64 KB kernel would wait for one to
     // retire (N = 4096: 3.27 -> 3.03 ms).  Below ~24 blocks the bulk launches are 64-tiles themselves: no difference.
@@ -553,11 +554,16 @@ static void plan_sweep(Plan& p) {
                 for (int i = i0; i < std::min(ihi, i0 + bulk_bi); ++i)
                     for (int j = j0; j < std::min(jhi, j0 + bulk_bj); ++j) fn(i, j);
     };
-    auto a_update = [&](int T, int jlo, int jhi, int klo, int khi) {
+    // only_diag >= 0: only the tiles of diagonal block only_diag; skip_diag >= 0: everything but those (the one-exchange-per-column
+    // form splits column c's K = 128 update of A: owner(c + 1) runs the diagonal block's tiles early, before the exchange)
+    auto a_update = [&](int T, int jlo, int jhi, int klo, int khi, int only_diag = -1, int skip_diag = -1) {
         const int sc = NB / T;
         in_blocks(jlo * sc, nb * sc, jlo * sc, jhi * sc, [&](int i, int j) {
             if (i < j) return;
             if (dist && !mine((int64_t)i * T)) return;
+            const bool on_diag_blk = i / sc == j / sc;
+            if (only_diag >= 0 && !(on_diag_blk && i / sc == only_diag)) return;
+            if (skip_diag >= 0 && on_diag_blk && i / sc == skip_diag) return;
             push(at(BUF_L, (int64_t)i * T, (int64_t)klo * NB), at(BUF_L, (int64_t)j * T, (int64_t)klo * NB),
                  at(BUF_A, (int64_t)i * T, (int64_t)j * T), -1, (khi - klo) * NB, 0, -1.0, 1.0);
         });
@@ -645,14 +651,18 @@ static void plan_sweep(Plan& p) {
         const int M2 = std::min(M1 + MB, nb);
         // ---- the chain of this macro panel (main stream) ----
         for (int c = M0; c < M1; ++c) {
-            if (!dist || mine((int64_t)c * NB)) {
+            // one exchange per column: column c's diagonal block came with the all-gather of panel c - 1 (its owner factorised it
+            // early, see below) wherever c is not the first column of its macro panel
+            const bool fused = dist && opt(p.opts.dist_fuse, 1) != 0;
+            const bool came_early = fused && c > M0;
+            if (!came_early && (!dist || mine((int64_t)c * NB))) {
                 Step s{};
                 s.kind = STEP_LEAF;
                 s.blk = c;
                 main_wait(s, ev_col[c]);
                 p.steps.push_back(s);
             }
-            if (dist) {   // L_cc, X_cc from the rank that factorised them (main_wait: a rank without the leaf meets column c here first)
+            if (dist && !came_early) {   // L_cc, X_cc from the rank that factorised them (main_wait: a rank without the leaf meets column c here first)
                 Step s{};
                 s.kind = STEP_COMM_DIAG;
                 s.blk = c;
@@ -669,16 +679,33 @@ static void plan_sweep(Plan& p) {
                     launch(T, first, 0, T == 128 ? 0 : chain_role_ct);
                 }
             }
+            const bool carry = fused && c + 1 < M1;     // the next column's diagonal block travels with this column's panel
+            const bool early_here = carry && mine((int64_t)(c + 1) * NB);
+            if (early_here) {
+                // this rank owns block c + 1: its own row of panel c is all it needs -- the diagonal block's share of column c's
+                // K = 128 update (the SAME tiles inner(c) would run: no result bit changes), then the leaf, before the exchange
+                const int first = (int)p.tasks.size();
+                a_update(CT, c + 1, c + 2, c, c + 1, c + 1);
+                Step* st = launch(CT, first, 0, chain_role_ct);
+                if (st) main_wait(*st, ev_col[c + 1]);
+                Step s{};
+                s.kind = STEP_LEAF;
+                s.blk = c + 1;
+                main_wait(s, ev_col[c + 1]);
+                p.steps.push_back(s);
+            }
             if (dist && c + 1 < nb) {   // block column c of L: every rank's rows to everybody (the updates read L[j, c] of every row j)
                 Step s{};
                 s.kind = STEP_COMM_PANEL;
                 s.blk = c;
+                s.carry = carry ? 1 : 0;
+                if (carry) main_wait(s, ev_col[c + 1]);   // (a rank without the early leaf meets block c + 1 here first)
                 p.steps.push_back(s);
             }
             {   // inner(c): right-looking K = 128 updates inside the macro (A: also the next macro's first column if `shift`)
                 const int inner_hi = shift ? std::min(M1 + 1, nb) : M1;
                 auto updates = [&]() {
-                    if (c + 1 < inner_hi) a_update(CT, c + 1, inner_hi, c, c + 1);
+                    if (c + 1 < inner_hi) a_update(CT, c + 1, inner_hi, c, c + 1, -1, early_here ? c + 1 : -1);
                     if (c + 1 < M1) b_update(CT, M0, c + 1, c + 1, M1, c, c + 1);
                 };
                 const int first = (int)p.tasks.size();
@@ -833,9 +860,18 @@ static void plan_sweep(Plan& p) {
     }
 }
 
-DistDecision dist_cholesky_pays(int nblk, int size, double coll_us) {
+int sweep_macro_columns(int nb, const PlanOpts& opts) {
+    return opts.macro > 0 ? opts.macro : (nb >= 80 ? 5 : (nb >= 56 ? 4 : (nb >= 25 ? 2 : (nb > 13 ? 3 : nb))));
+}
+int dist_collectives(int nblk, const PlanOpts& opts) {
+    if (opt(opts.dist_fuse, 1) == 0) return 2 * nblk - 1;
+    const int MB = sweep_macro_columns(nblk, opts);
+    return nblk - 1 + (nblk + MB - 1) / MB;     // one all-gather per column but the last + one broadcast per macro panel
+}
+
+DistDecision dist_cholesky_pays(int nblk, int size, double coll_us, const PlanOpts& opts) {
     DistDecision d{};
-    d.collectives = 2 * nblk - 1;
+    d.collectives = dist_collectives(nblk, opts);
     const double n = 128.0 * nblk;
     d.saving_ms = size > 1 ? (1.0 - 1.0 / size) * (n * n * n / 3.0) / 60e12 * 1e3 : 0.0;
     d.cost_ms = d.collectives * coll_us * 1e-3;
@@ -848,7 +884,7 @@ void build_plan(Plan& p, int nblk, int64_t ld, int64_t stride, const PlanOpts& o
     p.opts = opts;
     p.shard = shard;
     p.shard.dist = shard.size > 1 && (shard.dist || (opts.dist_chol >= 0 ? opts.dist_chol != 0
-                                                                         : dist_cholesky_pays(nblk, shard.size, shard.coll_us).dist));
+                                                                         : dist_cholesky_pays(nblk, shard.size, shard.coll_us, opts).dist));
     if (shard.size > 1) p.opts.kind = 0;      // a sharded evaluation always runs the sweep
     p.t128_min = std::max(1, (opts.t128_min > 0 ? opts.t128_min : (nblk >= 56 ? 600 : 300)) / std::max(1, t128_div));
     p.batch_div = std::max(1, t128_div);

@@ -52,6 +52,8 @@ struct Step {
     int gfirst, gcount; // gcount > 0: the task range to run INSTEAD of [first, first + count) when the gradient is wanted
                         // (the same tasks plus a chunk of the K^-1 accumulation, ordered longest first as a whole)
     int rec_ev_final;   // a second event recorded after the launch (the plan's final join), 0 = none
+    int carry;          // STEP_COMM_PANEL only: 1 = the all-gather of block column blk also carries L, X and the leaf's words of diagonal
+                        // block blk + 1 from its owner (the one-exchange-per-column form: no STEP_COMM_DIAG for column blk + 1)
 };
 
 // The planner's switches (DESIGN.md "Planner switches"): read from the environment ONCE when a handle plans for a size
@@ -67,6 +69,8 @@ struct PlanOpts {
     int dist_chol = -1;    // MFGP_DIST_CHOL: a sharded evaluation's Cholesky distributed over the group too (Shard::dist): 1 / 0 force
                            // it on / off; default (-1): decided from the group's MEASURED collective latency (Shard::coll_us,
                            // dist_cholesky_pays) -- and off while nothing has been measured
+    int dist_fuse = -1;    // MFGP_DIST_FUSE: the distributed Cholesky's two exchanges per block column fused into one wherever the next
+                           // column belongs to the same macro panel (default 1; 0: round 5's 2 nblk - 1 collectives)
 };
 // Row ownership of a sharded evaluation (mfgp_eval_sharded): the work on the image of the identity / the rows of X^T and the rows
 // of K^-1 -- 2 N^3 / 3 of an evaluation's N^3 flops -- splits by 128-row block with no dependency between blocks; block b belongs
@@ -79,6 +83,12 @@ struct PlanOpts {
 // everybody: 2 x 128 KB) before the panel, COMM_PANEL(c) (block column c of L below the diagonal, every 128-row block from its
 // owner to everybody: 8 (N - 128 c) 128 bytes in all) after it.  Every rank ends with the complete L; the tasks it runs are the
 // single evaluation's own tasks, so no result bit changes.
+// One exchange per column (round 6; DESIGN section 8.1 of round 5): owner(c + 1) needs only ITS OWN row of panel c to bring
+// A[c+1, c+1] up to date and run leaf(c + 1) -- it does so right after panel(c), before the all-gather of panel c, which then
+// carries L, X and the leaf's words of block c + 1 along (Step::carry): COMM_DIAG(c + 1) disappears.  Possible wherever column
+// c + 1 belongs to the same macro panel as c (its diagonal block is then complete once column c's K = 128 update has landed; the
+// first column of a macro panel still waits for the previous macro's bulk update and keeps its broadcast):
+// nblk + ceil(nblk / MB) - 1 collectives on the chain instead of 2 nblk - 1.
 struct Shard {
     int rank = 0, size = 1;
     bool dist = false;     // (set by build_plan from PlanOpts::dist_chol, or from the measurement below)
@@ -90,14 +100,18 @@ struct Shard {
 // distributed plan saves (1 - 1/G) of the Cholesky's N^3 / 3 flops per rank -- priced at 60 TFLOP/s, what the one-GPU projections
 // of round 5 gave for the saving at N = 8192 / 16384 / 32768 on 8 ranks (59 / 68 / 68: profiles/r05_dist_projection.txt) -- and
 // puts 2 nblk - 1 collectives (each with its pack and unpack launch) on the serial chain.  It is taken when the saving exceeds
-// 1.25 x that cost; never without a measurement (coll_us <= 0).  Pure arithmetic on its arguments: every rank of a group holds
+// 1.25 x that cost; never without a measurement (coll_us <= 0).  (With the exchanges of a column fused -- the default from round 6 --
+// the count is nblk + ceil(nblk / MB) - 1: dist_collectives.)  Pure arithmetic on its arguments: every rank of a group holds
 // the same coll_us and decides alike.
 struct DistDecision {
     bool dist;
     double saving_ms, cost_ms;
     int collectives;
 };
-DistDecision dist_cholesky_pays(int nblk, int size, double coll_us);
+DistDecision dist_cholesky_pays(int nblk, int size, double coll_us, const PlanOpts& opts = PlanOpts());
+// block columns per macro panel of the sweep at nblk block columns / exchange steps on the chain of a distributed Cholesky
+int sweep_macro_columns(int nblk, const PlanOpts& opts);
+int dist_collectives(int nblk, const PlanOpts& opts);
 enum StepKind { STEP_LEAF = 0, STEP_GEMM = 1, STEP_JOIN = 2, STEP_COMM_DIAG = 3, STEP_COMM_PANEL = 4 };
 inline int shard_owner(int blk, int size) {
     if (size <= 1) return 0;

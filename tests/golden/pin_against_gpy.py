@@ -11,7 +11,16 @@ fixture, and so everything under tests/golden/ certifies self-consistency with G
   * paramz' Logexp transform: f, its inverse and the gradient factor over the whole double range (limit value 36);
   * L-BFGS-B as paramz calls it: m = 10, factr = 1e7, pgtol = 1e-5, maxfun = maxiter = max_iters -- same optimum and evaluation
     count as engine.GPRegression.optimize on the same objective from the same start;
-  * optimize_restarts: the first restart CONTINUES from the current point, the others start from N(0, 1) draws in optimizer space.
+  * optimize_restarts: the first restart CONTINUES from the current point, the others start from N(0, 1) draws in optimizer space;
+  * (round 6) paramz' policy for an evaluation that fails inside the optimiser (Model._objective_grads: LinAlgError / ZeroDivisionError /
+    ValueError -> the objective DBL_MAX, the previous gradient clipped to +-1e10, `_fail_count` + 1, ten in a row allowed, reset by the next
+    success) -- engine.GPRegression carries exactly these on the model (`_fail_count`, `_allowed_failures`, `_F_FAILED`, `_G_CLIP_FAILED`);
+  * (round 6) GPy's jitchol: a factorisation that fails is retried with jitter mean(diag) * 1e-6 * 10^k, k = 0 .. 4 on top of the 1e-8.
+
+Nothing added since round 5 changes a number these checks look at: the distributed / batched / sharded evaluation paths and round 6's
+triangular-product kernels, rank-1 append with its O(N) alpha update and early exit of a failed factorisation compute the same
+quantities (bitwise for the sharded paths, within the stated tolerances for the re-ordered sums) -- the committed vectors and the
+tolerances in tests/tolerances.py are what GPy is held against here.
 
 Exit codes: 0 = everything agrees, 1 = a difference (printed), 77 = GPy is not importable (nothing was checked).
 It does not try to install anything and imports nothing from /root/reference.
@@ -181,6 +190,36 @@ def check_conventions(GPy, paramz, verbose=False):
     good = len(starts) == 3 and np.array_equal(starts[0], here)
     good = good and all(np.allclose(T.finv(T.f(d.copy())), s, rtol=1e-12) or np.allclose(d, s, rtol=1e-12) for d, s in zip(draws, starts[1:]))
     report("optimize_restarts: restart 0 continues, the others from N(0, 1) draws in optimizer space", good)
+    # (6) the failure policy inside an optimiser run (paramz Model._objective_grads)
+    ref3 = GPy.models.GPRegression(X, Y, GPy.kern.RBF(2))
+    f_good, g_good = ref3._objective_grads(np.array(ref3.optimizer_array, dtype=float))
+    allowed = int(getattr(ref3, "_allowed_failures", -1))
+    orig_obj = ref3.objective_function
+
+    def failing():
+        raise np.linalg.LinAlgError("injected")
+    ref3.objective_function = failing
+    outs = []
+    for _ in range(3):
+        outs.append(ref3._objective_grads(np.array(ref3.optimizer_array, dtype=float)))
+    fails_after = int(ref3._fail_count)
+    ref3.objective_function = orig_obj
+    ref3._objective_grads(np.array(ref3.optimizer_array, dtype=float))
+    good = allowed == 10 == gp.GPRegression(X, Y, kernel=gp.RBF(2), engine=OracleEngine())._allowed_failures
+    good = good and all(o[0] == np.finfo(np.float64).max == gp._F_FAILED for o in outs) and fails_after == 3 and int(ref3._fail_count) == 0
+    good = good and all(np.all(np.abs(o[1]) <= gp._G_CLIP_FAILED) for o in outs) and gp._G_CLIP_FAILED == 1e10
+    report("a failed evaluation: DBL_MAX, the previous gradient clipped to +-1e10, ten in a row, reset by a success", good,
+           "(_allowed_failures %d, _fail_count after three failures %d)" % (allowed, fails_after))
+    # (7) jitchol's retries: mean(diag) * 1e-6 * 10^k
+    from GPy.util.linalg import jitchol
+    A = np.ones((6, 6)) * 2.0                          # rank one: the plain factorisation fails
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Lj = jitchol(A.copy())
+    added = float(np.mean(np.diag(Lj.dot(Lj.T) - A)))
+    ks = [k for k in range(5) if abs(added - 2.0 * 1e-6 * 10 ** k) <= 1e-3 * added]
+    report("jitchol: the first jitter mean(diag) * 1e-6 * 10^k that factorises", len(ks) == 1, "(added %.3e)" % added)
     return ok
 
 

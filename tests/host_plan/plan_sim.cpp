@@ -244,6 +244,11 @@ void comm_accesses(Sim& s, const Step& st, int si) {
         touch(BUF_S, c, c, !own);
     } else {
         for (int i = c + 1; i < p.nblk; ++i) touch(BUF_L, i, c, shard_owner(i, size) != rank);
+        if (st.carry) {   // one exchange per column: diagonal block c + 1 travels along (read by its owner, written by the others)
+            const bool own = shard_owner(c + 1, size) == rank;
+            touch(BUF_L, c + 1, c + 1, !own);
+            touch(BUF_S, c + 1, c + 1, !own);
+        }
     }
 }
 
@@ -456,6 +461,7 @@ static int plan_sim_group(int nblk, int size, bool dist, double* report, char* m
     std::vector<Walker> wk((size_t)size);
     size_t max_tasks = 0;
     double comm_words = 0;
+    int n_exchanges = 0, n_exchanges_carry = 0;
     for (int r = 0; r < size; ++r) {
         Sim& s = rk[(size_t)r];
         s.ld = ld; s.stride = stride;
@@ -484,7 +490,7 @@ static int plan_sim_group(int nblk, int size, bool dist, double* report, char* m
             }
             if (!done) {
                 const Step& a = rk[(size_t)r].p.steps[(size_t)at[(size_t)r]], &b = rk[0].p.steps[(size_t)at[0]];
-                if (a.kind != b.kind || a.blk != b.blk) {
+                if (a.kind != b.kind || a.blk != b.blk || a.carry != b.carry) {
                     snprintf(msg, msglen, "rank %d meets exchange (%d, column %d) where rank 0 meets (%d, column %d)", r, a.kind, a.blk, b.kind, b.blk);
                     return -6;
                 }
@@ -507,10 +513,18 @@ static int plan_sim_group(int nblk, int size, bool dist, double* report, char* m
             copy_block(BUF_S, c, c, shard_owner(c, size));
         } else {
             for (int i = c + 1; i < nblk; ++i) copy_block(BUF_L, i, c, shard_owner(i, size));
+            if (st.carry) {
+                copy_block(BUF_L, c + 1, c + 1, shard_owner(c + 1, size));
+                copy_block(BUF_S, c + 1, c + 1, shard_owner(c + 1, size));
+            }
+            n_exchanges_carry += st.carry ? 1 : 0;
         }
+        n_exchanges += 1;
         for (int r = 0; r < size; ++r) wk[(size_t)r].resume();
     }
     report[5] = comm_words * 8.0;     // bytes every rank receives or sends through the Cholesky's exchange steps (per copy of a block)
+    report[6] = n_exchanges;          // exchange steps on the chain / of those, all-gathers that carried the next diagonal block along
+    report[7] = n_exchanges_carry;
     for (int r = 0; r < size; ++r) {
         Sim& s = rk[(size_t)r];
         report[0] += s.races;
@@ -609,8 +623,8 @@ int plan_sim_group_schedule(int nblk, int size, int dist, double* report, char* 
             if (at < 0) return at;
             if (at == (int)s.p.steps.size()) break;
             const Step& st = s.p.steps[(size_t)at];
-            order[(size_t)r].push_back({st.kind, st.blk});
-            if (r == 0) report[5] += 8.0 * NB * NB * (st.kind == STEP_COMM_DIAG ? 2 : nblk - 1 - st.blk);
+            order[(size_t)r].push_back({st.kind * 2 + st.carry, st.blk});
+            if (r == 0) report[5] += 8.0 * NB * NB * (st.kind == STEP_COMM_DIAG ? 2 : nblk - 1 - st.blk + 2 * st.carry);
             w.resume();
         }
         report[0] += s.races;

@@ -362,7 +362,7 @@ def test_rccl_communicator_of_several_ranks_on_one_gpu(world, dist_everywhere):
                 assert cal is not None and cal["broadcast_us"] > 0 and cal["allgather_us"] > 0 and cal["reps"] == 20, cal
                 # the rig's collectives go through RCCL's socket transport on loopback: far above what 127 of them may cost
                 assert dec["cholesky"] == "replicated" and not dec["forced_by_MFGP_DIST_CHOL"], dec
-                assert dec["collectives_on_chain"] == 127 and dec["measured_us_per_collective"] > 0, dec
+                assert dec["collectives_on_chain"] == 64 - 1 + 16 and dec["measured_us_per_collective"] > 0, dec   # one all-gather per column + one broadcast per macro panel of 4
                 assert dec["collective_cost_ms"] * 1.25 >= dec["projected_saving_ms"] and "collectives x" in dec["why"], dec
                 if r == 0:
                     print("2-rank rig: calibration %s -> N = 8192: %s" % (cal, dec))
@@ -431,7 +431,7 @@ def _failing_leader_worker(rank, port, q):
     import time
     from multifidelity_datafusion_gps_amd import sharding
     os.environ.update(sharding.rehearsal_env(rank))
-    os.environ["MFGP_SHARD_TIMEOUT_S"] = "6"               # a follower whose leader is gone gives up after this long
+    os.environ["MFGP_SHARD_TIMEOUT_S"] = "3"               # a follower whose leader is gone gives up after this long
     from multifidelity_datafusion_gps_amd import engine as gp
     from multifidelity_datafusion_gps_amd._lib import Engine
     comm = sharding.SocketComm(rank, 2, "127.0.0.1", port, timeout=120)
@@ -503,7 +503,7 @@ def _unmatched_gather_worker(rank, port, q, mode="absent_peer"):
     import time
     from multifidelity_datafusion_gps_amd import sharding
     os.environ.update(sharding.rehearsal_env(rank))
-    os.environ["MFGP_SHARD_TIMEOUT_S"] = "5"
+    os.environ["MFGP_SHARD_TIMEOUT_S"] = "3"
     from multifidelity_datafusion_gps_amd._lib import Engine
     comm = sharding.SocketComm(rank, 2, "127.0.0.1", port, timeout=120)
     e = Engine(0)
@@ -534,7 +534,7 @@ def _unmatched_gather_worker(rank, port, q, mode="absent_peer"):
         except RuntimeError as ex:
             res["again"] = str(ex)
     else:
-        time.sleep(12.0)                                   # alive, its communicator intact, but somewhere else in the protocol
+        time.sleep(7.0)                                    # alive, its communicator intact, but somewhere else in the protocol
     q.put((rank, res))
     q.close()
     q.join_thread()
@@ -568,8 +568,8 @@ def test_a_gather_the_peer_never_joins_gives_up_after_the_deadline():
     the call fails with a message that says so, and further collectives on the handle are refused."""
     out = _run_gather_pair("absent_peer")
     lone = out[0]
-    assert lone["error"] is not None and "no progress for 5 s" in lone["error"], lone
-    assert lone["aborted"] and 4.0 < lone["seconds"] < 30.0, lone
+    assert lone["error"] is not None and "no progress for 3 s" in lone["error"], lone
+    assert lone["aborted"] and 2.5 < lone["seconds"] < 30.0, lone
     assert lone["again"] != "issued" and "aborted" in lone["again"], lone
 
 
@@ -584,6 +584,6 @@ def test_a_gather_whose_rccl_call_fails_aborts_the_communicator_and_frees_the_pe
     assert failed["error"] is not None and "communicator was aborted" in failed["error"], failed
     assert failed["aborted"] and failed["seconds"] < 3.0, failed
     assert failed["again"] != "issued" and "aborted" in failed["again"], failed
-    assert peer["error"] is not None and "no progress for 5 s" in peer["error"], peer
-    assert peer["aborted"] and 4.0 < peer["seconds"] < 30.0, peer
+    assert peer["error"] is not None and "no progress for 3 s" in peer["error"], peer
+    assert peer["aborted"] and 2.5 < peer["seconds"] < 30.0, peer
     assert peer["again"] != "issued" and "aborted" in peer["again"], peer

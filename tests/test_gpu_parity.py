@@ -657,7 +657,7 @@ def test_north_star_size_n8192_against_oracle(engine):
 
 
 def test_randomised_parity_soak_across_planner_boundaries():
-    """60 seeded random cases of tools/fuzz_parity.py (sizes 1 .. 2000 with the block counts at which the planner's defaults
+    """48 seeded random cases of tools/fuzz_parity.py (sizes 1 .. 2000 with the block counts at which the planner's defaults
     change over-represented; single / composite kernels of RBF / Matern-3/2 / -5/2 factors, isotropic or ARD; random
     hyper-parameters, noise from 1e-4 to 0.3 of Var(y); every fourth case a rank-1 append against the fused evaluation):
     the stated tolerances (tests/tolerances.py: NLML 1e-10, gradient 1e-8 per component, mean / variance 1e-9 max(1, |y|), the
@@ -668,6 +668,6 @@ def test_randomised_parity_soak_across_planner_boundaries():
                                                                            "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    n, bad, worst = fz.run(seconds=3600.0, seed=7, nmax=2000, max_cases=60, verbose=False)   # the count bounds it, not the clock
+    n, bad, worst = fz.run(seconds=3600.0, seed=7, nmax=2000, max_cases=48, verbose=False)   # the count bounds it, not the clock
     print("soak: worst error / tolerance", worst)
-    assert n == 60 and not bad, bad[:3]
+    assert n == 48 and not bad, bad[:3]

@@ -174,7 +174,22 @@ def test_sharded_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
         assert rep[4] <= 1.0
 
 
-@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}],
+def _macro_columns(nb, env=None):
+    """plan.cpp sweep_macro_columns: block columns per macro panel of the sweep"""
+    m = int((env or {}).get("MFGP_MACRO", 0))
+    return m if m > 0 else (5 if nb >= 80 else (4 if nb >= 56 else (2 if nb >= 25 else (3 if nb > 13 else nb))))
+
+
+def _dist_collectives(nb, env=None):
+    """plan.cpp dist_collectives: one all-gather per block column but the last + one broadcast per macro panel (the diagonal block of a
+    macro panel's first column), or round 5's 2 nb - 1 under MFGP_DIST_FUSE=0"""
+    if (env or {}).get("MFGP_DIST_FUSE") == "0":
+        return 2 * nb - 1
+    mb = _macro_columns(nb, env)
+    return nb - 1 + (nb + mb - 1) // mb
+
+
+@pytest.mark.parametrize("env", [{}, {"MFGP_MACRO": "2"}, {"MFGP_MACRO": "3", "MFGP_SHIFT": "0"}, {"MFGP_DIST_FUSE": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_distributed_cholesky_plans_reproduce_the_single_plan_bit_for_bit(simlib, env):
     """SURVEY 8(e) "Cholesky" (round 5): the 1-D block-cyclic factorisation over a rank group (plan.h Shard::dist).  Every rank's plan
@@ -182,7 +197,10 @@ def test_distributed_cholesky_plans_reproduce_the_single_plan_bit_for_bit(simlib
     steps per block column -- the diagonal blocks from their owner, the panel column from the owners of its rows -- executed here
     in lock step over the ranks' own copies of the matrices (pre-filled with NaN: a rank that read a row it never received would
     poison its result).  Each rank's schedule is race-free, the exchange steps come in the same order on every rank, L, S and
-    the owned rows of K^-1 are BITWISE the single plan's, and the largest rank's task count falls towards 1/G of it."""
+    the owned rows of K^-1 are BITWISE the single plan's, and the largest rank's task count falls towards 1/G of it.
+    Round 6: ONE exchange per column wherever the next column belongs to the same macro panel -- its owner brings the diagonal
+    block up to date from its own row of the panel, factorises it before the all-gather, and the all-gather carries it along
+    (Step::carry): nb - 1 + ceil(nb / MB) collectives instead of 2 nb - 1 (MFGP_DIST_FUSE=0: round 5's form), the same bytes."""
     specs = [(3, 2), (8, 3), (14, 3), (16, 4)] if not env else [(5, 2), (9, 4), (14, 2)]
     results = _run_sharded(simlib, specs, env, "plan_sim_dist")
     for (nb, size), (rc, rep, msg) in zip(specs, results):
@@ -192,6 +210,9 @@ def test_distributed_cholesky_plans_reproduce_the_single_plan_bit_for_bit(simlib
         assert rep[4] <= 1.0
         # bytes through the Cholesky's exchange steps: 2 diagonal blocks + the blocks below, per block column
         assert rep[5] == 8 * 128 * 128 * sum(2 + (nb - 1 - c) for c in range(nb)), (nb, size, rep[5])
+        assert rep[6] == _dist_collectives(nb, env), (nb, size, rep[6], _dist_collectives(nb, env))
+        carried = 0 if env.get("MFGP_DIST_FUSE") == "0" else nb - (nb + _macro_columns(nb, env) - 1) // _macro_columns(nb, env)
+        assert rep[7] == carried, (nb, size, rep[7], carried)
     if not env:
         share = {(nb, size): rep[4] for (nb, size), (rc, rep, msg) in zip(specs, results)}
         assert share[(16, 4)] < 0.45 and share[(14, 3)] < 0.55, share   # (sharded without dist: 1/3 + 2/(3 G) = 0.5 / 0.56 at best)
@@ -217,8 +238,8 @@ def test_group_schedules_at_the_sizes_of_the_eight_rank_job(simlib):
     """What no one-GPU rig can run: the plans of an 8-rank group at the sizes they are made for -- the bench's LF group (64 block
     columns on 8 ranks) and chain group (on 3), and the distributed Cholesky at N = 8192 / 16384 (its default threshold) / 32768 on 8
     ranks.  Schedule only (no arithmetic): every rank's plan free of races with every wait behind its record, the exchange steps met
-    in the same order by all ranks (2 nb - 1 of them, 8 * 128 * 128 * (2 + blocks below) bytes per column), and the largest rank's task list
-    near 1/8 of the single plan's under the distributed Cholesky."""
+    in the same order by all ranks (nb - 1 + ceil(nb / MB) of them in the one-exchange-per-column form, 8 * 128 * 128 * (2 + blocks
+    below) bytes per column either way), and the largest rank's task list near 1/8 of the single plan's under the distributed Cholesky."""
     import json
     specs = [(64, 8, 0), (64, 3, 0), (64, 8, 1), (128, 8, 1), (128, 8, 0), (256, 8, 1), (128, 5, 1)]
 
@@ -228,7 +249,7 @@ def test_group_schedules_at_the_sizes_of_the_eight_rank_job(simlib):
     for (nb, size, dist), (rc, rep, msg) in zip(specs, _spread(specs, call)):
         assert rc == 0 and rep[0] == 0, (nb, size, dist, rc, msg)
         if dist:
-            assert rep[6] == 2 * nb - 1, (nb, size, rep)
+            assert rep[6] == _dist_collectives(nb), (nb, size, rep)
             assert rep[5] == 8 * 128 * 128 * sum(2 + (nb - 1 - c) for c in range(nb)), (nb, size, rep)
             assert rep[4] < 1.0 / size + 0.1, (nb, size, rep)
         else:

@@ -96,7 +96,7 @@ def check_against_truth(label, case, tr, nlml=None, grad=None, mean=None, var=No
 QUAD_MAX_ROWS = 4096      # quad-precision Cholesky: 2 s at 1024 rows, 25 s at 4096, 194 s at 8192 (16 threads)
 
 
-def check_add_noise_state(label, parts, theta, noise, X, Y, Xs, nlml, mean, var, jitter=1e-8, quad_rows=256):
+def check_add_noise_state(label, parts, theta, noise, X, Y, Xs, nlml, mean, var, jitter=1e-8, quad_rows=256, quad_max_rows=None):
     """One fitted / appended state in the add_noise regime (sigma_n^2 = 1e-6, src/MFDataFusion.py:154-155) -- `nlml`, `mean`, `var`
     (noise INCLUDED, as MultifidelityDataFusion.predict returns it) from the HIP path at (parts, theta, noise) on the rows (X, Y):
 
@@ -123,7 +123,7 @@ def check_add_noise_state(label, parts, theta, noise, X, Y, Xs, nlml, mean, var,
     tol._record(label, "cond_bound", cond)
     tol._record(label, "nlml_pair_err_over_eps_cond", abs(nlml - st["nlml"]) / abs(st["nlml"]) / (np.finfo(float).eps * cond))
     tol._record(label, "mean_pair_err_over_eps_cond", np.abs(mean - mu).max() / ys / (np.finfo(float).eps * cond))
-    if X.shape[0] <= QUAD_MAX_ROWS:
+    if X.shape[0] <= (QUAD_MAX_ROWS if quad_max_rows is None else min(QUAD_MAX_ROWS, quad_max_rows)):
         from oracle import quad_truth
         q = slice(0, min(quad_rows, len(mean)))
         tr = quad_truth.evaluate(parts, theta, noise, X, Y, np.ascontiguousarray(Xs[q]), jitter=jitter, want_grad=False)
