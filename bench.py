@@ -275,8 +275,8 @@ def cpu_baseline(args, data, n_lf_evals, n_hf_evals, budget_s=170.0):
                          measured, n_lf_evals, n_hf_evals)}
 
 
-PMC_FILE = os.path.join("profiles", "r05_pmc.json")
-MFMA_FILE = os.path.join("profiles", "r05_mfma_counters.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc.json")
+MFMA_FILE = os.path.join("profiles", "r06_mfma_counters.json")
 BARE_MFMA_TFLOPS = 71.0   # bare v_mfma_f64_4x4x4_4b loop on this part (profiles/r03_probes.txt): what the instruction itself can issue
 
 
@@ -684,6 +684,9 @@ def main():
                          "tools/time_eval.py, committed, taken with this library build %s; not measured by this run)" % build_id)
                          if traffic_sweep is not None else "null: " + traffic_why,
                          "launches": int(evals), "flops_per_launch": tot["cholinv_flops"] / max(evals, 1),
+                         "flops_are": ("algorithmic flops of one rank's evaluations" if world == 1 else
+                                       "rank 0's EXECUTED share: an evaluation shared by a rank group counts what this rank ran (the Cholesky in full or a G-th of it, "
+                                       "a G-th of the inverse and of K^-1), not the whole evaluation"),
                          "achieved_is": "all sweep flops of the timed region / its wall time (several evaluations are in flight at once -- "
                                         "%s -- so per-launch intervals overlap)" % ("batched passes on %d lanes" % lanes if lockstep else "%d free-running evaluations" % (1 + max(args.concurrency, 2))),
                          "per_launch_overlapped": {"avg_launch_ms": round(tot["cholinv_ms"] / max(evals, 1), 4),

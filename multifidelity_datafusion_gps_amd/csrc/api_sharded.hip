@@ -205,9 +205,19 @@ static int sharded_finish(mfgp_handle* h, bool want_grad) {
     if (int rs = comm_stream_wait(h, h->stream, "sharded evaluation: waiting for the pass (all-gather / all-reduce with the group)")) return rs;
     const bool streamed_flag = h->pl.kinv_streamed;       // finish_eval's flop accounting looks at the handle's own plan:
     h->pl.kinv_streamed = false;                          // a sharded pass never streams K^-1
+    const double sweep0 = h->cum.cholinv_flops, kinv0 = h->cum.kinv_flops;
     const int rc = finish_eval(h, want_grad);
     h->pl.kinv_streamed = streamed_flag;
     h->kinv_valid = false;                                // (this rank holds only its own rows of K^-1)
+    // finish_eval credited a whole evaluation; THIS RANK executed its share: the Cholesky in full or -- distributed -- a
+    // G-th of it, a G-th of the inverse's and of K^-1's N^3 / 3 (serpentine ownership: the ranks' shares agree within 0.5 %).  The
+    // counters of a multi-rank job are therefore per-rank EXECUTED work, and bench.py's roofline on such a line is labelled so.
+    const int G = std::max(1, h->pls.shard.size);
+    if (G > 1) {
+        const double n3 = (double)h->Np * h->Np * h->Np / 3.0;
+        h->cum.cholinv_flops = sweep0 + n3 * ((h->pls.shard.dist ? 1.0 / G : 1.0) + 1.0 / G);
+        if (want_grad) h->cum.kinv_flops = kinv0 + n3 / G;
+    }
     return rc;
 }
 

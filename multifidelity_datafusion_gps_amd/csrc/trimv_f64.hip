@@ -223,34 +223,14 @@ static inline int trimv_blocks(int nrows, int JR) {
 }
 
 // rows per wave / chunks per batch of the single-vector form: 4 rows x 2 chunks (measured at N = 8192, variance stage incl. its
-// finishing launch / append: "4 2" 0.0498 / 0.132 ms, "1 8" 0.0508 / 0.139, "2 4" 0.0555 / 0.143: profiles/r06_trimv_shapes.txt).
-// MFGP_TRIMV="JR U" selects "2 4" or "1 8" instead (lab switch, read once)
-static void trimv1_shape(int& JR, int& U) {
-    static int jr = 0, u = 0;
-    if (!jr) {
-        jr = 4; u = 2;
-        if (const char* e = getenv("MFGP_TRIMV")) {
-            int a = 0, b = 0;
-            if (sscanf(e, "%d %d", &a, &b) == 2) { jr = a; u = b; }
-        }
-    }
-    JR = jr; U = u;
-}
+// finishing launch / append: "4 2" 0.0498 / 0.132 ms, "1 8" 0.0508 / 0.139, "2 4" 0.0555 / 0.143: profiles/r06_trimv_shapes.txt)
+constexpr int TRIMV1_JR = 4, TRIMV1_U = 2;
 
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows, int ncols, int mode, int nbatch,
                    long long mstride, long long xstride, long long ystride) {
     if (nrows <= 0) return;
-    int JR, U;
-    trimv1_shape(JR, U);
-    const dim3 blk(256);
-    const int nb = nbatch > 0 ? nbatch : 1;
-#define TRIMV1(jr, u)                                                                                                     \
-    hipLaunchKernelGGL((mfgp_trimv_f64<1, jr, u>), dim3(trimv_blocks(nrows, jr), nb), blk, 0, s, M, ld, x, 0, y, 0, nrows, ncols, \
-                       mode, mstride, xstride, ystride)
-    if (JR == 1 && U == 8) TRIMV1(1, 8);
-    else if (JR == 2 && U == 4) TRIMV1(2, 4);
-    else TRIMV1(4, 2);
-#undef TRIMV1
+    hipLaunchKernelGGL((mfgp_trimv_f64<1, TRIMV1_JR, TRIMV1_U>), dim3(trimv_blocks(nrows, TRIMV1_JR), nbatch > 0 ? nbatch : 1), dim3(256), 0, s, M, ld,
+                       x, 0, y, 0, nrows, ncols, mode, mstride, xstride, ystride);
 }
 
 void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z, double* alpha, int Np, const double* logdet_part,
@@ -554,10 +534,10 @@ void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const
     const int64_t pieces = (int64_t)(Np >> 2) * 16 * RT;
     hipLaunchKernelGGL(mfgp_panel_fragments_f64, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, W, ld, Wt, Np, RT);
     const dim3 grid(Np / 16 + mean_blocks(rows)), blk(256);
-    static const int ks = getenv("MFGP_MFMA_KS") ? atoi(getenv("MFGP_MFMA_KS")) : 64;
+    // (stage width 64 columns where the W fragments of two stages fit the registers, 32 from three row tiles up)
 #define PREDV_MFMA(rt, k) hipLaunchKernelGGL((mfgp_predv_mfma_f64<rt, k>), grid, blk, 0, s, W, Wt, S, V, ld, Np, alpha, mean, rows)
     if (RT == 1) PREDV_MFMA(1, 64);
-    else if (RT == 2) { if (ks == 64) PREDV_MFMA(2, 64); else PREDV_MFMA(2, 32); }
+    else if (RT == 2) PREDV_MFMA(2, 64);
     else if (RT == 3) PREDV_MFMA(3, 32);
     else PREDV_MFMA(4, 32);
 #undef PREDV_MFMA
@@ -566,25 +546,14 @@ void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const
 void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, double* V, int ld, int Np, const double* alpha,
                        double* mean, int rows) {
     const dim3 blk(256);
-    int JR1, U1;
-    trimv1_shape(JR1, U1);
 #define TRIMVR(r, jr, u)                                                                                                  \
     hipLaunchKernelGGL((mfgp_predv_rows_f64<r, jr, u>), dim3(trimv_blocks(Np, jr) + mean_blocks(rows)), blk, 0, s, S, ld, W, V, Np, alpha, mean, rows)
-    if (R <= 1) {
-        if (JR1 == 1 && U1 == 8) TRIMVR(1, 1, 8);
-        else if (JR1 == 2 && U1 == 4) TRIMVR(1, 2, 4);
-        else TRIMVR(1, 4, 2);
-    } else if (R <= 2) TRIMVR(2, 4, 2);
+    if (R <= 1) TRIMVR(1, TRIMV1_JR, TRIMV1_U);
+    else if (R <= 2) TRIMVR(2, 4, 2);
     else if (R <= 4) TRIMVR(4, 4, 2);
-    else {
-        static const int lds = getenv("MFGP_TRIMV_LDS") ? atoi(getenv("MFGP_TRIMV_LDS")) : 1;
-#define PREDV_LDS(r, jr, nw, d)                                                                                           \
-    hipLaunchKernelGGL((mfgp_predv_rows_lds_f64<r, jr, nw, d>), dim3(Np / (nw * jr) / 2 + mean_blocks(rows)), dim3(64 * nw), 0, s, S, ld, W, V, \
-                       Np, alpha, mean, rows)
-        if (lds == 0) TRIMVR(8, 4, 2);
-        else PREDV_LDS(8, 4, 4, 2);
-#undef PREDV_LDS
-    }
+    else   // 8 rows: the W tile through LDS (measured against the register form <8, 4, 2>: 0.056 / 0.072 ms)
+        hipLaunchKernelGGL((mfgp_predv_rows_lds_f64<8, 4, 4, 2>), dim3(Np / 16 / 2 + mean_blocks(rows)), dim3(256), 0, s, S, ld, W, V, Np, alpha,
+                           mean, rows);
 #undef TRIMVR
 }
 

@@ -4,7 +4,6 @@ append -- with the GB/s of the triangle read behind each: the variance product r
 mirrored inverse once, an append reads it twice (l = X k, w = X^T l).
 
     python tools/adapt_latency.py [N ...]            (default 2048 4096 8192; N is rounded down by 64 so that appends fit)
-    MFGP_TRIMV="JR U"                                 rows per wave / chunks per batch of the single-vector product (lab)
     ADAPT_REPS=200                                    calls per figure
 
 Writes one JSON object per line (for profiles/), after the human-readable lines."""
@@ -33,7 +32,7 @@ for N in sizes:
     e.factorize(theta, 0.01)
     Np = (n0 + 127) // 128 * 128
     tri = 4.0 * Np * (Np + 1)                      # bytes of the lower part incl. the diagonal
-    rec = {"N": n0, "Np": Np, "triangle_MB": tri / 1e6, "library_build_id": build_id(), "trimv": os.environ.get("MFGP_TRIMV", "default")}
+    rec = {"N": n0, "Np": Np, "triangle_MB": tri / 1e6, "library_build_id": build_id()}
     for ns in (1, 2, 4, 8, 16, 17, 32, 64):
         Xs = Xa[:ns] + 0.01
         for _ in range(5):
