@@ -217,7 +217,7 @@ static int ensure_chain(mfgp_handle* lf, int64_t rows, int c) {
     const int d = lf->D;
     if (rows > lf->ch_rows || c > lf->ch_c || d != lf->ch_D) {   // (a handle reused at another input width re-allocates)
         HIPCHK(lf, hipStreamSynchronize(lf->stream));
-        if (lf->dXc) HIPCHK(lf, hipFree(lf->dXc));
+        // (dXc points INTO the allocation that starts at doffs: one host-to-device copy carries the stencil offsets and the base points)
         if (lf->dm) HIPCHK(lf, hipFree(lf->dm));
         if (lf->doffs) HIPCHK(lf, hipFree(lf->doffs));
         if (lf->dAug) HIPCHK(lf, hipFree(lf->dAug));
@@ -225,9 +225,10 @@ static int ensure_chain(mfgp_handle* lf, int64_t rows, int c) {
         lf->ch_rows = std::max(rows, lf->ch_rows);
         lf->ch_c = std::max(c, lf->ch_c);
         lf->ch_D = d;
-        HIPCHK(lf, hipMalloc(&lf->dXc, (size_t)lf->ch_rows * d * sizeof(double)));
+
         HIPCHK(lf, hipMalloc(&lf->dm, (size_t)lf->ch_rows * lf->ch_c * sizeof(double)));
-        HIPCHK(lf, hipMalloc(&lf->doffs, (size_t)lf->ch_c * d * sizeof(double)));
+        HIPCHK(lf, hipMalloc(&lf->doffs, ((size_t)lf->ch_c + (size_t)lf->ch_rows) * d * sizeof(double)));
+        lf->dXc = lf->doffs + (size_t)lf->ch_c * d;
         HIPCHK(lf, hipMalloc(&lf->dAug, (size_t)lf->ch_rows * (d + lf->ch_c) * sizeof(double)));
     }
     return 0;
@@ -245,23 +246,23 @@ static int chain_lf_means(mfgp_handle* lf, const double* Xhost, int64_t rows, co
     const int64_t T = rows * c;
     rc = ensure_xs(lf, (int)std::min<int64_t>(Np, (T + NB - 1) / NB * NB));
     if (rc) return rc;
-    if ((rows + c) * d <= mfgp_handle::IO_IN) {   // small batch: through pinned memory (see mfgp_predict), copies stay asynchronous
-        memcpy(lf->hio, Xhost, (size_t)rows * d * sizeof(double));
-        memcpy(lf->hio + rows * d, offs_host, (size_t)c * d * sizeof(double));
-        HIPCHK(lf, hipMemcpyAsync(lf->dXc, lf->hio, (size_t)rows * d * sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(lf, hipMemcpyAsync(lf->doffs, lf->hio + rows * d, (size_t)c * d * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rows + lf->ch_c) * d <= mfgp_handle::IO_IN) {   // small batch: through pinned memory (see mfgp_predict), ONE asynchronous copy:
+        // [stencil offsets, padded to the scratch's ch_c rows | base points] lands on [doffs | dXc], which are one allocation
+        memcpy(lf->hio, offs_host, (size_t)c * d * sizeof(double));
+        memcpy(lf->hio + (size_t)lf->ch_c * d, Xhost, (size_t)rows * d * sizeof(double));
+        HIPCHK(lf, hipMemcpyAsync(lf->doffs, lf->hio, ((size_t)lf->ch_c + (size_t)rows) * d * sizeof(double), hipMemcpyHostToDevice, s));
     } else {
         HIPCHK(lf, hipMemcpyAsync(lf->doffs, offs_host, (size_t)c * d * sizeof(double), hipMemcpyHostToDevice, s));
         HIPCHK(lf, hipMemcpyAsync(lf->dXc, Xhost, (size_t)rows * d * sizeof(double), hipMemcpyHostToDevice, s));
     }
     for (int64_t t0 = 0; t0 < T; t0 += Np) {
         const int n = (int)std::min(Np, T - t0);
-        const int n_p = (n + NB - 1) / NB * NB;
+        const int n_p = (n + 63) / 64 * 64;      // the panel kernel works in 64-row tiles (round 6: was 128 -- a one-point callback built and
+                                                 // read a 128 x N_lf panel, 16 MB at N_lf = 16384, for one row of it)
         launch_stencil_rows(s, lf->dXc, lf->doffs, d, c, t0, n, n_p, lf->dXs);
         launch_kbuild_panel(s, lf->spec, lf->dXs, n_p, lf->dX, (int)lf->N, (int)Np, lf->buf[BUF_W], (int)Np);
-        // the padded rows n..n_p of the mean land in dvec's tail, never in dm: write through dvec, then copy
-        launch_rowdot(s, lf->buf[BUF_W], (int)Np, lf->dalpha, lf->dvec, n_p, (int)Np, 2);
-        HIPCHK(lf, hipMemcpyAsync(lf->dm + t0, lf->dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        // the means of the n real rows only, straight to their place in dm
+        launch_rowdot(s, lf->buf[BUF_W], (int)Np, lf->dalpha, lf->dm + t0, n, (int)Np, 2);
         lf->launches += 3;
     }
     return 0;

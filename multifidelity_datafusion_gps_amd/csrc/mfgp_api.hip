@@ -208,7 +208,7 @@ int32_t mfgp_destroy(mfgp_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     free_mats(h);
     if (h->dXs) hipFree(h->dXs);
-    if (h->dXc) hipFree(h->dXc);
+    // (dXc lies inside the allocation that starts at doffs: api_predict.hip ensure_chain)
     if (h->dm) hipFree(h->dm);
     if (h->doffs) hipFree(h->doffs);
     if (h->dAug) hipFree(h->dAug);

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void mfgp_append_finish_f64(double* __restrict
 
 void launch_append_finish(hipStream_t s, double* L, double* S, int ld, int n, const double* l, const double* w, double* z,
                           double* alpha, double kdiag, double y_new, double* out, double* X, const double* xs_new, int D, double* Y) {
-    const int nwg = n >= 2048 ? 32 : (n >= 512 ? 8 : 1);
+    const int nwg = n >= 4096 ? 128 : (n >= 2048 ? 32 : (n >= 512 ? 8 : 1));
     hipLaunchKernelGGL(mfgp_append_finish_f64, dim3(nwg), dim3(256), 0, s, L, S, ld, n, l, w, z, alpha, kdiag, y_new, out, X,
                        xs_new, D, Y);
 }

@@ -16,7 +16,7 @@ durs = {0: [], 1: []}
 if len(sys.argv) > 2:
     for line in open(sys.argv[2]):
         f = line.split()
-        if not f or "kbuild" in f[0] or "rowdot" in f[0] or "grad" in f[0] or "finish" in f[0]:
+        if not f or "kbuild" in f[0] or "rowdot" in f[0] or "trimv" in f[0] or "grad" in f[0] or "finish" in f[0]:
             continue
         q = 0 if f[1] == "q1" else 1
         durs[q].append((f[0], int(f[4]), float(f[-2])))

@@ -63,8 +63,8 @@ def sweep_sum(rows):
     return sum(v for _, k, v in rows[kb[-2]:kb[-1]] if k in SWEEP)
 
 
-ADAPT = ("mfgp_trimv_f64", "mfgp_predv_rows_f64", "mfgp_predv_rows_lds_f64", "mfgp_predv_skinny_f64", "mfgp_predv_finish_f64",
-         "mfgp_append_finish_f64", "mfgp_kbuild_rbf2_f64<1>")
+ADAPT = ("mfgp_trimv_f64", "mfgp_predv_rows_f64", "mfgp_predv_rows_lds_f64", "mfgp_predv_mfma_f64", "mfgp_panel_fragments_f64",
+         "mfgp_predv_finish_f64", "mfgp_append_finish_f64", "mfgp_kbuild_rbf2_f64<1>")
 
 
 def short(name):
@@ -110,8 +110,8 @@ def adapt_block(n, files):
         R = None
         if k.startswith(("mfgp_trimv_f64", "mfgp_predv_rows_f64", "mfgp_predv_rows_lds_f64")):
             R = int(k.split("<")[1].split(",")[0])
-        elif k.startswith("mfgp_predv_skinny_f64"):
-            R = 16 * int(k.split("<")[1].split(">")[0])
+        elif k.startswith("mfgp_predv_mfma_f64"):
+            R = 16 * int(k.split("<")[1].split(",")[0])
         if R is not None:
             e["algorithmic_bytes"] = tri + R * 8 * Np
         if k in dur:

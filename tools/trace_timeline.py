@@ -4,7 +4,7 @@ files = glob.glob(path + "/**/*kernel_trace.csv", recursive=True)
 rows = []
 with open(files[0]) as f:
     for d in csv.DictReader(f):
-        rows.append((d['Kernel_Name'].split('(')[0].replace('mfgp::', '').replace('void ', ''), int(d['Start_Timestamp']),
+        rows.append((d['Kernel_Name'].split('(')[0].replace('mfgp::', '').replace('void ', '').replace(', ', ','), int(d['Start_Timestamp']),
                      int(d['End_Timestamp']), int(d['Grid_Size_X']) // int(d['Workgroup_Size_X']), d['Queue_Id'], d.get('Stream_Id', '')))
 rows.sort(key=lambda r: r[1])
 idx = [i for i, x in enumerate(rows) if ('kbuild_' in x[0] and '<0>' in x[0])]
