@@ -86,7 +86,7 @@ int ensure_xs(mfgp_handle* h, int rows_p) {
 // `pinned`: the results are written by the kernels straight into the handle's device-mapped pinned memory and copied to
 // mean / var by the host after the synchronisation (no device-to-host copy commands)
 static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean, double* var, int want_var,
-                         int include_noise, double* pan_ms, double* var_ms, bool pinned = false) {
+                         int include_noise, double* pan_ms, double* var_ms, int64_t* timed_rows, bool pinned = false) {
     hipStream_t s = h->stream;
     double* const mean_dev = pinned ? h->dio + mfgp_handle::IO_IN : h->dvec;
     double* const var_dev = pinned ? h->dio + mfgp_handle::IO_IN + mfgp_handle::IO_OUT : h->dvec2;
@@ -103,11 +103,12 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         rc = upload_tasks(h);
         if (rc) return rc;
     }
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[6], s));
+    const bool stamp = h->timing && (!few || h->timing_small);
+    if (stamp) HIPCHK(h, hipEventRecord(h->ev[6], s));
     if (few) {
         launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
         h->launches += 1;
-        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
+        if (stamp) HIPCHK(h, hipEventRecord(h->ev[7], s));
         if (want_var) {
             h->kinv_valid = false;  // V overwrites the K^-1 storage
             if (rows <= 8) {     // (measured at N = 8192, 16 rows: 0.080 ms on the VALU, 0.068 on the matrix pipe; 8 rows: 0.063 / 0.067)
@@ -126,7 +127,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
             launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, mean_dev, (int)rows, (int)Np, 2);
             h->launches += 1;
         }
-        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[8], s));
+        if (stamp) HIPCHK(h, hipEventRecord(h->ev[8], s));
         if (!pinned) {
             HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
             if (want_var) HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -135,7 +136,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         launch_kbuild_panel(s, h->spec, h->dXs, rows_p, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
         launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, mean_dev, rows_p, (int)Np, 2);
         h->launches += 2;
-        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[7], s));
+        if (stamp) HIPCHK(h, hipEventRecord(h->ev[7], s));
         if (!pinned) HIPCHK(h, hipMemcpyAsync(mean, h->dvec, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
         if (want_var) {
             h->kinv_valid = false;  // V overwrites the K^-1 storage
@@ -143,7 +144,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
             launch_rowsumsq(s, h->buf[BUF_A], (int)Np, h->dvec2, rows_p, (int)Np);
             launch_finish_var(s, h->spec, h->dvec2, var_dev, rows_p, include_noise ? h->noise : 0.0);
             h->launches += 2;
-            if (h->timing) HIPCHK(h, hipEventRecord(h->ev[8], s));
+            if (stamp) HIPCHK(h, hipEventRecord(h->ev[8], s));
             if (!pinned) HIPCHK(h, hipMemcpyAsync(var, h->dvec2, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
         }
     }
@@ -153,14 +154,15 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         memcpy(mean, h->hio + mfgp_handle::IO_IN, (size_t)rows * sizeof(double));
         if (want_var) memcpy(var, h->hio + mfgp_handle::IO_IN + mfgp_handle::IO_OUT, (size_t)rows * sizeof(double));
     }
-    if (h->timing) {
+    if (stamp) {
         *pan_ms += ev_ms(h->ev[6], h->ev[7]);
         if (want_var) *var_ms += ev_ms(h->ev[7], h->ev[8]);
+        *timed_rows += rows;
     }
     return 0;
 }
 
-static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double var_ms, bool want_var) {
+static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double var_ms, bool want_var, int64_t timed_rows) {
     h->tm.predict_panel_ms = pan_ms;
     h->tm.predict_var_ms = var_ms;
     h->cum.predicts += 1;
@@ -170,9 +172,9 @@ static void predict_account(mfgp_handle* h, int64_t Nstar, double pan_ms, double
     h->cum.predict_var_ms += var_ms;
     if (want_var) {
         h->cum.predict_var_flops += (double)h->Np * (double)h->Np * (double)Nstar;      // the work, timed or not
-        if (h->timing) h->cum.timed_predict_var_flops += (double)h->Np * (double)h->Np * (double)Nstar;
+        h->cum.timed_predict_var_flops += (double)h->Np * (double)h->Np * (double)timed_rows;    // (the rows whose launches were stamped)
     }
-    h->tm.timed = h->timing ? (h->tm.timed | 1) : h->tm.timed;
+    h->tm.timed = timed_rows > 0 ? (h->tm.timed | 1) : h->tm.timed;
     h->tm.n_launches = h->launches;
 }
 
@@ -188,6 +190,7 @@ int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double*
     const int D = h->D;
     const int64_t Np = h->Np;
     double pan_ms = 0, var_ms = 0;
+    int64_t timed_rows = 0;
     h->launches = 0;
     for (int64_t r0 = 0; r0 < Nstar; r0 += Np) {
         const int64_t rows = std::min(Np, Nstar - r0);
@@ -205,10 +208,10 @@ int32_t mfgp_predict(mfgp_handle* h, const double* Xstar, int64_t Nstar, double*
             HIPCHK(h, hipMemcpyAsync(h->dXs, Xstar + r0 * D, (size_t)rows * D * sizeof(double), hipMemcpyHostToDevice, s));
         }
         rc = predict_chunk(h, rows, rows_p, mean + r0, want_var ? var + r0 : nullptr, want_var, include_noise, &pan_ms,
-                           &var_ms, pinned);
+                           &var_ms, &timed_rows, pinned);
         if (rc) return rc;
     }
-    predict_account(h, Nstar, pan_ms, var_ms, want_var != 0);
+    predict_account(h, Nstar, pan_ms, var_ms, want_var != 0, timed_rows);
     return 0;
 }
 
@@ -315,6 +318,7 @@ int32_t mfgp_predict_chained(mfgp_handle* h, mfgp_handle* lf, const double* Xsta
     const int d = lf->D, D = h->D;
     const int64_t Np = h->Np;
     double pan_ms = 0, var_ms = 0;
+    int64_t timed_rows = 0;
     h->launches = 0;
     lf->launches = 0;
     for (int64_t r0 = 0; r0 < Nstar; r0 += Np) {
@@ -333,10 +337,10 @@ int32_t mfgp_predict_chained(mfgp_handle* h, mfgp_handle* lf, const double* Xsta
         h->launches += lf->launches + 1;
         lf->launches = 0;
         rc = predict_chunk(h, rows, rows_p, mean + r0, want_var ? var + r0 : nullptr, want_var, include_noise, &pan_ms,
-                           &var_ms, rows_p <= mfgp_handle::IO_OUT);
+                           &var_ms, &timed_rows, rows_p <= mfgp_handle::IO_OUT);
         if (rc) return rc;
     }
-    predict_account(h, Nstar, pan_ms, var_ms, want_var != 0);
+    predict_account(h, Nstar, pan_ms, var_ms, want_var != 0, timed_rows);
     return 0;
 }
 

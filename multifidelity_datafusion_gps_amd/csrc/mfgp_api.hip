@@ -281,7 +281,11 @@ int32_t mfgp_set_data(mfgp_handle* h, const double* X, int64_t N, int32_t D, con
     // no timing events at all below that size unless asked for (MFGP_TIMING=1: start / end stamps only): an optimiser never
     // reads them, and the two records of an evaluation (three of a predict) are ~7 us of the ~56 (~80) us a small one takes
     h->timing = h->stage_timing;
-    if (const char* e = getenv("MFGP_TIMING")) h->timing = h->timing || atoi(e) != 0;
+    h->timing_small = false;        // ... and a predict of <= 64 rows (~80 us at N = 8192, three records ~6.5 us of it) is stamped only on request
+    if (const char* e = getenv("MFGP_TIMING")) {
+        h->timing = h->timing || atoi(e) != 0;
+        h->timing_small = atoi(e) != 0;
+    }
     HIPCHK(h, hipMemsetAsync(h->dX, 0, (size_t)Np * D * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->dY, 0, (size_t)Np * sizeof(double), h->stream));
     HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, h->stream));

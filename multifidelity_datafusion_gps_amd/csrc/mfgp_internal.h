@@ -177,6 +177,7 @@ struct mfgp_handle {
     int* hinfo = nullptr;    // pinned
     bool stage_timing = true; // per-stage event stamps inside an evaluation (off below Np = 4096 unless MFGP_STAGE_TIMING=1; mfgp_timings.timed says what a call measured)
     bool timing = true;          // any timing events at all (start / end of an evaluation, of a predict)
+    bool timing_small = false;   // ... also around a predict of <= 64 test rows (MFGP_TIMING=1 only: the records are ~8 % of such a call)
     mfgp::Plan pl;                  // factorisation / inverse / K^-1 / predictive-variance launch lists (plan.cpp)
     mfgp::KernSpecDev spec{};
     bool have_kernel = false, have_data = false, factorized = false, kinv_valid = false, grad_valid = false,

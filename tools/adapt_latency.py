@@ -46,10 +46,10 @@ for N in sizes:
         dt = (time.perf_counter() - t0) / REPS * 1e3
         pan /= REPS; var /= REPS
         print("N=%5d N*=%3d  %.4f ms per predict call (panel %.4f, variance stage %.4f ms = %.2f TB/s of triangle)"
-              % (n0, ns, dt, pan, var, tri / (var * 1e-3) / 1e12), flush=True)
+              % (n0, ns, dt, pan, var, tri / (var * 1e-3) / 1e12 if var > 0 else 0.0), flush=True)
         rec["predict_call_ms_nstar%d" % ns] = round(dt, 5)
         rec["variance_stage_ms_nstar%d" % ns] = round(var, 5)
-        rec["variance_stage_TBps_nstar%d" % ns] = round(tri / (var * 1e-3) / 1e12, 3)
+        rec["variance_stage_TBps_nstar%d" % ns] = round(tri / (var * 1e-3) / 1e12, 3) if var > 0 else None      # (MFGP_TIMING=0: no stamps)
     # appends: 48 of the 64 slots, each timed by the host clock around the call (the call ends synchronised)
     ts = []
     for i in range(48):
