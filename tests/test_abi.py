@@ -126,9 +126,13 @@ def test_the_planners_rule_for_distributing_the_cholesky_is_arithmetic_on_a_meas
 
     assert pays(128, 8, 0.0)[0] == 0                       # no measurement: replicated, whatever the size
     assert pays(256, 8, -1.0)[0] == 0
+    # collectives on the chain, one exchange per block column inside a macro panel: nblk - 1 all-gathers + one broadcast per macro
+    # panel (5 block columns per macro from 80 block columns, 4 from 56): 153 at N = 16384, 79 at N = 8192, 307 at N = 32768
     yes, saving, cost = pays(128, 8, 20.0)                 # N = 16384 on 8 ranks, 20 us per collective
-    assert yes == 1 and abs(saving - 0.875 * 16384.0 ** 3 / 3 / 60e12 * 1e3) < 1e-9 and abs(cost - 255 * 20e-3) < 1e-12
-    assert pays(128, 8, 100.0)[0] == 0                     # ... at 100 us the 255 collectives cost more than they save
-    assert pays(64, 8, 20.0)[0] == 0 and pays(64, 8, 10.0)[0] == 1      # N = 8192: break-even between 10 and 20 us
+    assert yes == 1 and abs(saving - 0.875 * 16384.0 ** 3 / 3 / 60e12 * 1e3) < 1e-9 and abs(cost - 153 * 20e-3) < 1e-12
+    assert pays(128, 8, 150.0)[0] == 0                     # ... at 150 us the 153 collectives cost more than they save
+    _, _, cost64 = pays(64, 8, 30.0)
+    assert abs(cost64 - 79 * 30e-3) < 1e-12
+    assert pays(64, 8, 30.0)[0] == 0 and pays(64, 8, 20.0)[0] == 1      # N = 8192: break-even between 20 and 30 us
     assert pays(64, 1, 1.0)[0] == 0                        # a group of one has nothing to distribute
     assert pays(256, 2, 100.0)[0] == 1 and pays(64, 2, 100.0)[0] == 0   # two ranks over a slow transport: only the large size
