@@ -564,10 +564,19 @@ __global__ __launch_bounds__(256) void mfgp_predv_finish_f64(const double* __res
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* v = V + (int64_t)i * ld;
     double sv = 0.0;
-    for (int k = 2 * tid; k < Np; k += 512) {
-        const d2_t c = *reinterpret_cast<const d2_t*>(v + k);
-        sv = __builtin_fma(c.x, c.x, sv);
-        sv = __builtin_fma(c.y, c.y, sv);
+    for (int k0 = 2 * tid; k0 < Np; k0 += 512 * 8) {       // (Np is a multiple of 128: a chunk of 512 columns is whole or absent)
+        d2_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                        // eight loads in flight, not a chain of Np / 512 round trips
+            const int k = k0 + 512 * u;
+            c[u] = *reinterpret_cast<const d2_t*>(v + min(k, Np - 2));
+            if (k >= Np) c[u] = (d2_t){0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            sv = __builtin_fma(c[u].x, c[u].x, sv);
+            sv = __builtin_fma(c[u].y, c[u].y, sv);
+        }
     }
     sv = wave_sum_f64(sv);
     if (lane == 0) red[wave] = sv;
