@@ -103,3 +103,61 @@ def test_beyond_the_baseline_sizes_n32768(engine_cls):
     (n0, g0), (n1, g1) = got
     assert np.isfinite(n0) and n0 == pytest.approx(n1, rel=1e-12)
     np.testing.assert_allclose(g0, g1, rtol=0, atol=1e-10 * np.abs(g1).max())
+
+
+_SWITCH_DRIVER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from multifidelity_datafusion_gps_amd._lib import Engine
+from tests import cases
+rng = np.random.default_rng(5)
+N = 700
+X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
+Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+e = Engine(0)
+e.set_data(Xa, Y); e.set_kernel(cases.composite(4, 1))
+theta, noise = np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+nlml, grad = e.eval(theta, noise, 1e-8)
+Xs = rng.uniform(size=(40, 5))
+out = {"nlml": nlml, "grad": grad.tolist()}
+for ns in (1, 5, 20, 40):
+    m, v = e.predict(Xs[:ns])
+    out["m%d" % ns] = m.tolist(); out["v%d" % ns] = v.tolist()
+e.close()
+print(json.dumps(out))
+"""
+
+
+def test_process_wide_switches_in_a_process_of_their_own():
+    """MFGP_SKINNY=0 (every predict through the padded tile GEMM) and MFGP_KBUILD_FAST=0 (the generic covariance / gradient kernels for
+    the structures the fast paths cover) are read once per process: a child process under both switches evaluates and predicts
+    (1, 5, 20 and 40 test rows: the sizes of the VALU and matrix-pipe forms) the same problem as a child under the defaults, and
+    both agree with the oracle at the stated tolerances."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for name, env in (("default", {}), ("switched", {"MFGP_SKINNY": "0", "MFGP_KBUILD_FAST": "0"})):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_DRIVER, root], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    rng = np.random.default_rng(5)
+    N = 700
+    X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
+    Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+    parts, theta, noise = cases.composite(4, 1), np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var()
+    st = orc.inference(parts, theta, noise, Xa, Y)
+    Xs = rng.uniform(size=(40, 5))
+    mu, var = orc.predict_stable(parts, theta, noise, Xa, st, Xs)
+    for name, o in runs.items():
+        tol.check_nlml(o["nlml"], st["nlml"])
+        tol.check_grad(np.array(o["grad"]), st["grad"])
+        for ns in (1, 5, 20, 40):
+            tol.check_pred(np.array(o["m%d" % ns]), mu[:ns], np.abs(Y).max(), what="mean")
+            tol.check_pred(np.array(o["v%d" % ns]), var[:ns], np.abs(Y).max(), what="var")
+    for ns in (1, 5, 20, 40):     # the two routes differ in the order of their sums only
+        np.testing.assert_allclose(runs["default"]["v%d" % ns], runs["switched"]["v%d" % ns], rtol=0, atol=1e-12)
