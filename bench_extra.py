@@ -88,7 +88,9 @@ def cfg3_cfg5(mf, evals=20):
     n_lf, n_hf = 16384, 4096
     X_lf = rng.uniform(size=(n_lf, 4)); X_hf = rng.uniform(size=(n_hf, 4)); Xs = rng.uniform(size=(4096, 4))
     t0 = time.perf_counter()
-    m = BudgetNARGP(4, _hf_4d, None, lf_X=X_lf, lf_Y=_lf_4d(X_lf), seed=2)
+    # (lf_hf_adapt_ratio = 0: the acquisitions below grow the high-fidelity set only -- the low-fidelity level keeps its 16384 rows -- while
+    # predictions stay on the data-driven path with the level hand-over on the device)
+    m = BudgetNARGP(4, _hf_4d, None, lf_X=X_lf, lf_Y=_lf_4d(X_lf), lf_hf_adapt_ratio=0, seed=2)
     t1 = time.perf_counter()
     m.fit(X_hf)                                                               # first fit on these handles: plans, slabs
     t2 = time.perf_counter()
@@ -110,7 +112,6 @@ def cfg3_cfg5(mf, evals=20):
     n8 = 8192 - 64
     m.eval_cap = m.lf_max_iters = m.first_run_max_iters = m.restart_max_iters = 2     # a token fit: the acquisition is what is timed
     m.num_restarts = 1
-    m.data_driven_lf_approach = False
     m.eps = 0.0                                                                         # never stop early
     m.fit(rng.uniform(size=(n8, 4)))
     Np = 8192

@@ -93,9 +93,8 @@ lvl2.close(); lvl3.close()
 n_lf, n0, steps = (1024, 128, 3) if args.quick else (16384, 512, 4)
 rng = np.random.default_rng(4)
 X_lf = rng.uniform(size=(n_lf, 4))
-m = BudgetNARGP(4, col(cases.hf_4d), None, lf_X=X_lf, lf_Y=col(cases.lf_4d)(X_lf), seed=5,
-                adapt_maximizer=mf.DIRECT1Maximizer())
-m.data_driven_lf_approach = False   # adapt only the HF level (the reference's LF adaptation is unreachable)
+m = BudgetNARGP(4, col(cases.hf_4d), None, lf_X=X_lf, lf_Y=col(cases.lf_4d)(X_lf), lf_hf_adapt_ratio=0, seed=5,
+                adapt_maximizer=mf.DIRECT1Maximizer())      # ratio 0: adapt only the HF level (the reference's LF adaptation is unreachable)
 m.fit(rng.uniform(size=(n0, 4)))
 t0 = time.perf_counter()
 m.adapt(steps)
