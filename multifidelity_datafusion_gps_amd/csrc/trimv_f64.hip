@@ -3,8 +3,15 @@
 //     V[i][j] = sum_{k in range(j)} W[i][k] * M[j][k]        i < R right-hand sides, j < nrows
 //     range(j):  mode 0: k <= j (lower part)   mode 1: j <= k < ncols (upper part)   mode 2: k < ncols
 //
+// What is in this file (round 6; everything the adaptation loop of src/abstractMFGP.py:317-359 calls between two refits):
+//   trimv_wave / mfgp_trimv_f64          the body: R <= 4 right-hand sides on the VALU (launch_rowdot: R = 1)
+//   mfgp_alpha_finish_f64                alpha = X^T z + the solve's scalars in one launch
+//   mfgp_predv_rows_f64 / _lds_f64       predict with <= 8 test rows: the variance product + the means in one launch
+//   mfgp_panel_fragments_f64, mfgp_predv_mfma_f64   9 .. 64 test rows: the same product on the matrix pipe, S streamed through LDS
+//   mfgp_predv_finish_f64                var = max(k** - |V|^2, 1e-15) + noise, one workgroup per test row
+//
 // One kernel body serves every O(N^2) pass of the path: z = X y and alpha = X^T z behind GPy's dpotrs (a5), the
-// predictive mean K(X*,X) alpha and -- R <= 16 test rows, the N* = 1 callback of the reference's DIRECT maximiser
+// predictive mean K(X*,X) alpha and -- few test rows, the N* = 1 callback of the reference's DIRECT maximiser
 // (src/adaptation_maximizers/scipydirect_wrapper.py:22-24) -- the variance product V = K(X*,X) X^T (a11), and the two passes
 // l = X k, w = X^T l of a rank-1 append (8(f1)).  Each is bound by ONE read of the 4 Np^2-byte triangle of the mirrored inverse
 // S = X + X^T - diag, so the only thing that matters is the shape of the reads:
