@@ -93,10 +93,12 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     const int64_t Np = h->Np;
     int rc;
     // <= 64 test rows (the DIRECT callback / acquisition case): bandwidth-bound products instead of a padded tile GEMM, all in
-    // trimv_f64.hip -- up to 8 rows on the VALU behind one coalesced read of the triangle, 9 .. 64 rows on the matrix pipe with S
-    // streamed through LDS in the same coalesced shape; either way: panel, product (+ the means), ONE finishing launch
+    // trimv_f64.hip -- a few rows on the VALU behind one coalesced read of the triangle, up to 64 rows on the matrix pipe with S
+    // staged in the same coalesced shape (through registers from Np = 3072, by LDS-DMA below); either way: panel, product (+ the
+    // means), ONE finishing launch.  MFGP_PREDV2=0 keeps the matrix-pipe products on the LDS-DMA form at every size.
     static const bool skinny_on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
     const bool few = skinny_on && rows <= 64;
+    static const bool predv2_on = !(getenv("MFGP_PREDV2") && atoi(getenv("MFGP_PREDV2")) == 0);
     if (want_var && !few && h->pl.predv_rows != rows_p) {
         // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
         plan_predv(h->pl, rows_p);
@@ -111,18 +113,28 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
         if (stamp) HIPCHK(h, hipEventRecord(h->ev[7], s));
         if (want_var) {
             h->kinv_valid = false;  // V overwrites the K^-1 storage
-            if (rows <= 8) {     // (measured at N = 8192, 16 rows: 0.080 ms on the VALU, 0.068 on the matrix pipe; 8 rows: 0.063 / 0.067)
+            // up to 4 rows on the VALU; 5 .. 8 too below Np = 2048, from there the 16-row matrix-pipe forms are faster than the 8-row
+            // VALU form (variance stage, ms, 8 rows VALU / 16 rows matrix pipe: Np = 2048 0.018 / 0.016, 3072 0.024 / 0.016,
+            // 4096 0.028 / 0.023, 8192 0.060 / 0.054; 4 rows VALU: 0.014, 0.017, 0.020, 0.055)
+            const double kss = prior_variance(h), add = include_noise ? h->noise : 0.0;
+            if (rows <= 4 || (rows <= 8 && Np < 2048)) {
                 const int R = rows <= 1 ? 1 : (rows <= 2 ? 2 : (rows <= 4 ? 4 : 8));
                 launch_predv_rows(s, R, h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np, h->dalpha, mean_dev, (int)rows);
+                launch_predv_finish(s, (int)rows, h->buf[BUF_A], (int)Np, (int)Np, kss, add, var_dev);
+                h->launches += 2;
+            } else if (predv2_on && predv_mfma2_pays((int)rows, (int)Np)) {
+                // the register-staged form: partial planes per share of the triangle, summed by its own finishing launch
+                launch_predv_mfma2(s, (int)((rows + 15) / 16), h->buf[BUF_W], h->buf[BUF_S], h->buf[BUF_A], (int)Np, (int)Np,
+                                   h->dalpha, mean_dev, (int)rows);
+                launch_predv_finish_planes(s, (int)rows, h->buf[BUF_A], (int)Np, (int)Np, kss, add, var_dev);
+                h->launches += 2;
             } else {
                 // (the fragment-ordered copy of the panel: rows 64 .. 127 of the workspace matrix, which holds the 64-row panel)
                 launch_predv_mfma(s, (int)((rows + 15) / 16), h->buf[BUF_W], h->buf[BUF_W] + 64 * Np, h->buf[BUF_S], h->buf[BUF_A],
                                   (int)Np, (int)Np, h->dalpha, mean_dev, (int)rows);
-                h->launches += 1;
+                launch_predv_finish(s, (int)rows, h->buf[BUF_A], (int)Np, (int)Np, kss, add, var_dev);
+                h->launches += 3;
             }
-            launch_predv_finish(s, (int)rows, h->buf[BUF_A], (int)Np, (int)Np, prior_variance(h), include_noise ? h->noise : 0.0,
-                                var_dev);
-            h->launches += 2;
         } else {
             launch_rowdot(s, h->buf[BUF_W], (int)Np, h->dalpha, mean_dev, (int)rows, (int)Np, 2);
             h->launches += 1;

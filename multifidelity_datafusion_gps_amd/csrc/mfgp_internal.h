@@ -59,6 +59,10 @@ void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const
                        const double* alpha, double* mean, int rows);
 //   and their finish, one workgroup per test row: var[i] = max(kss - |V[i]|^2, 1e-15) + add
 void launch_predv_finish(hipStream_t s, int rows, const double* V, int ld, int Np, double kss, double add, double* var);
+void launch_predv_mfma2(hipStream_t s, int RT, const double* W, const double* S, double* Vp, int ld, int Np,
+                        const double* alpha, double* mean, int rows);
+bool predv_mfma2_pays(int rows, int Np);
+void launch_predv_finish_planes(hipStream_t s, int rows, const double* Vp, int ld, int Np, double kss, double add, double* var);
 
 // leaf: Cholesky + inverse of the 128x128 diagonal block `blk` of A (ld), in LDS.
 //   L block (zeros above diag) -> Lout[blk,blk];  X = L^-1 -> S[blk,blk] stored mirrored (X + X^T - diag)

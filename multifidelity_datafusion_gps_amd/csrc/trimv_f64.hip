@@ -7,7 +7,9 @@
 //   trimv_wave / mfgp_trimv_f64          the body: R <= 4 right-hand sides on the VALU (launch_rowdot: R = 1)
 //   mfgp_alpha_finish_f64                alpha = X^T z + the solve's scalars in one launch
 //   mfgp_predv_rows_f64 / _lds_f64       predict with <= 8 test rows: the variance product + the means in one launch
-//   mfgp_panel_fragments_f64, mfgp_predv_mfma_f64   9 .. 64 test rows: the same product on the matrix pipe, S streamed through LDS
+//   mfgp_panel_fragments_f64, mfgp_predv_mfma_f64   9 .. 64 test rows below Np = 3072: the same product on the matrix pipe, S by LDS-DMA
+//   mfgp_predv_mfma2_f64, mfgp_predv_finish_planes_f64   9 .. 64 test rows from Np = 3072: S and a shared W tile staged through registers,
+//                                        equal shares of the triangle per workgroup, partial planes summed by the finish
 //   mfgp_predv_finish_f64                var = max(k** - |V|^2, 1e-15) + noise, one workgroup per test row
 //
 // One kernel body serves every O(N^2) pass of the path: z = X y and alpha = X^T z behind GPy's dpotrs (a5), the
@@ -28,6 +30,7 @@
 // are clamped to it for the ADDRESS (an L1 hit) and masked out by their intended k.
 //
 // Requirements: ld, ldw >= the column count rounded up to 128 (every matrix / vector of the engine is padded to Np).
+#include <type_traits>
 #include "mfgp_internal.h"
 
 namespace mfgp {
@@ -548,6 +551,232 @@ void launch_predv_mfma(hipStream_t s, int RT, const double* W, double* Wt, const
     else if (RT == 3) PREDV_MFMA(3, 32);
     else PREDV_MFMA(4, 32);
 #undef PREDV_MFMA
+}
+
+// ---- the register-staged form of the same product (9 .. 64 test rows from Np = 3072: predv_mfma2_pays) --------------------------
+// In the kernel above every wave fetches its own copy of the W fragments from L2 (RT x the bytes of S), a workgroup is one 16-row
+// block (its waves split the block's stages and meet through LDS), and the panel is re-laid in a launch of its own.  Here:
+//   * a workgroup = four waves = four 16-row blocks of S (64 consecutive rows) that walk the SAME 32-column stages in step, so
+//     the stage's W tile (RT x 16 rows x 32 columns) is fetched ONCE per workgroup -- each wave a quarter, straight from the
+//     row-major panel: an instruction = 4 rows x 256 contiguous bytes, the full-rate shape, no re-laid copy -- and shared in LDS;
+//   * S and the W quarter are register loads in that coalesced shape issued P stages ahead; the compiler's own counted
+//     s_waitcnt vmcnt retires exactly one stage per step, nothing else shares the counter (no LDS-DMA);
+//   * LDS is a transposition buffer only: 4 KiB per wave for S (own wave: no barrier), 2 x RT x 4 KiB for the W tile (written
+//     for stage s + 1 while stage s is consumed: one barrier per stage), 16-byte chunks XOR-swizzled by the row as above;
+//   * the triangle is cut into equal shares: with the (group, stage) pairs in one line (group G has 2 G + 2 stages), workgroup b
+//     takes L consecutive stages [b L, (b + 1) L) -- every workgroup the same number of bytes and of MFMAs, two resident per
+//     CU, no reduction between waves -- and writes one partial 64-column tile per group it touches into plane (b - first
+//     workgroup of the group); the finishing launch adds a column's planes in that fixed order (deterministic) before it squares.
+// What bounds it (profiles/r06_adapt_sq.txt): the issue rate of v_mfma_f64_16x16x4 (64 busy cycles, one per ~100: gemm_f64.hip's
+// header) -- 64 test rows are 4.3 GFLOP = 0.086 ms at that rate against 0.085 measured for the launch, 32 rows 0.043 against
+// 0.054; the read of S alone is 0.046.  Four stages ahead instead of two measured the same or slower, and so did the
+// v_mfma_f64_4x4x4_4b form in this kernel (S fragment rotated by four LDS reads: 0.084 / 0.123 ms at 32 / 64 rows; by DPP
+// row_ror: 0.080 / 0.117; the 16x16x4 form then: 0.070 / 0.102) -- the rotations cost more issue slots than the shape saves.
+template <int RT, int P>
+__global__ __launch_bounds__(256, 2) void mfgp_predv_mfma2_f64(const double* __restrict__ W, const double* __restrict__ S,
+                                                               double* __restrict__ Vp, int ld, int Np, const double* __restrict__ alpha,
+                                                               double* __restrict__ mean, int rows, int L) {
+    static_assert(P == 2 || P == 4, "the W tile's buffer index is the parity of the step");
+    constexpr int WT_B = RT * 4096;              // bytes of a stage's W tile
+    __shared__ __attribute__((aligned(1024))) char lds[2 * WT_B + 4 * 4096];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nmean = ((rows + 1) / 2 + 3) / 4;
+    if ((int)blockIdx.x < nmean) {
+        predv_mean_block(W, ld, alpha, mean, rows, Np, blockIdx.x, wave, lane);
+        return;
+    }
+    const int b = (int)blockIdx.x - nmean;
+    const int NG = Np >> 6;
+    const int T = NG * (NG + 1);                 // stages of the whole triangle: group G holds stages G (G + 1) .. (G + 1)(G + 2) - 1
+    int lin = b * L;                             // first stage of this workgroup, in the line
+    const int lin_end = min(lin + L, T);
+    int G = (int)((sqrt(4.0 * (double)lin + 1.0) - 1.0) * 0.5);
+    while (G * (G + 1) > lin) --G;
+    while ((G + 1) * (G + 2) <= lin) ++G;
+    char* const Tb = lds + 2 * WT_B + wave * 4096;
+    const int r = lane & 15, q = lane >> 4;
+    const int plane = 64 * ld;                   // doubles between two planes
+
+    while (lin < lin_end) {
+        const int g_lo = G * (G + 1);
+        const int s_lo = lin - g_lo, s_hi = min(lin_end - g_lo, 2 * G + 2);   // stages [s_lo, s_hi) of group G
+        const int n = s_hi - s_lo;
+        const int j0 = 64 * G + 16 * wave;
+        const double* const Srow = S + (int64_t)(j0 + q) * ld + 2 * r;       // lane (row q of an instruction's four, chunk r)
+        // this wave's quarter of a tile, instruction 0: rows 4 (wave RT + v) + q of the row-major panel, chunk r
+        const double* const Wsh = W + (int64_t)(4 * wave * RT + q) * ld + 2 * r;
+        d2_t sS[P][4], sW[P][RT];
+        auto issue = [&](int st, d2_t (&xs)[4], d2_t (&xw)[RT]) {             // S of stage st, W quarter of stage st + 1
+            const int a = min(st, s_hi - 1), aw = min(st + 1, s_hi - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xs[u] = *reinterpret_cast<const d2_t*>(Srow + (int64_t)(4 * u) * ld + 32 * a);
+#pragma unroll
+            for (int v = 0; v < RT; ++v) xw[v] = *reinterpret_cast<const d2_t*>(Wsh + (int64_t)(4 * v) * ld + 32 * aw);
+        };
+        auto put_w = [&](int buf, const d2_t (&xw)[RT]) {
+#pragma unroll
+            for (int v = 0; v < RT; ++v) {
+                const int row = 4 * (wave * RT + v) + q;
+                *reinterpret_cast<d2_t*>(lds + buf * WT_B + row * 256 + ((r ^ (row & 15)) << 4)) = xw[v];
+            }
+        };
+        double acc[RT][4];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] = 0.0;
+        {   // the first stage's W tile, then P stages of requests
+            d2_t w0[RT];
+#pragma unroll
+            for (int v = 0; v < RT; ++v) w0[v] = *reinterpret_cast<const d2_t*>(Wsh + (int64_t)(4 * v) * ld + 32 * s_lo);
+            __builtin_amdgcn_sched_barrier(0);   // (first in the queue: its wait leaves the P stages in flight)
+#pragma unroll
+            for (int k = 0; k < P; ++k) {        // in THIS order: set 0 oldest, as it is on the loop's back edge
+                issue(s_lo + k, sS[k], sW[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            put_w(0, w0);
+        }
+        __syncthreads();
+        // one step; KK = k mod P names the register set.  (The k loop below has ONE exit: with an exit inside the unrolled body
+        // the compiler routes it through the loop's latch, and its wait-count bookkeeping then merges "one step since set 0 was
+        // requested" into the loop header -- an s_waitcnt vmcnt(0) every P steps.)
+        auto step = [&](auto KK, int k) {
+            constexpr int kk = decltype(KK)::value;
+            const int st = s_lo + k;
+            // into LDS: this wave's stage of S, its quarter of the NEXT stage's W tile
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = 4 * u + q;
+                *reinterpret_cast<d2_t*>(Tb + row * 256 + ((r ^ row) << 4)) = sS[kk][u];
+            }
+            put_w((kk + 1) & 1, sW[kk]);
+            issue(st + P, sS[kk], sW[kk]);
+            // the stage: lane (r, q) multiplies k = 16 c + 4 q + m of row j0 + r (v_mfma_f64_16x16x4, the fragment order of the
+            // kernel above)
+            const int kb = 32 * st;
+            const bool diag = kb + 32 > j0;
+            const char* const wt = lds + (kk & 1) * WT_B;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int s0 = 8 * c + 2 * q;
+                d2_t b0 = *reinterpret_cast<const d2_t*>(Tb + r * 256 + ((s0 ^ r) << 4));
+                d2_t b1 = *reinterpret_cast<const d2_t*>(Tb + r * 256 + (((s0 + 1) ^ r) << 4));
+                if (diag) {
+                    const int kx = kb + 16 * c + 4 * q, j = j0 + r;
+                    if (kx + 0 > j) b0[0] = 0.0;
+                    if (kx + 1 > j) b0[1] = 0.0;
+                    if (kx + 2 > j) b1[0] = 0.0;
+                    if (kx + 3 > j) b1[1] = 0.0;
+                }
+                const double bv[4] = {b0[0], b0[1], b1[0], b1[1]};
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const d2_t a0 = *reinterpret_cast<const d2_t*>(wt + (16 * i + r) * 256 + ((s0 ^ r) << 4));
+                    const d2_t a1 = *reinterpret_cast<const d2_t*>(wt + (16 * i + r) * 256 + (((s0 + 1) ^ r) << 4));
+                    d4_t d = (d4_t){acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], bv[0], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], bv[1], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], bv[2], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], bv[3], d, 0, 0, 0);
+                    acc[i][0] = d[0]; acc[i][1] = d[1]; acc[i][2] = d[2]; acc[i][3] = d[3];
+                }
+            }
+            __syncthreads();     // the next stage's W tile is complete; this stage's is free
+        };
+        const int nfull = n - n % P;
+        for (int k0 = 0; k0 < nfull; k0 += P) {
+            step(std::integral_constant<int, 0>{}, k0);
+            step(std::integral_constant<int, 1>{}, k0 + 1);
+            if constexpr (P > 2) {
+                step(std::integral_constant<int, 2>{}, k0 + 2);
+                step(std::integral_constant<int, 3>{}, k0 + 3);
+            }
+        }
+        if (nfull < n) step(std::integral_constant<int, 0>{}, nfull);
+        if (nfull + 1 < n) step(std::integral_constant<int, 1>{}, nfull + 1);
+        if constexpr (P > 2)
+            if (nfull + 2 < n) step(std::integral_constant<int, 2>{}, nfull + 2);
+        // the partial tile of this (group, workgroup): plane = workgroups since the group's first
+        double* const out = Vp + (int64_t)(b - g_lo / L) * plane + j0 + r;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[(int64_t)(i * 16 + q + 4 * e) * ld] = acc[i][e];
+        lin = g_lo + s_hi;
+        ++G;
+    }
+}
+
+// its finish, one workgroup per test row:  var[i] = max(kss - sum_j (sum_p Vp[p][i][j])^2, 1e-15) + add, the planes of a column's
+// group in their fixed order
+__global__ __launch_bounds__(1024) void mfgp_predv_finish_planes_f64(const double* __restrict__ Vp, int ld, int Np, int L, double kss,
+                                                                     double add, double* __restrict__ var) {
+    __shared__ double red[16];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t plane = (int64_t)64 * ld;
+    const double* v = Vp + (int64_t)i * ld;
+    double sv = 0.0;
+    for (int j = 2 * tid; j < Np; j += 2048) {
+        const int G = j >> 6;
+        const int cnt = ((G + 1) * (G + 2) - 1) / L - (G * (G + 1)) / L + 1;
+        d2_t t = (d2_t){0.0, 0.0};
+        for (int p0 = 0; p0 < cnt; p0 += 8) {
+            d2_t c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c[u] = *reinterpret_cast<const d2_t*>(v + (int64_t)min(p0 + u, cnt - 1) * plane + j);
+                if (p0 + u >= cnt) c[u] = (d2_t){0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += c[u];
+        }
+        sv = __builtin_fma(t.x, t.x, sv);
+        sv = __builtin_fma(t.y, t.y, sv);
+    }
+    sv = wave_sum_f64(sv);
+    if (lane == 0) red[wave] = sv;
+    __syncthreads();
+    if (tid == 0) {
+        double x = 0.0;
+        for (int w = 0; w < 16; ++w) x += red[w];
+        x = kss - x;
+        if (!(x > 1e-15)) x = 1e-15;
+        var[i] = x + add;
+    }
+}
+
+// stages per workgroup: two workgroups per CU, all resident at once, every one the same share of the triangle (measured at
+// Np = 8192, 32 / 64 test rows, variance stage: 512 shares 0.066 / 0.098 ms, 768 with three workgroups per CU 0.067 / 0.115,
+// 1024 0.069 / 0.102 -- more shares are more planes)
+int predv_mfma2_stages(int Np) {
+    const int NG = Np >> 6, T = NG * (NG + 1);
+    const int Lq = (T + 511) / 512;
+    return Lq < 16 ? 16 : Lq;
+}
+// does the register-staged form pay?  Variance stage first form / this one, ms, at 16 / 32 / 48 / 64 test rows (r06 lab notes):
+//   Np = 2048: 0.016 / 0.015, 0.022 / 0.021, 0.026 / 0.026, 0.029 / 0.031      Np = 3072: 0.019 / 0.017, 0.031 / 0.022, 0.036 / 0.028, 0.041 / 0.033
+//   Np = 4096: 0.024 / 0.024, 0.036 / 0.030, 0.043 / 0.038, 0.053 / 0.048      Np = 6144: 0.038 / 0.032, 0.053 / 0.038, 0.064 / 0.047, 0.080 / 0.057
+//   Np = 8192: 0.065 / 0.053, 0.088 / 0.061, 0.103 / 0.075, 0.127 / 0.092
+bool predv_mfma2_pays(int rows, int Np) { return rows > 4 && Np >= 3072; }
+
+void launch_predv_mfma2(hipStream_t s, int RT, const double* W, const double* S, double* Vp, int ld, int Np,
+                        const double* alpha, double* mean, int rows) {
+    RT = RT <= 1 ? 1 : (RT == 2 ? 2 : (RT == 3 ? 3 : 4));
+    const int NG = Np >> 6, T = NG * (NG + 1), L = predv_mfma2_stages(Np);
+    const dim3 grid((T + L - 1) / L + mean_blocks(rows)), blk(256);
+    // (two stages ahead: four measured the same or slower -- 0.070 / 0.102 ms -- the product is bound by the issue rate of
+    // v_mfma_f64_16x16x4, not by what is in flight)
+#define PREDV_MFMA2(rt) hipLaunchKernelGGL((mfgp_predv_mfma2_f64<rt, 2>), grid, blk, 0, s, W, S, Vp, ld, Np, alpha, mean, rows, L)
+    if (RT == 1) PREDV_MFMA2(1);
+    else if (RT == 2) PREDV_MFMA2(2);
+    else if (RT == 3) PREDV_MFMA2(3);
+    else PREDV_MFMA2(4);
+#undef PREDV_MFMA2
+}
+void launch_predv_finish_planes(hipStream_t s, int rows, const double* Vp, int ld, int Np, double kss, double add, double* var) {
+    hipLaunchKernelGGL(mfgp_predv_finish_planes_f64, dim3(rows), dim3(1024), 0, s, Vp, ld, Np, predv_mfma2_stages(Np), kss, add, var);
 }
 
 void launch_predv_rows(hipStream_t s, int R, const double* W, const double* S, double* V, int ld, int Np, const double* alpha,

@@ -576,10 +576,12 @@ def test_low_fidelity_handle_reused_at_another_input_width(engine_cls):
     lf.close(); hf.close()
 
 
-@pytest.mark.parametrize("N", [97, 700, 2100])
+@pytest.mark.parametrize("N", [97, 700, 2100, 4700])
 def test_skinny_variance_path_for_small_batches(engine, N):
     """N* <= 64 (the DIRECT callback / acquisition case) takes the bandwidth-bound skinny product
-    instead of the padded tile GEMM: oracle tolerance, and agreement with the tile-GEMM path on the same rows."""
+    instead of the padded tile GEMM: oracle tolerance, and agreement with the tile-GEMM path on the same rows.  (N = 4700:
+    Np = 4736 = 74 groups of 64 rows, past the size (Np = 3072) from which 9 .. 64 rows take the register-staged form with its shares
+    of the triangle and partial planes; 74 (74 + 1) stages do not divide by the share.)"""
     rng = np.random.default_rng(N)
     X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
     Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
@@ -654,6 +656,18 @@ def test_north_star_size_n8192_against_oracle(engine):
     Xsa = np.hstack([Xs, cases.lf_4d(Xs)[:, None]])
     nlml, grad, mean, v = _run(engine, parts, theta, noise, Xa, Y, Xsa)
     _check_all(parts, theta, noise, Xa, Y, st, Xsa, nlml, grad, mean, v, "north_star/N=8192")   # incl. GPy's explicit-inverse variance
+    # the few-row forms of the variance product at this size (1-8 rows on the VALU, 9-64 on the matrix pipe in its register-staged
+    # form: partial planes per share of the triangle, summed by the finishing launch) against the same oracle state and against the
+    # 65-row tile-GEMM result above
+    mu, var_tri = orc.predict_stable(parts, theta, noise, Xa, st, Xsa)
+    ys = np.abs(Y).max()
+    for ns in (1, 8, 9, 16, 17, 32, 47, 64):
+        m, vv = engine.predict(Xsa[:ns], want_var=True, include_noise=True)
+        tol.check_pred(m, mu[:ns], ys, label="north_star/ns=%d" % ns, what="mean")
+        tol.check_pred(vv, var_tri[:ns] , ys, label="north_star/ns=%d" % ns, what="var_triangular")
+        np.testing.assert_allclose(vv, v[:ns], rtol=0, atol=1e-12)
+        assert np.array_equal(m, mean[:ns])
+        assert np.array_equal(vv, engine.predict(Xsa[:ns], want_var=True, include_noise=True)[1])      # deterministic
 
 
 def test_randomised_parity_soak_across_planner_boundaries():

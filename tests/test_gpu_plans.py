@@ -161,3 +161,54 @@ def test_process_wide_switches_in_a_process_of_their_own():
             tol.check_pred(np.array(o["v%d" % ns]), var[:ns], np.abs(Y).max(), what="var")
     for ns in (1, 5, 20, 40):     # the two routes differ in the order of their sums only
         np.testing.assert_allclose(runs["default"]["v%d" % ns], runs["switched"]["v%d" % ns], rtol=0, atol=1e-12)
+
+
+_PREDV2_DRIVER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from multifidelity_datafusion_gps_amd._lib import Engine
+from tests import cases
+rng = np.random.default_rng(9)
+N = 7400                                    # Np = 7424 (58 leaf blocks, 116 groups of 64 rows)
+X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
+Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+e = Engine(0)
+e.set_data(Xa, Y); e.set_kernel(cases.composite(4, 1))
+e.factorize(np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var())
+Xs = rng.uniform(size=(64, 5))
+out = {}
+for ns in (12, 16, 20, 40, 64):
+    m, v = e.predict(Xs[:ns])
+    out["m%d" % ns] = m.tolist(); out["v%d" % ns] = v.tolist()
+m, v = e.predict(rng.uniform(size=(200, 5))[:65] * 0 + np.vstack([Xs, Xs[:1]]))     # 65 rows: the tile GEMM, either way
+out["m65"] = m.tolist(); out["v65"] = v.tolist()
+e.close()
+print(json.dumps(out))
+"""
+
+
+def test_the_two_forms_of_the_9_to_64_row_variance_product_agree():
+    """MFGP_PREDV2=0 keeps every 9 .. 64-row predict on round 6's first matrix-pipe form (S through LDS-DMA, a workgroup per 16-row
+    block); the default takes the register-staged form from the sizes at which it pays (shares of the triangle, partial planes).
+    Read once per process: two child processes predict the same 12 / 16 / 20 / 40 / 64 rows at N = 7400; the means are bitwise
+    equal (the same mean blocks ride in either launch), the variances agree to 1e-12 with each other and with the 65-row tile
+    GEMM of the same rows."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for name, env in (("default", {}), ("first_form", {"MFGP_PREDV2": "0"})):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _PREDV2_DRIVER, root], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = runs["default"], runs["first_form"]
+    assert a["m65"] == b["m65"] and a["v65"] == b["v65"]
+    for ns in (12, 16, 20, 40, 64):
+        assert a["m%d" % ns] == b["m%d" % ns] == a["m65"][:ns]
+        np.testing.assert_allclose(a["v%d" % ns], b["v%d" % ns], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(a["v%d" % ns], a["v65"][:ns], rtol=0, atol=1e-12)
+        assert a["v%d" % ns] != b["v%d" % ns] or ns == 0      # (different orders of the k sums: the switch did switch)
