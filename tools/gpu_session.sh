@@ -110,6 +110,10 @@ profile)
     rm -rf $out/apmc_$c
   done
   (cd $R && python3 tools/pmc_summary.py 8192 $out/pmc.json FETCH_SIZE=$out/pmc_FETCH_SIZE_time_eval_8192.csv WRITE_SIZE=$out/pmc_WRITE_SIZE_time_eval_8192.csv ADAPT_FETCH_SIZE=$out/pmc_FETCH_SIZE_predv_once_8192.csv ADAPT_WRITE_SIZE=$out/pmc_WRITE_SIZE_predv_once_8192.csv ADAPT_STATS=$out/adapt_kernel_stats.csv > $out/pmc_summary.log 2>&1; tail -60 $out/pmc_summary.log)
+  echo "== the adaptation loop's kernels: SQ counters (wait / active / matrix-pipe busy fractions)"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $out/asq -- python3 $R/tools/predv_once.py 8192 > $out/asq.log 2>&1
+  (cd $R && python3 tools/sq_summary.py $out/asq > $out/adapt_sq.txt 2>&1; cat $out/adapt_sq.txt)
+  rm -rf $out/asq
   echo "== PMC pass: matrix-pipe busy"
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmcA_eval_d -- python3 $R/tools/time_eval.py 8192 > $out/pmcA_eval.log 2>&1
   f=$(find $out/pmcA_eval_d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmcA_eval.csv

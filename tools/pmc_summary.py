@@ -63,8 +63,8 @@ def sweep_sum(rows):
     return sum(v for _, k, v in rows[kb[-2]:kb[-1]] if k in SWEEP)
 
 
-ADAPT = ("mfgp_trimv_f64", "mfgp_predv_rows_f64", "mfgp_predv_rows_lds_f64", "mfgp_predv_mfma_f64", "mfgp_panel_fragments_f64",
-         "mfgp_predv_finish_f64", "mfgp_append_finish_f64", "mfgp_kbuild_rbf2_f64<1>")
+ADAPT = ("mfgp_trimv_f64", "mfgp_predv_rows_f64", "mfgp_predv_rows_lds_f64", "mfgp_predv_mfma_f64", "mfgp_predv_mfma2_f64",
+         "mfgp_panel_fragments_f64", "mfgp_predv_finish_f64", "mfgp_predv_finish_planes_f64", "mfgp_append_finish_f64", "mfgp_kbuild_rbf2_f64<1>")
 
 
 def short(name):
@@ -100,7 +100,7 @@ def adapt_block(n, files):
                     dur[k] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "min_us": float(row["MinNs"]) / 1e3}
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes, --kernel-trace only) and rocprofv3 --kernel-trace --stats (a "
                    "third run, no counters: the durations) over `python3 tools/predv_once.py %d` (N = %d - 64 rows, Np = %d): 5 predict calls "
-                   "each at N* = 1, 2, 4, 8, 16, 32, 64, then 5 rank-1 appends.  Per kernel instantiation: median over its launches; FETCH_SIZE "
+                   "each at N* = 1, 2, 4, 8, 16, 32, 48, 64, then 5 rank-1 appends.  Per kernel instantiation: median over its launches; FETCH_SIZE "
                    "doubled as the guide prescribes for wide coalesced reads.  algorithmic_bytes: one read of the triangle of the mirrored "
                    "inverse (4 Np (Np + 1)) + R right-hand-side rows of 8 Np bytes; achieved = algorithmic bytes / average duration of the "
                    "un-countered run." % (n, n, Np)}
@@ -110,7 +110,7 @@ def adapt_block(n, files):
         R = None
         if k.startswith(("mfgp_trimv_f64", "mfgp_predv_rows_f64", "mfgp_predv_rows_lds_f64")):
             R = int(k.split("<")[1].split(",")[0])
-        elif k.startswith("mfgp_predv_mfma_f64"):
+        elif k.startswith(("mfgp_predv_mfma_f64", "mfgp_predv_mfma2_f64")):       # (the partial planes of the second are not algorithmic)
             R = 16 * int(k.split("<")[1].split(",")[0])
         if R is not None:
             e["algorithmic_bytes"] = tri + R * 8 * Np

@@ -1,4 +1,4 @@
-"""A handful of predict calls (N* = 1, 8, 16, 32, 64) and rank-1 appends at N = 8128 (Np = 8192) -- the workload of the counter
+"""A handful of predict calls (N* = 1, 2, 4, 8, 16, 32, 48, 64) and rank-1 appends at N = 8128 (Np = 8192) -- the workload of the counter
 passes over the adaptation loop's kernels (tools/gpu_session.sh adapt): few dispatches, one kernel name per shape."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
 e = Engine(0)
 e.set_data(Xa[:n0], Y[:n0]); e.set_kernel(cases.composite(4, 1))
 e.factorize(np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01)
-for ns in (1, 2, 4, 8, 16, 32, 64):
+for ns in (1, 2, 4, 8, 16, 32, 48, 64):
     for _ in range(reps):
         e.predict(Xa[:ns] + 0.01)
 for i in range(reps):
