@@ -239,6 +239,17 @@ constexpr int TRIMV1_JR = 4, TRIMV1_U = 2;
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows, int ncols, int mode, int nbatch,
                    long long mstride, long long xstride, long long ystride) {
     if (nrows <= 0) return;
+    if (mode == 2 && nrows <= 4096 && nbatch <= 1) {
+        // full-length rows, not enough of them to fill the chip with 4-row waves (the means of a predict; the low-fidelity means of a
+        // level-chained one, N_lf columns long): a wave walks ITS rows alone, so what counts is how much of a row is in flight -- one
+        // row per wave and 8 chunks per batch (2 x 8 KiB) instead of 4 rows x 2 chunks.  Measured, mean-only predict call old / new,
+        // ms: N = 16384: 1 row 0.060 / 0.037 (the kernel 36 -> 7 us), 128 rows 0.114 / 0.057, 1024 rows 0.138 / 0.084, 4096 rows
+        // 0.282 / 0.270, 8192 rows 0.473 / 0.554; N = 8192: 128 rows 0.071 / 0.043, 4096 rows 0.140 / 0.126, 8192 rows the same.
+        // The same bits either way: a row's sum does not depend on (JR, U).
+        hipLaunchKernelGGL((mfgp_trimv_f64<1, 1, 8>), dim3(trimv_blocks(nrows, 1), 1), dim3(256), 0, s, M, ld, x, 0, y, 0, nrows, ncols, mode,
+                           mstride, xstride, ystride);
+        return;
+    }
     hipLaunchKernelGGL((mfgp_trimv_f64<1, TRIMV1_JR, TRIMV1_U>), dim3(trimv_blocks(nrows, TRIMV1_JR), nbatch > 0 ? nbatch : 1), dim3(256), 0, s, M, ld,
                        x, 0, y, 0, nrows, ncols, mode, mstride, xstride, ystride);
 }
