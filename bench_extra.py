@@ -151,6 +151,18 @@ def cfg3_cfg5(mf, evals=20):
     c5["nstar1_variance_stage_frac"] = round(tri / (var_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if var_ms > 0 else None
     c5["variance_stage_is"] = ("mfgp_predv_rows_f64 (V = k(x*,X) L^-T on the VALU behind one coalesced read of the triangle, + the mean) "
                                "+ mfgp_predv_finish_f64, between two HIP events on the engine's stream; algorithmic bytes = 4 Np (Np + 1)")
+    # the call the reference's loop issues per acquisition evaluation (src/abstractMFGP.py:317-359 -> predict of the NARGP model,
+    # src/MFDataFusion.py:106-156): the low-fidelity mean of the test row (N_lf = 16384 columns) and the high-fidelity predict, the
+    # hand-over on the device
+    xb = rng.uniform(size=(1, 4))
+    for _ in range(5):
+        m.predict(xb)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.predict(xb)
+    c5["nstar1_model_predict_call_ms"] = round((time.perf_counter() - t0) * 1e3 / reps, 4)
+    c5["nstar1_model_predict_is"] = ("NARGP.predict of one row: mfgp_predict_chained (LF panel row + mean over 16384 columns, augmented row, HF panel, "
+                                     "variance product, finish: 7 launches + one upload), host clock around the Python call")
     ts = []
     Xn = rng.uniform(size=(12, 4))
     Xn = np.hstack([Xn, m.lf_model.predict(Xn)[0]]) if Xa.shape[1] == 5 else Xn
