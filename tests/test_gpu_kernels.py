@@ -179,3 +179,30 @@ def test_adaptation_loop_calls_stay_at_the_read_roofline(engine_cls):
     assert 0.0 < stage < 0.07, stage
     assert call < 0.12, call
     assert append < 0.25, append
+
+
+def test_register_staged_variance_product_at_every_block_count(engine_cls):
+    """mfgp_predv_mfma2_f64 cuts the triangle into equal shares of L = max(16, ceil(T / 512)) stages, T = NG (NG + 1), NG = Np / 64: every
+    Np from 3072 to 8192 (41 block counts: shares that end inside a group, on a group's edge, a last share shorter than L, L = 16 .. 33),
+    a random N inside the block and random row counts of every row-tile count, against the 65-row tile-GEMM product of the same rows
+    (itself held to the oracle elsewhere): variances to 1e-12, means bitwise, twice the same bits."""
+    from tests import cases
+    e = engine_cls(0)
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for Np in range(3072, 8192 + 1, 128):
+        N = Np - int(rng.integers(0, 128))
+        X = rng.uniform(size=(N, 4)); Y = cases.hf_4d(X)
+        Xa = np.hstack([X, cases.lf_4d(X)[:, None]])
+        e.set_data(Xa, Y); e.set_kernel(cases.composite(4, 1))
+        e.factorize(np.array([1.2, 1.1, 0.9, 0.6, 0.4, 0.8]), 0.01 * Y.var())
+        Xs = rng.uniform(size=(65, 5))
+        m_big, v_big = e.predict(Xs)
+        for ns in (int(rng.integers(5, 17)), int(rng.integers(17, 33)), int(rng.integers(33, 49)), int(rng.integers(49, 65))):
+            m, v = e.predict(Xs[:ns])
+            assert np.array_equal(m, m_big[:ns]), (Np, N, ns)
+            worst = max(worst, float(np.abs(v - v_big[:ns]).max()))
+            np.testing.assert_allclose(v, v_big[:ns], rtol=0, atol=1e-12, err_msg="Np=%d N=%d ns=%d" % (Np, N, ns))
+            assert np.array_equal(v, e.predict(Xs[:ns])[1])
+    print("register-staged product vs tile GEMM, 41 block counts x 4 row counts: worst |dv| %.2e" % worst)
+    e.close()
