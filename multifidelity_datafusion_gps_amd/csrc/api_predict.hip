@@ -37,7 +37,8 @@ int32_t mfgp_append_row(mfgp_handle* h, const double* x_new, double y_new) {
     // k = K(x_new, X[0:n]) -> row 0 of W (0 in the padded columns) ; l = X k ; w = X^T l.  The first pass runs to the end of
     // row n's 128-block: rows n .. of S are still identity rows, so l[n ..] = k[n ..] = 0 -- the second pass reads l in whole
     // 128-column chunks (masked by its column range, but the operand has to be finite)
-    launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np);
+    if (!launch_kbuild_panel_few(s, h->spec, few_rows_packed(h->dXs, D, 1), 1, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np))
+        launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, n, (int)Np, h->buf[BUF_W], (int)Np);
     launch_rowdot(s, h->buf[BUF_S], (int)Np, h->buf[BUF_W], h->dvec, ((n >> 7) + 1) << 7, (int)Np, 0);
     launch_rowdot(s, h->buf[BUF_S], (int)Np, h->dvec, h->dvec2, n, n, 1);
     const double kdiag = prior_variance(h) + h->noise + h->jitter;
@@ -85,8 +86,16 @@ int ensure_xs(mfgp_handle* h, int rows_p) {
 // mean (and variance) of the `rows` test rows already resident (zero padded to rows_p) in h->dXs, in stream order
 // `pinned`: the results are written by the kernels straight into the handle's device-mapped pinned memory and copied to
 // mean / var by the host after the synchronisation (no device-to-host copy commands)
+static bool skinny_enabled() {
+    static const bool on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
+    return on;
+}
+// `src`: where the (at most 4) test rows are, if not in h->dXs -- a level-chained predict hands its augmented rows over unassembled
+// (only when few_source_ok(h, rows) said the panel can be built from them)
+static bool few_source_ok(const mfgp_handle* h, int64_t rows) { return skinny_enabled() && rows <= 4 && kbuild_panel_few_ok(h->spec); }
 static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean, double* var, int want_var,
-                         int include_noise, double* pan_ms, double* var_ms, int64_t* timed_rows, bool pinned = false) {
+                         int include_noise, double* pan_ms, double* var_ms, int64_t* timed_rows, bool pinned = false,
+                         const FewRows* src = nullptr) {
     hipStream_t s = h->stream;
     double* const mean_dev = pinned ? h->dio + mfgp_handle::IO_IN : h->dvec;
     double* const var_dev = pinned ? h->dio + mfgp_handle::IO_IN + mfgp_handle::IO_OUT : h->dvec2;
@@ -96,8 +105,7 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     // trimv_f64.hip -- a few rows on the VALU behind one coalesced read of the triangle, up to 64 rows on the matrix pipe with S
     // staged in the same coalesced shape (through registers from Np = 3072, by LDS-DMA below); either way: panel, product (+ the
     // means), ONE finishing launch.  MFGP_PREDV2=0 keeps the matrix-pipe products on the LDS-DMA form at every size.
-    static const bool skinny_on = !(getenv("MFGP_SKINNY") && atoi(getenv("MFGP_SKINNY")) == 0);
-    const bool few = skinny_on && rows <= 64;
+    const bool few = skinny_enabled() && rows <= 64;
     static const bool predv2_on = !(getenv("MFGP_PREDV2") && atoi(getenv("MFGP_PREDV2")) == 0);
     if (want_var && !few && h->pl.predv_rows != rows_p) {
         // (re)plan the variance product for this panel height; keep the cholinv/kinv tasks
@@ -108,7 +116,15 @@ static int predict_chunk(mfgp_handle* h, int64_t rows, int rows_p, double* mean,
     const bool stamp = h->timing && (!few || h->timing_small);
     if (stamp) HIPCHK(h, hipEventRecord(h->ev[6], s));
     if (few) {
-        launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
+        // (up to 4 rows -- the products below then read 1, 2 or 4 rows of the panel, the means `rows` -- one thread per training point
+        // instead of 64-row tiles, where the kernel description allows)
+        const int Rfew = rows <= 1 ? 1 : (rows <= 2 ? 2 : 4);
+        const FewRows packed = few_rows_packed(h->dXs, h->D, Rfew);
+        if (!(rows <= 4 && launch_kbuild_panel_few(s, h->spec, src ? *src : packed, Rfew, h->dX, (int)h->N, (int)Np, h->buf[BUF_W],
+                                                   (int)Np))) {
+            if (src) return fail(h, -1, "predict_chunk: unassembled test rows without the few-row panel");
+            launch_kbuild_panel(s, h->spec, h->dXs, 64, h->dX, (int)h->N, (int)Np, h->buf[BUF_W], (int)Np);
+        }
         h->launches += 1;
         if (stamp) HIPCHK(h, hipEventRecord(h->ev[7], s));
         if (want_var) {
@@ -274,11 +290,18 @@ static int chain_lf_means(mfgp_handle* lf, const double* Xhost, int64_t rows, co
         const int n = (int)std::min(Np, T - t0);
         const int n_p = (n + 63) / 64 * 64;      // the panel kernel works in 64-row tiles (round 6: was 128 -- a one-point callback built and
                                                  // read a 128 x N_lf panel, 16 MB at N_lf = 16384, for one row of it)
-        launch_stencil_rows(s, lf->dXc, lf->doffs, d, c, t0, n, n_p, lf->dXs);
-        launch_kbuild_panel(s, lf->spec, lf->dXs, n_p, lf->dX, (int)lf->N, (int)Np, lf->buf[BUF_W], (int)Np);
+        // up to 4 rows: the stencil rows are formed inside the few-row panel kernel (covariance.hip) -- one launch less
+        const FewRows st{lf->dXc, lf->doffs, nullptr, d, c, 0, n, (long long)t0};
+        if (n <= 4 && launch_kbuild_panel_few(s, lf->spec, st, n <= 1 ? 1 : (n <= 2 ? 2 : 4), lf->dX, (int)lf->N, (int)Np,
+                                              lf->buf[BUF_W], (int)Np)) {
+            lf->launches += 2;
+        } else {
+            launch_stencil_rows(s, lf->dXc, lf->doffs, d, c, t0, n, n_p, lf->dXs);
+            launch_kbuild_panel(s, lf->spec, lf->dXs, n_p, lf->dX, (int)lf->N, (int)Np, lf->buf[BUF_W], (int)Np);
+            lf->launches += 3;
+        }
         // the means of the n real rows only, straight to their place in dm
         launch_rowdot(s, lf->buf[BUF_W], (int)Np, lf->dalpha, lf->dm + t0, n, (int)Np, 2);
-        lf->launches += 3;
     }
     return 0;
 }
@@ -342,14 +365,20 @@ int32_t mfgp_predict_chained(mfgp_handle* h, mfgp_handle* lf, const double* Xsta
         // input) and this level's predict follow each other in stream order -- no event, no cross-stream hop (~12 us)
         rc = chain_lf_means(lf, Xstar + r0 * d, rows, offsets, c, h->stream);
         if (rc) return fail(h, rc, std::string("mfgp_predict_chained: low-fidelity level: ") + lf->err);
-        launch_assemble_aug(h->stream, lf->dXc, lf->dm, (int)rows, rows_p, d, c, h->dXs, D);
+        // up to 4 rows: this level's few-row panel kernel reads the augmented rows [Xc[i] | m[i]] where they are -- no assembling launch
+        const bool unassembled = !aug_out && few_source_ok(h, rows);
+        const FewRows augsrc{lf->dXc, nullptr, lf->dm, d, 1, c, (int)rows, 0};
+        if (!unassembled) {
+            launch_assemble_aug(h->stream, lf->dXc, lf->dm, (int)rows, rows_p, d, c, h->dXs, D);
+            h->launches += 1;
+        }
         if (aug_out)
             HIPCHK(h, hipMemcpyAsync(aug_out + r0 * D, h->dXs, (size_t)rows * D * sizeof(double), hipMemcpyDeviceToHost,
                                      h->stream));
-        h->launches += lf->launches + 1;
+        h->launches += lf->launches;
         lf->launches = 0;
         rc = predict_chunk(h, rows, rows_p, mean + r0, want_var ? var + r0 : nullptr, want_var, include_noise, &pan_ms,
-                           &var_ms, &timed_rows, rows_p <= mfgp_handle::IO_OUT);
+                           &var_ms, &timed_rows, rows_p <= mfgp_handle::IO_OUT, unassembled ? &augsrc : nullptr);
         if (rc) return rc;
     }
     predict_account(h, Nstar, pan_ms, var_ms, want_var != 0, timed_rows);

@@ -419,6 +419,74 @@ void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* X
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_PANEL>), dim3(Np / KT, Nsp / KT), dim3(256), kb_lds(spec.D), s,
                        spec, Xs, X, N, Np, Kx, ld, 0);
 }
+// A panel of 1, 2 or 4 test rows (the N* = 1 callback of the reference's maximiser, the low-fidelity level's row of a level-chained
+// predict, the new row of a rank-1 append): one thread per training point instead of 64 x 64 tiles of which one row is wanted.  The
+// arithmetic of a pair is kbuild_rbf2_body's, operation for operation (squared distances by fma in column order, test minus training
+// point; the same exp_nonpos) -- the panel rows are the same bits as the tile kernel's, and so are the means formed from them.
+// The test rows are read where they are (FewRows, mfgp_internal.h): a packed block; the stencil rows Xc[t / c] + offs[t % c] of a
+// level-chained predict (what mfgp_stencil_rows_f64 would write first); or the augmented rows [Xc[t] | m[t]] of its next level (what
+// mfgp_assemble_aug_f64 would) -- two launches less on the chained N* = 1 call.
+__device__ __forceinline__ double few_coord(const FewRows& q, int r, int d) {
+    if (r >= q.n) return 0.0;
+    const long long t = q.t0 + r;
+    if (d < q.da) {
+        double v = q.a[(t / q.c) * q.da + d];
+        if (q.offs) v += q.offs[(t % q.c) * q.da + d];
+        return v;
+    }
+    return q.m[t * q.dm + (d - q.da)];
+}
+template <int R>
+__global__ __launch_bounds__(256) void mfgp_kpanel_few_rbf2_f64(Rbf2Spec sp, FewRows q, const double* __restrict__ X, int N, int Np,
+                                                                double* __restrict__ out, int ld) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Np) return;
+    const int D = sp.D;
+    const double* xj = X + (int64_t)j * D;
+    double r2a[R], r2b[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) r2a[r] = r2b[r] = 0.0;
+    for (int d = sp.b0; d < sp.b1; ++d) {
+        const double x = xj[d];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double df = few_coord(q, r, d) - x;
+            r2b[r] = __builtin_fma(df, df, r2b[r]);
+        }
+    }
+    if (sp.a1 > sp.a0) {
+        for (int d = sp.a0; d < sp.a1; ++d) {
+            const double x = xj[d];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double df = few_coord(q, r, d) - x;
+                r2a[r] = __builtin_fma(df, df, r2a[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        double k = sp.v1 * exp_nonpos(-__builtin_fma(sp.ca, r2a[r], sp.cb * r2b[r]));
+        if (sp.has2) k = __builtin_fma(sp.v2, exp_nonpos(-sp.cc * r2b[r]), k);
+        if (j >= N) k = 0.0;
+        out[(int64_t)r * ld + j] = k;
+    }
+}
+bool kbuild_panel_few_ok(const KernSpecDev& spec) {
+    Rbf2Spec f;
+    return rbf2_match(spec, f);
+}
+// -> false: the kernel description is not one of the fast path's (the caller builds the 64-row tile panel instead)
+bool launch_kbuild_panel_few(hipStream_t s, const KernSpecDev& spec, const FewRows& q, int R, const double* X, int N, int Np,
+                             double* Kx, int ld) {
+    Rbf2Spec f;
+    if (R > 4 || !rbf2_match(spec, f)) return false;
+    const dim3 grid((Np + 255) / 256), blk(256);
+    if (R <= 1) hipLaunchKernelGGL((mfgp_kpanel_few_rbf2_f64<1>), grid, blk, 0, s, f, q, X, N, Np, Kx, ld);
+    else if (R == 2) hipLaunchKernelGGL((mfgp_kpanel_few_rbf2_f64<2>), grid, blk, 0, s, f, q, X, N, Np, Kx, ld);
+    else hipLaunchKernelGGL((mfgp_kpanel_few_rbf2_f64<4>), grid, blk, 0, s, f, q, X, N, Np, Kx, ld);
+    return true;
+}
 void launch_kbuild_full(hipStream_t s, const KernSpecDev& spec, const double* X,
                         int N, int Np, double* out, int ld) {
     hipLaunchKernelGGL((mfgp_kbuild_f64<MODE_FULL>), dim3(Np / KT, Np / KT), dim3(256), kb_lds(spec.D), s,

@@ -85,6 +85,20 @@ void launch_kbuild_tri_batch(hipStream_t s, const KernSpecDev* specs, int nbatch
 //   panel: Kx[r][c] = k(Xs[r], X[c]) for r < Nsp, c < Np (0 for padded columns c >= N)
 void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* Xs, int Nsp,
                          const double* X, int N, int Np, double* Kx, int ld);
+// 1, 2 or 4 test rows (R; rows R .. of the panel are NOT written), read where they are: row r < n is
+//     [ a[(t0 + r) / c][0 .. da) + offs[(t0 + r) % c][0 .. da)  |  m[(t0 + r)][0 .. dm) ]      (offs, m optional; c >= 1)
+// and a zero row from n on.  The fast-path kernel descriptions only -> false otherwise (kbuild_panel_few_ok says which).
+struct FewRows {
+    const double* a;
+    const double* offs;
+    const double* m;
+    int da, c, dm, n;
+    long long t0;
+};
+inline FewRows few_rows_packed(const double* Xs, int D, int n) { return FewRows{Xs, nullptr, nullptr, D, 1, 0, n, 0}; }
+bool kbuild_panel_few_ok(const KernSpecDev& spec);
+bool launch_kbuild_panel_few(hipStream_t s, const KernSpecDev& spec, const FewRows& q, int R, const double* X, int N, int Np,
+                             double* Kx, int ld);
 //   rows [row_begin, row_end) (multiples of 64) of Ky, all Np columns, written at their place in A
 void launch_kbuild_rows(hipStream_t s, const KernSpecDev& spec, const double* X, int N, int Np,
                         double* A, int ld, int row_begin, int row_end);

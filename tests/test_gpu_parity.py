@@ -492,7 +492,10 @@ def test_wide_inputs_up_to_the_column_limit(engine):
         engine.set_data(np.zeros((4, 33)), np.zeros(4))
 
 
-@pytest.mark.parametrize("n_lf,n_hf,n_star,nder", [(100, 40, 300, 2), (260, 150, 37, 1), (50, 10, 1, 0)])
+@pytest.mark.parametrize("n_lf,n_hf,n_star,nder", [(100, 40, 300, 2), (260, 150, 37, 1), (50, 10, 1, 0),
+                                                     # up to 4 test rows: the few-row panel kernel reads the stencil rows (LF level: while
+                                                     # rows x stencil <= 4) and the augmented rows (HF level) where they are
+                                                     (120, 60, 1, 1), (120, 60, 2, 0), (120, 60, 4, 0), (120, 60, 3, 1), (120, 60, 4, 2)])
 def test_device_resident_level_chaining_equals_host_hand_over(engine, engine_cls, n_lf, n_hf, n_star, nder):
     """mfgp_augment / mfgp_predict_chained keep the low-fidelity stencil means on the device.
     Bitwise the numbers of the host route (lf predict -> concatenate -> hf predict, src/MFDataFusion.py:177-208),
@@ -538,6 +541,10 @@ def test_device_resident_level_chaining_equals_host_hand_over(engine, engine_cls
     assert np.array_equal(m_dev, m_host) and np.array_equal(v_dev, v_host)
     m2, none = hf.predict_chained(lf, Xs, offs, want_var=False)
     assert none is None and np.array_equal(m2, m_host)
+    m3, v3 = hf.predict_chained(lf, Xs, offs)                       # (no augmented rows asked for: nothing is assembled for <= 4 rows)
+    assert np.array_equal(m3, m_host) and np.array_equal(v3, v_host)
+    m4, v4 = hf.predict(aug_s)                                        # ... and the plain predict after it still sees ITS rows
+    assert np.array_equal(m4, m_host) and np.array_equal(v4, v_host)
     # argument errors are reported, not executed
     with pytest.raises((RuntimeError, ValueError)):
         hf.predict_chained(hf, Xs, offs)
