@@ -426,16 +426,6 @@ void launch_kbuild_panel(hipStream_t s, const KernSpecDev& spec, const double* X
 // The test rows are read where they are (FewRows, mfgp_internal.h): a packed block; the stencil rows Xc[t / c] + offs[t % c] of a
 // level-chained predict (what mfgp_stencil_rows_f64 would write first); or the augmented rows [Xc[t] | m[t]] of its next level (what
 // mfgp_assemble_aug_f64 would) -- two launches less on the chained N* = 1 call.
-__device__ __forceinline__ double few_coord(const FewRows& q, int r, int d) {
-    if (r >= q.n) return 0.0;
-    const long long t = q.t0 + r;
-    if (d < q.da) {
-        double v = q.a[(t / q.c) * q.da + d];
-        if (q.offs) v += q.offs[(t % q.c) * q.da + d];
-        return v;
-    }
-    return q.m[t * q.dm + (d - q.da)];
-}
 template <int R>
 __global__ __launch_bounds__(256) void mfgp_kpanel_few_rbf2_f64(Rbf2Spec sp, FewRows q, const double* __restrict__ X, int N, int Np,
                                                                 double* __restrict__ out, int ld) {
@@ -443,24 +433,35 @@ __global__ __launch_bounds__(256) void mfgp_kpanel_few_rbf2_f64(Rbf2Spec sp, Few
     if (j >= Np) return;
     const int D = sp.D;
     const double* xj = X + (int64_t)j * D;
+    // the R test rows (wave-uniform: scalar loads): row r = [pa[r][0 .. da) + po[r][0 .. da) | pm[r][0 .. dm)], a zero row from n on
+    const double *pa[R], *po[R], *pm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = (int)q.t0 + r;
+        pa[r] = q.a + (int64_t)(t / q.c) * q.da;
+        po[r] = q.offs ? q.offs + (int64_t)(t % q.c) * q.da : nullptr;
+        pm[r] = q.m ? q.m + (int64_t)t * q.dm : nullptr;
+    }
     double r2a[R], r2b[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) r2a[r] = r2b[r] = 0.0;
-    for (int d = sp.b0; d < sp.b1; ++d) {
-        const double x = xj[d];
+    const bool two = sp.a1 > sp.a0;
+    for (int d0 = 0; d0 < D; d0 += 4) {
+        double x[4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double df = few_coord(q, r, d) - x;
-            r2b[r] = __builtin_fma(df, df, r2b[r]);
-        }
-    }
-    if (sp.a1 > sp.a0) {
-        for (int d = sp.a0; d < sp.a1; ++d) {
-            const double x = xj[d];
+        for (int u = 0; u < 4; ++u) x[u] = xj[min(d0 + u, D - 1)];       // four loads in flight (the rows of X are 8 D bytes apart)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u;
+            const bool inb = d < D && d >= sp.b0 && d < sp.b1, ina = d < D && two && d >= sp.a0 && d < sp.a1;
+            if (!(inb || ina)) continue;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const double df = few_coord(q, r, d) - x;
-                r2a[r] = __builtin_fma(df, df, r2a[r]);
+                double xs = 0.0;
+                if (r < q.n) xs = d < q.da ? (po[r] ? pa[r][d] + po[r][d] : pa[r][d]) : pm[r][d - q.da];
+                const double df = xs - x[u];
+                if (inb) r2b[r] = __builtin_fma(df, df, r2b[r]);      // (ascending d within either range: kbuild_rbf2_body's order)
+                if (ina) r2a[r] = __builtin_fma(df, df, r2a[r]);
             }
         }
     }

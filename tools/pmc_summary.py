@@ -64,7 +64,7 @@ def sweep_sum(rows):
 
 
 ADAPT = ("mfgp_trimv_f64", "mfgp_predv_rows_f64", "mfgp_predv_rows_lds_f64", "mfgp_predv_mfma_f64", "mfgp_predv_mfma2_f64",
-         "mfgp_panel_fragments_f64", "mfgp_predv_finish_f64", "mfgp_predv_finish_planes_f64", "mfgp_append_finish_f64", "mfgp_kbuild_rbf2_f64<1>")
+         "mfgp_panel_fragments_f64", "mfgp_predv_finish_f64", "mfgp_predv_finish_planes_f64", "mfgp_kpanel_few_rbf2_f64", "mfgp_append_finish_f64", "mfgp_kbuild_rbf2_f64<1>")
 
 
 def short(name):
