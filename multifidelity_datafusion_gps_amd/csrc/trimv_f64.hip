@@ -11,6 +11,8 @@
 //   mfgp_predv_mfma2_f64, mfgp_predv_finish_planes_f64   9 .. 64 test rows from Np = 3072: S and a shared W tile staged through registers,
 //                                        equal shares of the triangle per workgroup, partial planes summed by the finish
 //   mfgp_predv_finish_f64                var = max(k** - |V|^2, 1e-15) + noise, one workgroup per test row
+//   mean_segment / mean_row / mfgp_rowmean_f64   the predictive means: a full-length row's sum as the ordered sum of its 2048-column
+//                                        segments' sums, so that a few long rows split along k inside a workgroup (mode 2 of launch_rowdot)
 //
 // One kernel body serves every O(N^2) pass of the path: z = X y and alpha = X^T z behind GPy's dpotrs (a5), the
 // predictive mean K(X*,X) alpha and -- few test rows, the N* = 1 callback of the reference's DIRECT maximiser
@@ -216,15 +218,98 @@ __global__ __launch_bounds__(256) void mfgp_alpha_finish_f64(const double* __res
     trimv_wave<1, JR, U>(S, ld, z, 0, alpha, 0, Np, Np, 1, wv, lane);
 }
 
-// The means of a small predict ride in the variance product's launch: W[i] . alpha for the `rows` real test rows, one row per
-// group (a row's sum is formed in the same order as in launch_rowdot's launches, whatever their shape -- the mean of a test row
-// does not depend on the size of the batch it travels in).  They take the FIRST workgroups of the grid, two rows per wave: as the
+// The means of a small predict ride in the variance product's launch: W[i] . alpha for the `rows` real test rows (the segmented
+// row sums below, the same as launch_rowdot's mode 2 forms them -- the mean of a test row does not depend on the size of the
+// batch it travels in).  They take the FIRST workgroups of the grid, two rows per wave: as the
 // last workgroup of the launch -- rounds 6's first form -- one CU read all the rows alone behind everybody else (64 rows x 64 KiB
 // at N = 8192: a 0.03 - 0.08 ms tail, the whole difference between the 16- and the 8-row product).
 static inline int mean_blocks(int rows) { return ((rows + 1) / 2 + 3) / 4; }
+
+// ---- full-length row sums (the predictive means  W[i] . alpha) ------------------------------------------------------------
+// A row's sum is DEFINED as the sum, in order, of its SEGMENT sums: segment s = the MEAN_SEG chunks (of 128 columns) from
+// s MEAN_SEG on; inside a segment lane l runs one FMA chain over its two columns of every chunk in order, and the 64 chains are
+// folded in the fixed order of wave_sum_f64.  Every mean of the engine is formed this way (mfgp_rowmean_f64 = launch_rowdot's
+// mode 2, the mean blocks of the small predicts' product launches), whoever walks the row: one wave alone, segment after segment,
+// or -- a few rows of many columns, the low-fidelity mean of a level-chained N* = 1 predict is ONE row of N_lf columns -- the eight
+// waves of a workgroup, a segment each (a row of 16384 columns: one round of 2 x 16 KiB requests instead of 64 dependent ones at
+// the start of the round, 8 after the first fix).  The same bits either way, so the mean of a test row does not depend on the
+// batch it travels in.  (Rows of up to MEAN_SEG chunks are one segment: the sums of rounds 1-5.)
+constexpr int MEAN_SEG = 16;
+__device__ __forceinline__ double mean_segment(const double* __restrict__ row, const double* __restrict__ x, int sg, int nchunk,
+                                               int ncols, int lane) {
+    d2_t mv[MEAN_SEG], xv[MEAN_SEG];
+#pragma unroll
+    for (int u = 0; u < MEAN_SEG; ++u) {                      // the whole segment requested at once
+        const int c = min(sg * MEAN_SEG + u, nchunk - 1);
+        mv[u] = *reinterpret_cast<const d2_t*>(row + (c << 7) + 2 * lane);
+        xv[u] = *reinterpret_cast<const d2_t*>(x + (c << 7) + 2 * lane);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < MEAN_SEG; ++u) {
+        const int c = sg * MEAN_SEG + u, k = (c << 7) + 2 * lane;
+        const double m0 = (c < nchunk && k < ncols) ? mv[u].x : 0.0;      // (selects, as everywhere: what lies beyond never reaches a sum)
+        const double m1 = (c < nchunk && k + 1 < ncols) ? mv[u].y : 0.0;
+        acc = __builtin_fma(m0, xv[u].x, acc);
+        acc = __builtin_fma(m1, xv[u].y, acc);
+    }
+    return wave_sum_f64(acc);
+}
+// one wave, one row: every lane returns the row's sum
+__device__ __forceinline__ double mean_row(const double* __restrict__ row, const double* __restrict__ x, int ncols, int lane) {
+    const int nchunk = (ncols + 127) >> 7, nseg = (nchunk + MEAN_SEG - 1) / MEAN_SEG;
+    double tot = 0.0;
+    for (int sg = 0; sg < nseg; ++sg) tot += mean_segment(row, x, sg, nchunk, ncols, lane);
+    return tot;
+}
 __device__ __forceinline__ void predv_mean_block(const double* __restrict__ W, int ld, const double* __restrict__ alpha,
                                                  double* __restrict__ mean, int rows, int Np, int block, int wave, int lane) {
-    trimv_wave<1, 1, 8>(W, ld, alpha, 0, mean, 0, rows, Np, 2, block * 4 + wave, lane);
+    // (two rows per wave, a short and a long end of the list, as the launch's grid was sized: mean_blocks)
+    const int wv = block * 4 + wave;
+    const int ja = wv, jb = rows - 1 - wv;
+    if (ja > jb) return;
+    const double sa = mean_row(W + (int64_t)ja * ld, alpha, Np, lane);
+    if (lane == 0) mean[ja] = sa;
+    if (jb != ja) {
+        const double sb = mean_row(W + (int64_t)jb * ld, alpha, Np, lane);
+        if (lane == 0) mean[jb] = sb;
+    }
+}
+// y[j] = M[j] . x over ncols columns: the eight waves of a workgroup share 8 / wps rows, wps = min(8, segments of a row rounded down
+// to a power of two) waves per row -- wave w of a row takes its segments w, w + wps, ... -- and one lane per row adds the segment
+// sums in order.  (wps = 1: a wave walks its row alone, rows of up to 2048 columns.)
+static inline int rowmean_wps(int ncols) {
+    const int nseg = (((ncols + 127) >> 7) + MEAN_SEG - 1) / MEAN_SEG;
+    return nseg >= 8 ? 8 : (nseg >= 4 ? 4 : (nseg >= 2 ? 2 : 1));
+}
+__global__ __launch_bounds__(512) void mfgp_rowmean_f64(const double* __restrict__ M, int ld, const double* __restrict__ x,
+                                                        double* __restrict__ y, int nrows, int ncols, int wps) {
+    __shared__ double part[512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 8 / wps, slot = wave / wps, w = wave % wps;
+    const int j = blockIdx.x * rpw + slot;
+    const int nchunk = (ncols + 127) >> 7, nseg = (nchunk + MEAN_SEG - 1) / MEAN_SEG;     // (nseg <= 512: launch_rowdot)
+    if (wps == 1) {                                      // (whole workgroup: no barrier ahead)
+        if (j < nrows) {
+            const double sv = mean_row(M + (int64_t)j * ld, x, ncols, lane);
+            if (lane == 0) y[j] = sv;
+        }
+        return;
+    }
+    double* const mine = part + (wps == 8 ? 0 : slot * 8);                                  // (wps < 8: nseg <= 7)
+    if (j < nrows) {
+        const double* row = M + (int64_t)j * ld;
+        for (int sg = w; sg < nseg; sg += wps) {
+            const double sv = mean_segment(row, x, sg, nchunk, ncols, lane);
+            if (lane == 0) mine[sg] = sv;
+        }
+    }
+    __syncthreads();
+    if (w == 0 && lane == 0 && j < nrows) {
+        double tot = 0.0;
+        for (int sg = 0; sg < nseg; ++sg) tot += mine[sg];
+        y[j] = tot;
+    }
 }
 
 static inline int trimv_blocks(int nrows, int JR) {
@@ -239,15 +324,16 @@ constexpr int TRIMV1_JR = 4, TRIMV1_U = 2;
 void launch_rowdot(hipStream_t s, const double* M, int ld, const double* x, double* y, int nrows, int ncols, int mode, int nbatch,
                    long long mstride, long long xstride, long long ystride) {
     if (nrows <= 0) return;
-    if (mode == 2 && nrows <= 4096 && nbatch <= 1) {
-        // full-length rows, not enough of them to fill the chip with 4-row waves (the means of a predict; the low-fidelity means of a
-        // level-chained one, N_lf columns long): a wave walks ITS rows alone, so what counts is how much of a row is in flight -- one
-        // row per wave and 8 chunks per batch (2 x 8 KiB) instead of 4 rows x 2 chunks.  Measured, mean-only predict call old / new,
-        // ms: N = 16384: 1 row 0.060 / 0.037 (the kernel 36 -> 7 us), 128 rows 0.114 / 0.057, 1024 rows 0.138 / 0.084, 4096 rows
-        // 0.282 / 0.270, 8192 rows 0.473 / 0.554; N = 8192: 128 rows 0.071 / 0.043, 4096 rows 0.140 / 0.126, 8192 rows the same.
-        // The same bits either way: a row's sum does not depend on (JR, U).
-        hipLaunchKernelGGL((mfgp_trimv_f64<1, 1, 8>), dim3(trimv_blocks(nrows, 1), 1), dim3(256), 0, s, M, ld, x, 0, y, 0, nrows, ncols, mode,
-                           mstride, xstride, ystride);
+    if (mode == 2 && nbatch <= 1) {
+        // the means: the segmented row sums above, a row's segments spread over up to eight waves (measured, mean-only predict call at
+        // N = 16384, 4-rows-per-wave walk / one row per wave, 8 chunks per batch / this: 1 row 0.060 / 0.034 / 0.026 ms, 64 rows
+        // 0.110 / 0.049 / 0.030, 1024 rows 0.138 / 0.084 / 0.083, 16384 rows 0.868 / 0.873 / 0.856)
+        const int nseg = (((ncols + 127) >> 7) + MEAN_SEG - 1) / MEAN_SEG;
+        int wps = nseg <= 512 ? rowmean_wps(ncols) : 1;      // (the segment sums of a row wait in 512 LDS slots)
+        if (nseg <= 2 && nrows >= 2048) wps = 1;             // (two segments and many rows: 0.059 / 0.080 / 0.159 ms against 0.063 / 0.085 /
+                                                             // 0.168 at 2048 / 4096 / 8192 rows, N = 4096; the same bits)
+        const int rpw = 8 / wps;
+        hipLaunchKernelGGL(mfgp_rowmean_f64, dim3((nrows + rpw - 1) / rpw), dim3(512), 0, s, M, ld, x, y, nrows, ncols, wps);
         return;
     }
     hipLaunchKernelGGL((mfgp_trimv_f64<1, TRIMV1_JR, TRIMV1_U>), dim3(trimv_blocks(nrows, TRIMV1_JR), nbatch > 0 ? nbatch : 1), dim3(256), 0, s, M, ld,
@@ -262,9 +348,7 @@ void launch_alpha_finish(hipStream_t s, const double* S, int ld, const double* z
 
 // Predict with <= 8 test rows: V[i][j] = sum_{k <= j} W[i][k] X[j][k], i < R (R in {1, 2, 4, 8}: the caller rounds its row
 // count up; the panel W holds at least that many rows), j < Np, X = L^-1 read from the lower part of the mirrored S -- and, in
-// the launch's extra last workgroup, the means W[i] . alpha of the `rows` real test rows (the single-vector body over the panel:
-// a row's sum is formed in the same order as in launch_rowdot's launches, whatever their shape -- the mean of a test row does
-// not depend on the size of the batch it travels in).
+// the launch's first workgroups, the means W[i] . alpha of the `rows` real test rows (predv_mean_block).
 template <int R, int JR, int U>
 __global__ __launch_bounds__(256) void mfgp_predv_rows_f64(const double* __restrict__ S, int ld, const double* __restrict__ W,
                                                            double* __restrict__ V, int Np, const double* __restrict__ alpha,
