@@ -38,3 +38,9 @@ print("%-34s %12.2e %12.2e   (%.1e)" % ("NLML, relative", abs(nlml - tr["nlml"])
 print("%-34s %12.2e %12.2e   (%.1e)" % ("mean, max abs", np.abs(mean - tr["mean"]).max(), np.abs(np.ravel(mu) - tr["mean"]).max(), tol.PRED_ABS * cf * ys))
 print("%-34s %12.2e %12.2e   (%.1e)" % ("variance (triangular), max abs", np.abs(np.maximum(var, 1e-15) - tv).max(), np.abs(np.ravel(v_tri) - tv).max(), tol.PRED_ABS * cf * ys))
 print("%-34s %12s %12.2e   (explicit-inverse bound %.1e)" % ("variance (GPy's explicit inverse)", "-", np.abs(np.ravel(v_exp) - tv).max(), tol.explicit_inverse_bound(cond, kss, ys)))
+# the few-row forms of the same predict (1-4 rows: few-row panel kernel + VALU product; 5-64: the matrix-pipe product with its partial
+# planes; the means in the product launches' mean blocks), against the same quad values
+for ns in (1, 2, 4, 8, 16, 32, 64):
+    m, v = e.predict(Xsa[:ns], want_var=True, include_noise=False)
+    print("%-34s %12.2e %12.2e   (mean / variance, max abs against the quad values; 256-row call: the rows above)"
+          % ("predict of the first %d rows" % ns, np.abs(m - tr["mean"][:ns]).max(), np.abs(np.maximum(v, 1e-15) - tv[:ns]).max()))
